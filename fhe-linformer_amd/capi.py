@@ -1,0 +1,184 @@
+"""ctypes binding of include/fhelin.h (test / bench harness only; the product is the .so)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class FhelinError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"fhelin error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("log_n", C.c_int32), ("n_q", C.c_int32), ("first_bits", C.c_int32), ("scale_bits", C.c_int32),
+        ("n_p", C.c_int32), ("special_bits", C.c_int32), ("dnum", C.c_int32), ("log_slots", C.c_int32),
+        ("hamming", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64),
+    ]
+
+
+# Parameter presets.  "reference" = literal values of reference src/FHEController.cpp:6-35 (N=2^15, depth 27
+# -> 28 Q limbs, dnum 4 -> alpha 7, 7 special primes); "bench" = BASELINE.json synthetic config
+# (N=2^16, 24 limbs, k=6); "deep" = config 5 (N=2^17, 30 limbs, k=8); "toy*" = small rings for fast tests.
+PRESETS = {
+    "bench": dict(log_n=16, n_q=24, first_bits=55, scale_bits=52, n_p=6, special_bits=60, dnum=4, log_slots=14, hamming=192),
+    "reference": dict(log_n=15, n_q=28, first_bits=55, scale_bits=52, n_p=7, special_bits=60, dnum=4, log_slots=14, hamming=192),
+    "deep": dict(log_n=17, n_q=30, first_bits=55, scale_bits=52, n_p=8, special_bits=60, dnum=4, log_slots=14, hamming=192),
+    "toy": dict(log_n=12, n_q=6, first_bits=55, scale_bits=52, n_p=2, special_bits=60, dnum=3, log_slots=11, hamming=64),
+    "toy13": dict(log_n=13, n_q=7, first_bits=55, scale_bits=52, n_p=3, special_bits=60, dnum=3, log_slots=12, hamming=64),
+}
+
+
+def library_path():
+    return os.path.join(_HERE, "libfhelin_amd.so")
+
+
+def load_library():
+    """Load libfhelin_amd.so; raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise FhelinError(-1, f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp, i32, u64p, f32p = C.c_void_p, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_float)
+    sigs = {
+        "fhelin_last_error": (C.c_char_p, []),
+        "fhelin_version": (C.c_char_p, []),
+        "fhelin_ctx_create": (i32, [C.POINTER(Params), C.POINTER(vp)]),
+        "fhelin_ctx_destroy": (None, [vp]),
+        "fhelin_ctx_info": (i32, [vp, C.POINTER(Params), C.POINTER(i32), C.POINTER(i32)]),
+        "fhelin_ctx_moduli": (i32, [vp, u64p, i32]),
+        "fhelin_ctx_roots": (i32, [vp, u64p, i32]),
+        "fhelin_ctx_scaling_factors": (i32, [vp, C.POINTER(C.c_double), i32]),
+        "fhelin_ctx_set_stream": (i32, [vp, vp]),
+        "fhelin_sync": (i32, [vp]),
+        "fhelin_timer_start": (i32, [vp]),
+        "fhelin_timer_stop": (i32, [vp, f32p]),
+        "fhelin_dev_alloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
+        "fhelin_dev_free": (i32, [vp, vp]),
+        "fhelin_dev_upload": (i32, [vp, vp, vp, C.c_size_t]),
+        "fhelin_dev_download": (i32, [vp, vp, vp, C.c_size_t]),
+        "fhelin_ntt": (i32, [vp, vp, i32, i32, i32, i32]),
+        "fhelin_microbench": (i32, [vp, i32, i32, i32, f32p]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def _np_u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class DevBuf:
+    """A raw device allocation owned by an Engine."""
+
+    def __init__(self, eng, nbytes):
+        self.eng, self.nbytes = eng, int(nbytes)
+        p = C.c_void_p()
+        eng._ck(eng.lib.fhelin_dev_alloc(eng.h, self.nbytes, C.byref(p)))
+        self.ptr = p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.eng._ck(self.eng.lib.fhelin_dev_upload(self.eng.h, self.ptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes))
+        return self
+
+    def download(self, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.eng._ck(self.eng.lib.fhelin_dev_download(self.eng.h, out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.eng._ck(self.eng.lib.fhelin_dev_free(self.eng.h, self.ptr))
+            self.ptr = None
+
+
+class Engine:
+    """One fhelin context (one GPU, one stream)."""
+
+    def __init__(self, preset="bench", device=0, seed=1, **overrides):
+        self.lib = load_library()
+        cfg = dict(PRESETS[preset]) if isinstance(preset, str) else dict(preset)
+        cfg.update(overrides)
+        self.params = Params(device=device, seed=seed, **cfg)
+        h = C.c_void_p()
+        rc = self.lib.fhelin_ctx_create(C.byref(self.params), C.byref(h))
+        if rc != 0:
+            raise FhelinError(rc, self.lib.fhelin_last_error().decode())
+        self.h = h
+        self.log_n, self.N = self.params.log_n, 1 << self.params.log_n
+        self.n_q, self.n_p = self.params.n_q, self.params.n_p
+        nl = self.n_q + self.n_p
+        m = np.zeros(nl, dtype=np.uint64)
+        self._ck(self.lib.fhelin_ctx_moduli(self.h, m.ctypes.data_as(C.POINTER(C.c_uint64)), nl))
+        r = np.zeros(nl, dtype=np.uint64)
+        self._ck(self.lib.fhelin_ctx_roots(self.h, r.ctypes.data_as(C.POINTER(C.c_uint64)), nl))
+        self.moduli, self.roots = m, r
+        self.q, self.p = m[: self.n_q], m[self.n_q:]
+        self.psi_q, self.psi_p = r[: self.n_q], r[self.n_q:]
+        sf = np.zeros(self.n_q, dtype=np.float64)
+        self._ck(self.lib.fhelin_ctx_scaling_factors(self.h, sf.ctypes.data_as(C.POINTER(C.c_double)), self.n_q))
+        self.scaling_factors = sf
+        a, d = C.c_int32(), C.c_int32()
+        self._ck(self.lib.fhelin_ctx_info(self.h, None, C.byref(a), C.byref(d)))
+        self.alpha, self.has_device = a.value, bool(d.value)
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise FhelinError(rc, self.lib.fhelin_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.fhelin_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- raw buffers / kernels
+    def buf(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DevBuf(self, arr.nbytes).upload(arr)
+
+    def sync(self):
+        self._ck(self.lib.fhelin_sync(self.h))
+
+    def timer_start(self):
+        self._ck(self.lib.fhelin_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._ck(self.lib.fhelin_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def ntt(self, buf, nvec, limb_first=0, limb_count=None, inverse=False):
+        if limb_count is None:
+            limb_count = self.n_q
+        self._ck(self.lib.fhelin_ntt(self.h, buf.ptr, nvec, limb_first, limb_count, 1 if inverse else 0))
+
+    def microbench(self, variant, iters=4096, blocks=2048):
+        ms = C.c_float()
+        self._ck(self.lib.fhelin_microbench(self.h, variant, iters, blocks, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,189 @@
+// extern "C" boundary: translates C++ exceptions into status codes, owns nothing but handles.
+#include "../../include/fhelin.h"
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <string>
+#include "context.h"
+#include "capi_internal.h"
+
+using namespace fhelin;
+
+static thread_local std::string g_last_error;
+
+namespace fhelin {
+int capi_fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+}  // namespace fhelin
+
+extern "C" {
+
+const char* fhelin_last_error(void) { return g_last_error.c_str(); }
+const char* fhelin_version(void) { return "fhelin_amd 0.1 (gfx950)"; }
+
+int fhelin_ctx_create(const fhelin_params* p, fhelin_ctx** out) {
+    if (!p || !out) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    FHELIN_TRY
+    Params q;
+    q.log_n = p->log_n;
+    q.n_q = p->n_q;
+    q.first_bits = p->first_bits;
+    q.scale_bits = p->scale_bits;
+    q.n_p = p->n_p;
+    q.special_bits = p->special_bits;
+    q.dnum = p->dnum;
+    q.log_slots = p->log_slots;
+    q.hamming = p->hamming;
+    q.device = p->device;
+    q.seed = p->seed;
+    auto* c = new fhelin_ctx(q);
+    *out = c;
+    FHELIN_CATCH
+}
+
+void fhelin_ctx_destroy(fhelin_ctx* c) { delete c; }
+
+int fhelin_ctx_info(const fhelin_ctx* c, fhelin_params* out, int32_t* alpha, int32_t* has_device) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    if (out) {
+        const Params& q = c->ctx.prm;
+        out->log_n = q.log_n;
+        out->n_q = q.n_q;
+        out->first_bits = q.first_bits;
+        out->scale_bits = q.scale_bits;
+        out->n_p = q.n_p;
+        out->special_bits = q.special_bits;
+        out->dnum = q.dnum;
+        out->log_slots = q.log_slots;
+        out->hamming = q.hamming;
+        out->device = q.device;
+        out->seed = q.seed;
+    }
+    if (alpha) *alpha = c->ctx.alpha;
+    if (has_device) *has_device = c->ctx.has_device ? 1 : 0;
+    return FHELIN_OK;
+}
+
+int fhelin_ctx_moduli(const fhelin_ctx* c, uint64_t* out, int32_t cap) {
+    if (!c || !out) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    if (cap < (int)c->ctx.moduli.size()) return capi_fail(FHELIN_ERR_ARG, "buffer too small");
+    std::memcpy(out, c->ctx.moduli.data(), c->ctx.moduli.size() * sizeof(uint64_t));
+    return FHELIN_OK;
+}
+
+int fhelin_ctx_roots(const fhelin_ctx* c, uint64_t* out, int32_t cap) {
+    if (!c || !out) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    if (cap < (int)c->ctx.tw.size()) return capi_fail(FHELIN_ERR_ARG, "buffer too small");
+    for (size_t i = 0; i < c->ctx.tw.size(); ++i) out[i] = c->ctx.tw[i].psi;
+    return FHELIN_OK;
+}
+
+int fhelin_ctx_scaling_factors(const fhelin_ctx* c, double* out, int32_t cap) {
+    if (!c || !out) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    if (cap < c->ctx.prm.n_q) return capi_fail(FHELIN_ERR_ARG, "buffer too small");
+    for (int i = 0; i < c->ctx.prm.n_q; ++i) out[i] = (double)c->ctx.sf_real[i];
+    return FHELIN_OK;
+}
+
+int fhelin_ctx_set_stream(fhelin_ctx* c, void* hip_stream) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    FHELIN_TRY
+    c->ctx.require_device();
+    c->ctx.sync();
+    if (c->ctx.own_stream && c->ctx.stream) hip_check(hipStreamDestroy(c->ctx.stream), "hipStreamDestroy");
+    c->ctx.stream = (hipStream_t)hip_stream;
+    c->ctx.own_stream = false;
+    FHELIN_CATCH
+}
+
+int fhelin_sync(fhelin_ctx* c) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    FHELIN_TRY
+    c->ctx.sync();
+    FHELIN_CATCH
+}
+
+int fhelin_timer_start(fhelin_ctx* c) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    FHELIN_TRY
+    c->ctx.require_device();
+    hip_check(hipEventRecord(c->ctx.ev_start, c->ctx.stream), "hipEventRecord");
+    FHELIN_CATCH
+}
+
+int fhelin_timer_stop(fhelin_ctx* c, float* ms) {
+    if (!c || !ms) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    FHELIN_TRY
+    c->ctx.require_device();
+    hip_check(hipEventRecord(c->ctx.ev_stop, c->ctx.stream), "hipEventRecord");
+    hip_check(hipEventSynchronize(c->ctx.ev_stop), "hipEventSynchronize");
+    hip_check(hipEventElapsedTime(ms, c->ctx.ev_start, c->ctx.ev_stop), "hipEventElapsedTime");
+    FHELIN_CATCH
+}
+
+int fhelin_dev_alloc(fhelin_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    FHELIN_TRY
+    c->ctx.require_device();
+    *out = c->ctx.pool.alloc(bytes);
+    FHELIN_CATCH
+}
+
+int fhelin_dev_free(fhelin_ctx* c, void* p) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    FHELIN_TRY
+    c->ctx.require_device();
+    c->ctx.pool.free(p);
+    FHELIN_CATCH
+}
+
+int fhelin_dev_upload(fhelin_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    FHELIN_TRY
+    c->ctx.require_device();
+    hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->ctx.stream), "hipMemcpyAsync H2D");
+    hip_check(hipStreamSynchronize(c->ctx.stream), "hipStreamSynchronize");
+    FHELIN_CATCH
+}
+
+int fhelin_dev_download(fhelin_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    FHELIN_TRY
+    c->ctx.require_device();
+    hip_check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->ctx.stream), "hipMemcpyAsync D2H");
+    hip_check(hipStreamSynchronize(c->ctx.stream), "hipStreamSynchronize");
+    FHELIN_CATCH
+}
+
+int fhelin_ntt(fhelin_ctx* c, uint64_t* d_data, int32_t nvec, int32_t limb_first, int32_t limb_count, int32_t inverse) {
+    if (!c || !d_data) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    FHELIN_TRY
+    Context& x = c->ctx;
+    x.require_device();
+    if (nvec < 0 || limb_count < 1 || limb_first < 0 || limb_first + limb_count > (int)x.moduli.size())
+        throw Error(FHELIN_ERR_ARG, "fhelin_ntt: limb range outside the context's moduli");
+    LimbBatch b{d_data, nvec, nullptr, limb_first, limb_count};
+    launch_ntt(x.dt, b, inverse != 0, x.stream);
+    hip_check(hipGetLastError(), "launch_ntt");
+    FHELIN_CATCH
+}
+
+int fhelin_microbench(fhelin_ctx* c, int32_t variant, int32_t iters, int32_t blocks, float* ms) {
+    if (!c || !ms) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    FHELIN_TRY
+    Context& x = c->ctx;
+    x.require_device();
+    if (variant < 0 || variant > 7 || iters < 1 || blocks < 1) throw Error(FHELIN_ERR_ARG, "bad microbench arguments");
+    u64* out = x.dalloc<u64>((size_t)blocks * 256);
+    launch_mulbench(out, 8, variant, blocks, x.stream);  // warm
+    hip_check(hipEventRecord(x.ev_start, x.stream), "hipEventRecord");
+    launch_mulbench(out, iters, variant, blocks, x.stream);
+    hip_check(hipEventRecord(x.ev_stop, x.stream), "hipEventRecord");
+    hip_check(hipEventSynchronize(x.ev_stop), "hipEventSynchronize");
+    hip_check(hipEventElapsedTime(ms, x.ev_start, x.ev_stop), "hipEventElapsedTime");
+    x.pool.free(out);
+    FHELIN_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,23 @@
+// Shared plumbing for the extern "C" translation units.
+#pragma once
+#include <exception>
+#include <string>
+#include "context.h"
+
+// opaque handle behind include/fhelin.h's `fhelin_ctx`
+struct fhelin_ctx {
+    fhelin::Context ctx;
+    explicit fhelin_ctx(const fhelin::Params& p) : ctx(p) {}
+};
+
+namespace fhelin {
+int capi_fail(int code, const std::string& msg);
+}
+
+#define FHELIN_TRY try {
+#define FHELIN_CATCH                                                          \
+    return FHELIN_OK;                                                         \
+    }                                                                         \
+    catch (const fhelin::Error& e) { return fhelin::capi_fail(e.code, e.what()); }          \
+    catch (const std::bad_alloc&) { return fhelin::capi_fail(FHELIN_ERR_INTERNAL, "host out of memory"); } \
+    catch (const std::exception& e) { return fhelin::capi_fail(FHELIN_ERR_INTERNAL, e.what()); }

@@ -1,0 +1,258 @@
+#include "context.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstring>
+
+namespace fhelin {
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw Error(FHELIN_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// ---------------------------------------------------------------- DevicePool
+DevicePool::~DevicePool() {
+    for (auto& kv : idle_) (void)hipFree(kv.second);
+    for (auto& kv : live_) (void)hipFree(kv.first);
+}
+void* DevicePool::alloc(size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    bytes = (bytes + 255) & ~size_t(255);
+    auto it = idle_.find(bytes);
+    void* p = nullptr;
+    if (it != idle_.end()) {
+        p = it->second;
+        idle_.erase(it);
+    } else {
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            trim();
+            hip_check(hipMalloc(&p, bytes), "hipMalloc");
+        }
+        reserved_ += bytes;
+    }
+    live_[p] = bytes;
+    return p;
+}
+void DevicePool::free(void* p) {
+    if (!p) return;
+    auto it = live_.find(p);
+    if (it == live_.end()) throw Error(FHELIN_ERR_STATE, "DevicePool::free of unknown pointer");
+    idle_.emplace(it->second, p);
+    live_.erase(it);
+}
+void DevicePool::trim() {
+    if (idle_.empty()) return;
+    (void)hipDeviceSynchronize();
+    for (auto& kv : idle_) {
+        (void)hipFree(kv.second);
+        reserved_ -= kv.first;
+    }
+    idle_.clear();
+}
+
+// ---------------------------------------------------------------- Context
+template <class T>
+const T* Context::upload_table(const std::vector<T>& v) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    hip_check(hipMalloc(&p, bytes), "hipMalloc(table)");
+    if (!v.empty()) hip_check(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(table)");
+    table_allocs.push_back(p);
+    return static_cast<const T*>(p);
+}
+template const u64* Context::upload_table<u64>(const std::vector<u64>&);
+template const int* Context::upload_table<int>(const std::vector<int>&);
+template const u32* Context::upload_table<u32>(const std::vector<u32>&);
+
+static u64 prod_mod(const std::vector<u64>& ms, int skip, u64 t) {
+    u64 r = 1 % t;
+    for (int i = 0; i < (int)ms.size(); ++i)
+        if (i != skip) r = h_mulmod(r, ms[i] % t, t);
+    return r;
+}
+
+Context::Context(const Params& p) : prm(p) {
+    if (p.log_n < 12 || p.log_n > 17) throw Error(FHELIN_ERR_ARG, "log_n must be in [12,17]");
+    if (p.n_q < 1 || p.n_q > 64 || p.n_p < 0 || p.n_p > 16) throw Error(FHELIN_ERR_ARG, "bad limb counts");
+    if (p.dnum < 1) throw Error(FHELIN_ERR_ARG, "dnum must be >= 1");
+    if (p.first_bits > 60 || p.scale_bits > 60 || p.special_bits > 60) throw Error(FHELIN_ERR_ARG, "primes must be <= 60 bits");
+    if (p.log_slots < 1 || p.log_slots > p.log_n - 1) throw Error(FHELIN_ERR_ARG, "log_slots out of range");
+    N = 1 << p.log_n;
+    L = p.n_q - 1;
+    K = p.n_p;
+    alpha = (p.n_q + p.dnum - 1) / p.dnum;
+    if (alpha > 16) throw Error(FHELIN_ERR_ARG, "digit size > 16 limbs not supported");
+    if (K > 0 && (long)K * p.special_bits < (long)alpha * std::max(p.scale_bits, p.first_bits) - 8)
+        ;  // P smaller than a digit is allowed (noise grows); no hard error
+    try {
+        chain = make_prime_chain(p.log_n, p.n_q, p.first_bits, p.scale_bits, p.n_p, p.special_bits);
+    } catch (const std::exception& e) {
+        throw Error(FHELIN_ERR_ARG, std::string("prime chain: ") + e.what());
+    }
+    moduli = chain.q;
+    moduli.insert(moduli.end(), chain.p.begin(), chain.p.end());
+    for (u64 q : moduli) {
+        barrett.push_back(h_barrett(q));
+        tw.push_back(make_twiddles(q, p.log_n));
+    }
+    sf_real.assign(p.n_q + 1, 0.0L);
+    sf_real[0] = (long double)chain.q[L];
+    for (int k = 0; k < L; ++k) sf_real[k + 1] = sf_real[k] * sf_real[k] / (long double)chain.q[L - k];
+
+    if (p.device < 0) return;  // host-only: parameter layer only
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        throw Error(FHELIN_ERR_NO_DEVICE, "no HIP device visible: the fhe-linformer_amd engine has no CPU fallback");
+    if (p.device >= ndev) throw Error(FHELIN_ERR_ARG, "device index out of range");
+    hip_check(hipSetDevice(p.device), "hipSetDevice");
+    hip_check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+    own_stream = true;
+    hip_check(hipEventCreate(&ev_start), "hipEventCreate");
+    hip_check(hipEventCreate(&ev_stop), "hipEventCreate");
+    has_device = true;
+
+    const int nl = (int)moduli.size();
+    {
+        std::vector<u64> bar(2 * nl), ninv(4 * nl);
+        for (int i = 0; i < nl; ++i) {
+            bar[2 * i] = barrett[i].r0;
+            bar[2 * i + 1] = barrett[i].r1;
+            ninv[4 * i] = tw[i].n_inv;
+            ninv[4 * i + 1] = tw[i].n_inv_s;
+            ninv[4 * i + 2] = tw[i].w1_n_inv;
+            ninv[4 * i + 3] = tw[i].w1_n_inv_s;
+        }
+        dt.log_n = p.log_n;
+        dt.n_limbs = nl;
+        dt.moduli = upload_table(moduli);
+        dt.barrett = upload_table(bar);
+        dt.ninv = upload_table(ninv);
+        std::vector<u64> f((size_t)nl * 2 * N), g((size_t)nl * 2 * N);
+        for (int i = 0; i < nl; ++i) {
+            std::memcpy(&f[(size_t)i * 2 * N], tw[i].fwd.data(), sizeof(u64) * 2 * N);
+            std::memcpy(&g[(size_t)i * 2 * N], tw[i].inv.data(), sizeof(u64) * 2 * N);
+        }
+        dt.tw_fwd = upload_table(f);
+        dt.tw_inv = upload_table(g);
+    }
+    // ---- ModDown / rescale constants
+    {
+        std::vector<u64> phatinv(2 * std::max(K, 1)), phatmod((size_t)std::max(K, 1) * (L + 1)), pinv(2 * (L + 1));
+        for (int j = 0; j < K; ++j) {
+            u64 pj = chain.p[j];
+            u64 hat = prod_mod(chain.p, j, pj);
+            u64 inv = h_invmod(hat, pj);
+            phatinv[2 * j] = inv;
+            phatinv[2 * j + 1] = h_shoup(inv, pj);
+            for (int t = 0; t <= L; ++t) phatmod[(size_t)j * (L + 1) + t] = prod_mod(chain.p, j, chain.q[t]);
+        }
+        for (int t = 0; t <= L; ++t) {
+            u64 qt = chain.q[t];
+            u64 pm = prod_mod(chain.p, -1, qt);
+            u64 inv = K > 0 ? h_invmod(pm, qt) : 1;
+            pinv[2 * t] = inv;
+            pinv[2 * t + 1] = h_shoup(inv, qt);
+        }
+        d_phatinv = upload_table(phatinv);
+        d_phatmod = upload_table(phatmod);
+        d_pinv = upload_table(pinv);
+        std::vector<u64> qlinv((size_t)(L + 1) * (L + 1) * 2, 0), qlmod((size_t)(L + 1) * (L + 1), 0);
+        for (int l = 0; l <= L; ++l)
+            for (int t = 0; t < l; ++t) {
+                u64 qt = chain.q[t];
+                u64 r = chain.q[l] % qt;
+                u64 inv = h_invmod(r, qt);
+                qlmod[(size_t)l * (L + 1) + t] = r;
+                qlinv[((size_t)l * (L + 1) + t) * 2] = inv;
+                qlinv[((size_t)l * (L + 1) + t) * 2 + 1] = h_shoup(inv, qt);
+            }
+        d_qlinv = upload_table(qlinv);
+        d_qlmod = upload_table(qlmod);
+    }
+    // ---- ModUp constants per level
+    lvl.resize(L + 2);
+    for (int ell = 1; ell <= L + 1; ++ell) {
+        LevelTables& lt = lvl[ell];
+        lt.ell = ell;
+        lt.beta = digits_at(ell);
+        const int nt = ell + K;
+        std::vector<u64> hatinv(2 * ell), hatmod((size_t)ell * nt, 0);
+        std::vector<int> tab((size_t)lt.beta * nt, -1);
+        for (int j = 0; j < lt.beta; ++j) {
+            const int lo = j * alpha, hi = std::min((j + 1) * alpha, ell);
+            std::vector<u64> dig(chain.q.begin() + lo, chain.q.begin() + hi);
+            for (int i = lo; i < hi; ++i) {
+                u64 qi = chain.q[i];
+                u64 inv = h_invmod(prod_mod(dig, i - lo, qi), qi);
+                hatinv[2 * i] = inv;
+                hatinv[2 * i + 1] = h_shoup(inv, qi);
+                for (int t = 0; t < nt; ++t) {
+                    u64 mt = t < ell ? chain.q[t] : chain.p[t - ell];
+                    hatmod[(size_t)i * nt + t] = prod_mod(dig, i - lo, mt);
+                }
+            }
+            for (int t = 0; t < nt; ++t) {
+                bool own = t >= lo && t < hi;
+                tab[(size_t)j * nt + t] = own ? -1 : (t < ell ? limb_id_q(t) : limb_id_p(t - ell));
+            }
+        }
+        lt.up_hatinv = upload_table(hatinv);
+        lt.up_hatmod = upload_table(hatmod);
+        lt.ext_limb_tab = upload_table(tab);
+    }
+}
+
+Context::~Context() {
+    if (has_device) {
+        (void)hipSetDevice(prm.device);
+        (void)hipDeviceSynchronize();
+        for (void* p : table_allocs) (void)hipFree(p);
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_stop) (void)hipEventDestroy(ev_stop);
+        if (own_stream && stream) (void)hipStreamDestroy(stream);
+    }
+}
+
+void Context::require_device() const {
+    if (!has_device)
+        throw Error(FHELIN_ERR_NO_DEVICE, "operation needs the HIP device path (host-only context): no CPU fallback exists");
+}
+
+void Context::sync() {
+    require_device();
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+}
+
+u64 Context::galois_element(int r) const {
+    const u64 M = 2ull * N;
+    const u64 order = N / 2;  // order of 5 in Z_{2N}^*
+    long rr = r % (long)order;
+    if (rr < 0) rr += order;
+    u64 g = 1, b = 5;
+    u64 e = (u64)rr;
+    while (e) {
+        if (e & 1) g = (g * b) % M;
+        b = (b * b) % M;
+        e >>= 1;
+    }
+    return g;
+}
+
+const u32* Context::automorph_map(u64 g) {
+    require_device();
+    auto it = automorph_maps.find(g);
+    if (it != automorph_maps.end()) return it->second;
+    const int ln = prm.log_n;
+    const u64 M = 2ull * N;
+    std::vector<u32> m(N);
+    for (u32 j = 0; j < (u32)N; ++j) {
+        u64 e = (2ull * bitrev32(j, ln) + 1) * g % M;  // odd exponent of the evaluation point that feeds slot j
+        m[j] = bitrev32((u32)((e - 1) >> 1), ln);
+    }
+    const u32* d = upload_table(m);
+    automorph_maps[g] = d;
+    return d;
+}
+
+}  // namespace fhelin

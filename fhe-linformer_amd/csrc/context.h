@@ -1,0 +1,111 @@
+// Engine context: CKKS parameter set -> prime chain -> host/device tables, HIP stream, device pool.
+// Mirrors what reference FHEController::generate_context builds through OpenFHE's GenCryptoContext
+// (reference src/FHEController.cpp:3-49): ring dimension, 55/52-bit Q chain, HYBRID key switching with
+// dnum large digits and 60-bit special primes, SPARSE_TERNARY secret, FLEXIBLEAUTO real scaling factors.
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include <hip/hip_runtime_api.h>
+#include "../../include/fhelin.h"  // status codes
+#include "hostmath.h"
+#include "kernels.h"
+
+namespace fhelin {
+
+struct Params {
+    int log_n = 16;
+    int n_q = 24;          // L+1 Q limbs
+    int first_bits = 55;
+    int scale_bits = 52;
+    int n_p = 6;           // special limbs k
+    int special_bits = 60;
+    int dnum = 4;
+    int log_slots = 14;
+    int hamming = 192;     // sparse ternary secret weight
+    uint64_t seed = 1;
+    int device = 0;        // < 0: host-only context (parameter tables only; every device op fails)
+};
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+void hip_check(hipError_t e, const char* what);
+
+// Size-bucketed caching allocator on one device/stream (all work is stream-ordered on Context::stream,
+// so a freed block can be handed out again immediately).
+class DevicePool {
+public:
+    ~DevicePool();
+    void* alloc(size_t bytes);
+    void free(void* p);
+    void trim();
+    size_t bytes_reserved() const { return reserved_; }
+private:
+    std::unordered_map<void*, size_t> live_;
+    std::multimap<size_t, void*> idle_;
+    size_t reserved_ = 0;
+};
+
+// Per-level constants of hybrid key switching / rescale, resident on the device.
+struct LevelTables {
+    int ell = 0;        // live Q limbs
+    int beta = 0;       // digits present at this level
+    // ModUp: per source limb i < ell: (Qhat_i^{-1} mod q_i, shoup); and [ell][ell+k] Qhat_i mod t
+    const u64* up_hatinv = nullptr;   // [ell][2]
+    const u64* up_hatmod = nullptr;   // [ell][ell+k]
+    const int* ext_limb_tab = nullptr;  // [beta*(ell+k)] limb id for the NTT after ModUp, -1 on own-digit slots
+};
+
+struct Context {
+    Params prm;
+    int N = 0;
+    int L = 0;       // n_q - 1
+    int K = 0;       // n_p
+    int alpha = 0;   // limbs per digit
+    PrimeChain chain;
+    std::vector<u64> moduli;          // Q then P
+    std::vector<Barrett> barrett;     // same order
+    std::vector<TwiddleTable> tw;     // same order (host copies)
+    std::vector<long double> sf_real; // FLEXIBLEAUTO real scaling factor per level (0 = fresh)
+
+    bool has_device = false;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    DevicePool pool;
+    DeviceTables dt{};
+    std::vector<void*> table_allocs;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+
+    // ModDown / rescale constants (level independent)
+    const u64* d_phatinv = nullptr;  // [k][2]   (P/p)^{-1} mod p, shoup
+    const u64* d_phatmod = nullptr;  // [k][L+1] (P/p) mod q_t
+    const u64* d_pinv = nullptr;     // [L+1][2] P^{-1} mod q_t, shoup
+    const u64* d_qlinv = nullptr;    // [L+1][L+1][2]  q_l^{-1} mod q_t, shoup   (row l, col t<l)
+    const u64* d_qlmod = nullptr;    // [L+1][L+1]     q_l mod q_t
+    std::vector<LevelTables> lvl;    // index by ell (1..L+1)
+    std::map<u64, const u32*> automorph_maps;  // galois element -> device map [N]
+
+    explicit Context(const Params& p);
+    ~Context();
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+
+    void require_device() const;
+    template <class T> T* dalloc(size_t count) { return static_cast<T*>(pool.alloc(count * sizeof(T))); }
+    template <class T> const T* upload_table(const std::vector<T>& v);
+    int limb_id_q(int i) const { return i; }
+    int limb_id_p(int j) const { return L + 1 + j; }
+    int digits_at(int ell) const { return (ell + alpha - 1) / alpha; }
+    u64 galois_element(int rot_index) const;       // 5^r mod 2N (r may be negative)
+    const u32* automorph_map(u64 galois);          // device map for the NTT-domain permutation
+    void sync();
+};
+
+}  // namespace fhelin

@@ -1,0 +1,41 @@
+// Launch interface of the hand-written gfx950 kernels (implementation: kernels_*.hip).
+// Host code (evaluator.cpp, capi.cpp) sees only these plain-C++ launchers.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <hip/hip_runtime_api.h>
+#include "modarith.h"
+
+namespace fhelin {
+
+// A batch of independent length-N residue vectors ("limb vectors"), contiguous: data[v][N].
+// Vector v belongs to RNS limb  limb_tab ? limb_tab[v] : limb_first + (v % limb_count);
+// a negative table entry skips the vector.  Limb ids index the context-wide arrays
+// (moduli, twiddles): Q limbs 0..L, then special limbs L+1..L+k.
+struct LimbBatch {
+    u64* data;
+    int nvec;
+    const int* limb_tab;  // device pointer or nullptr
+    int limb_first;
+    int limb_count;
+};
+
+// Device-resident per-context tables.
+struct DeviceTables {
+    int log_n;
+    int n_limbs;           // L+1+k
+    const u64* moduli;     // [n_limbs]
+    const u64* barrett;    // [n_limbs][2]  (r0, r1) of floor(2^128/q)
+    const u64* tw_fwd;     // [n_limbs][2N]  (w, w') pairs, bit-reversed powers of psi
+    const u64* tw_inv;     // [n_limbs][2N]  same for psi^{-1}
+    const u64* ninv;       // [n_limbs][4]   N^{-1}, shoup, ipsi_br[1]*N^{-1}, shoup
+};
+
+// K1: negacyclic NTT (natural -> bit-reversed) / INTT (bit-reversed -> natural, scaled by N^{-1}).
+// In place, canonical [0,q) in and out.
+void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStream_t s);
+
+// micro-benchmark kernels used by bench.py --micro to calibrate the integer-multiply ceiling
+void launch_mulbench(u64* out, int iters, int variant, int blocks, hipStream_t s);
+
+}  // namespace fhelin

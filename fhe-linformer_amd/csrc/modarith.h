@@ -1,0 +1,123 @@
+// 64-bit modular arithmetic shared by the HIP kernels and the host-side client code.
+//
+// Every residue on the hot path is an unsigned 64-bit integer in [0, q) with q < 2^61
+// (55-bit first prime, 52-bit scaling primes, 60-bit special primes; parameters follow
+// reference src/FHEController.cpp:6-31).  Three multiplication flavours are used:
+//   * Shoup ("precomputed quotient") for constant operands: twiddles, basis-conversion
+//     constants, q_l^{-1}, P^{-1}.       cost: 1 mulhi64 + 2 mullo64
+//   * Barrett (2-word ratio floor(2^128/q)) for data x data products (ct x pt, tensor).
+//   * 128-bit accumulate + one Barrett reduction for the fast-basis-conversion sums.
+// The functions are exact: every op on this path is a mathematical function mod q, which is
+// what makes GPU results comparable bit-for-bit with oracle/.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FHE_HD __host__ __device__ __forceinline__
+#else
+#define FHE_HD inline
+#endif
+
+namespace fhelin {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef unsigned __int128 u128;
+
+FHE_HD u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((u128)a * b) >> 64);
+#endif
+}
+
+// ---- Shoup multiplication by a constant w with ws = floor(w * 2^64 / q) ---------------
+// result in [0, 2q) for ANY 64-bit x (Harvey 2014); q < 2^63.
+FHE_HD u64 mul_shoup_lazy(u64 x, u64 w, u64 ws, u64 q) {
+    u64 h = mulhi64(x, ws);
+    return x * w - h * q;
+}
+FHE_HD u64 mul_shoup(u64 x, u64 w, u64 ws, u64 q) {
+    u64 r = mul_shoup_lazy(x, w, ws, q);
+    return r >= q ? r - q : r;
+}
+
+FHE_HD u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }
+FHE_HD u64 add_mod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
+FHE_HD u64 sub_mod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+FHE_HD u64 neg_mod(u64 a, u64 q) { return a ? q - a : 0; }
+
+// ---- Barrett: ratio (r1:r0) = floor(2^128 / q) ------------------------------------------
+struct Barrett {
+    u64 q;
+    u64 r0;  // low word of floor(2^128/q)
+    u64 r1;  // high word
+};
+
+// reduce a 128-bit value (hi:lo) modulo q; requires q < 2^62 (quotient estimate off by <= 2... we
+// correct with two conditional subtractions).  Any 128-bit input is accepted.
+FHE_HD u64 barrett_reduce128(u64 lo, u64 hi, const Barrett& b) {
+    // qhat = floor( (hi:lo) * (r1:r0) / 2^128 ), computed without the lowest partial product's low word
+    u64 carry = mulhi64(lo, b.r0);
+    // lo * r1
+    u64 t_lo = lo * b.r1;
+    u64 t_hi = mulhi64(lo, b.r1);
+    u64 s1 = t_lo + carry;
+    u64 c1 = t_hi + (s1 < t_lo);
+    // hi * r0
+    t_lo = hi * b.r0;
+    t_hi = mulhi64(hi, b.r0);
+    u64 s2 = s1 + t_lo;
+    u64 c2 = t_hi + (s2 < t_lo);
+    u64 qhat = hi * b.r1 + c1 + c2;
+    u64 r = lo - qhat * b.q;
+    r = r >= b.q ? r - b.q : r;
+    r = r >= b.q ? r - b.q : r;
+    return r;
+}
+
+FHE_HD u64 mul_mod(u64 a, u64 c, const Barrett& b) {
+    return barrett_reduce128(a * c, mulhi64(a, c), b);
+}
+
+// 128-bit accumulator for sums of up to 16 products of 60-bit numbers.
+struct Acc128 {
+    u64 lo, hi;
+};
+FHE_HD void acc_mac(Acc128& a, u64 x, u64 y) {
+    u64 pl = x * y;
+    u64 ph = mulhi64(x, y);
+    a.lo += pl;
+    a.hi += ph + (a.lo < pl);
+}
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// ---- host-only helpers ------------------------------------------------------------------
+inline u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+inline u64 h_powmod(u64 a, u64 e, u64 q) {
+    u64 r = 1 % q;
+    a %= q;
+    while (e) {
+        if (e & 1) r = h_mulmod(r, a, q);
+        a = h_mulmod(a, a, q);
+        e >>= 1;
+    }
+    return r;
+}
+inline u64 h_invmod(u64 a, u64 q) { return h_powmod(a, q - 2, q); }  // q prime
+inline u64 h_shoup(u64 w, u64 q) { return (u64)((((u128)w) << 64) / q); }
+inline Barrett h_barrett(u64 q) {
+    Barrett b;
+    b.q = q;
+    // floor(2^128 / q) = floor((2^128 - 1) / q) because q is odd and > 1
+    u128 all = ~(u128)0;
+    u128 r = all / q;
+    b.r0 = (u64)r;
+    b.r1 = (u64)(r >> 64);
+    return b;
+}
+#endif
+
+}  // namespace fhelin

@@ -1,0 +1,90 @@
+/*
+ * fhelin.h — C ABI of the MI355X-native RNS-CKKS evaluation engine (libfhelin_amd.so).
+ *
+ * This is the drop-in boundary underneath the reference's `class FHEController`
+ * (reference src/FHEController.h:22-161).  The reference binds OpenFHE's C++ objects directly
+ * (`CryptoContext<DCRTPoly> context`, `Ciphertext<DCRTPoly>`, `Plaintext`; src/FHEController.h:19-23);
+ * a maintainer replaces those with the opaque handles below (see INTEGRATION.md and the
+ * source-compatible shim include/FHEController.h).  Every entry point cites the reference call site
+ * it stands in for.  All functions return 0 on success or an FHELIN_ERR_* code; the message of the
+ * last failure on the calling thread is available from fhelin_last_error().
+ *
+ * Conventions
+ *  - plain C types only: pointers, sizes, integers, doubles.  No torch / HIP types in signatures
+ *    (a hipStream_t travels as void*).
+ *  - residue data is uint64_t, limb-major: poly[limb][N]; ciphertext = poly 0 then poly 1 (then 2).
+ *  - limb ids: Q limbs 0..L, special (P) limbs L+1..L+k.
+ *  - device work is asynchronous on the context's stream; fhelin_sync() waits for it.
+ *  - there is NO CPU fallback: on a host-only context (device < 0) every evaluation entry point
+ *    fails with FHELIN_ERR_NO_DEVICE.
+ */
+#ifndef FHELIN_H
+#define FHELIN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FHELIN_OK 0
+#define FHELIN_ERR_ARG 1
+#define FHELIN_ERR_NO_DEVICE 2
+#define FHELIN_ERR_HIP 3
+#define FHELIN_ERR_STATE 4
+#define FHELIN_ERR_KEY 5
+#define FHELIN_ERR_INTERNAL 6
+
+typedef struct fhelin_ctx fhelin_ctx;   /* CryptoContext<DCRTPoly>            (FHEController.h:23)  */
+typedef struct fhelin_ct fhelin_ct;     /* Ctxt = Ciphertext<DCRTPoly>        (FHEController.h:20)  */
+typedef struct fhelin_pt fhelin_pt;     /* Ptxt = Plaintext                   (FHEController.h:19)  */
+
+/* CCParams<CryptoContextCKKSRNS> as set in generate_context (FHEController.cpp:4-35). */
+typedef struct fhelin_params {
+    int32_t log_n;         /* SetRingDim(1 << log_n)                 :12-13 */
+    int32_t n_q;           /* multiplicative depth + 1               :31-35 */
+    int32_t first_bits;    /* SetFirstModSize(55)                    :25    */
+    int32_t scale_bits;    /* SetScalingModSize(52), FLEXIBLEAUTO    :18-24 */
+    int32_t n_p;           /* special primes of HYBRID key switching (OpenFHE-internal) */
+    int32_t special_bits;  /* 60                                                       */
+    int32_t dnum;          /* SetNumLargeDigits(4)                   :11    */
+    int32_t log_slots;     /* SetBatchSize(1 << 14)                  :6,14  */
+    int32_t hamming;       /* SPARSE_TERNARY secret weight           :8     */
+    int32_t device;        /* HIP device ordinal; < 0 = host-only parameter context */
+    uint64_t seed;         /* PRNG seed for key generation / encryption randomness */
+} fhelin_params;
+
+const char* fhelin_last_error(void);
+const char* fhelin_version(void);
+
+/* ---- context (GenCryptoContext + Enable(...), FHEController.cpp:37-45) ------------------------ */
+int fhelin_ctx_create(const fhelin_params* p, fhelin_ctx** out);
+void fhelin_ctx_destroy(fhelin_ctx* c);
+int fhelin_ctx_info(const fhelin_ctx* c, fhelin_params* out, int32_t* alpha, int32_t* has_device);
+int fhelin_ctx_moduli(const fhelin_ctx* c, uint64_t* out, int32_t cap);          /* Q then P */
+int fhelin_ctx_roots(const fhelin_ctx* c, uint64_t* out, int32_t cap);           /* psi per limb */
+int fhelin_ctx_scaling_factors(const fhelin_ctx* c, double* out, int32_t cap);   /* real Delta per level */
+int fhelin_ctx_set_stream(fhelin_ctx* c, void* hip_stream);                      /* adopt a caller stream */
+int fhelin_sync(fhelin_ctx* c);
+/* HIP-event timer on the context's stream (bench.py measures kernel time with these) */
+int fhelin_timer_start(fhelin_ctx* c);
+int fhelin_timer_stop(fhelin_ctx* c, float* ms);
+
+/* ---- raw device buffers + residue-polynomial kernels (parity tests and bench call these) ------- */
+int fhelin_dev_alloc(fhelin_ctx* c, size_t bytes, void** out);
+int fhelin_dev_free(fhelin_ctx* c, void* p);
+int fhelin_dev_upload(fhelin_ctx* c, void* dst, const void* src, size_t bytes);
+int fhelin_dev_download(fhelin_ctx* c, void* dst, const void* src, size_t bytes);
+
+/* K1: in-place negacyclic NTT/INTT of nvec limb vectors d_data[v][N]; vector v uses limb
+ * limb_first + (v % limb_count).  Stands in for DCRTPoly::SetFormat inside OpenFHE. */
+int fhelin_ntt(fhelin_ctx* c, uint64_t* d_data, int32_t nvec, int32_t limb_first, int32_t limb_count, int32_t inverse);
+
+/* instruction-rate probe (bench.py --micro): variant 0..7, see csrc/kernels_micro.hip */
+int fhelin_microbench(fhelin_ctx* c, int32_t variant, int32_t iters, int32_t blocks, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FHELIN_H */

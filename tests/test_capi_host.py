@@ -1,0 +1,76 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/fhelin.h declares, builds the
+parameter layer identically to the oracle's independent restatement, and refuses to evaluate without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "fhelin.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fhelin_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(fa):
+    lib = fa.load_library()
+    names = _declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"libfhelin_amd.so does not export {n}"
+    assert b"gfx950" in lib.fhelin_version()
+
+
+@pytest.mark.parametrize("preset", ["toy", "reference", "bench", "deep"])
+def test_parameter_layer_matches_oracle(fa, orc, preset):
+    e = fa.Engine(preset, device=-1)
+    try:
+        cfg = fa.PRESETS[preset]
+        q, p = orc.prime_chain(cfg["log_n"], cfg["n_q"], cfg["first_bits"], cfg["scale_bits"], cfg["n_p"], cfg["special_bits"])
+        assert np.array_equal(e.q, q) and np.array_equal(e.p, p)
+        two_n = 2 << cfg["log_n"]
+        for m, r in list(zip(e.moduli, e.roots))[:: max(1, len(e.moduli) // 6)]:
+            assert int(r) == orc.min_root(int(m), two_n)
+        assert e.alpha == -(-cfg["n_q"] // cfg["dnum"])
+        # FLEXIBLEAUTO real scaling factors: Delta_0 = q_L, Delta_{k+1} = Delta_k^2 / q_{L-k}
+        sf = e.scaling_factors
+        assert sf[0] == float(q[-1])
+        for k in range(len(sf) - 1):
+            assert abs(sf[k + 1] - sf[k] * sf[k] / float(q[len(q) - 1 - k])) <= 2.0 ** -40 * sf[k + 1]
+    finally:
+        e.close()
+
+
+def test_reference_parameter_shape(fa):
+    """reference src/FHEController.cpp:6-35: N=2^15, depth 27 -> 28 limbs, dnum 4 -> 7 limbs per digit."""
+    e = fa.Engine("reference", device=-1)
+    assert (e.N, e.n_q, e.n_p, e.alpha) == (1 << 15, 28, 7, 7)
+    e.close()
+
+
+def test_host_only_context_refuses_to_evaluate(fa):
+    """No CPU fallback: evaluation entry points on a device-less context fail with FHELIN_ERR_NO_DEVICE."""
+    e = fa.Engine("toy", device=-1)
+    assert not e.has_device
+    with pytest.raises(fa.FhelinError) as ei:
+        e.buf(1024)
+    assert ei.value.code == 2
+    with pytest.raises(fa.FhelinError) as ei:
+        e.sync()
+    assert ei.value.code == 2
+    dummy = type("B", (), {"ptr": C.c_void_p(16)})()
+    with pytest.raises(fa.FhelinError) as ei:
+        e.ntt(dummy, 1)
+    assert ei.value.code == 2
+    e.close()
+
+
+def test_bad_parameters_are_rejected(fa):
+    for kw in (dict(log_n=11), dict(log_n=18), dict(n_q=0), dict(dnum=0), dict(special_bits=62)):
+        with pytest.raises(fa.FhelinError) as ei:
+            fa.Engine("toy", device=-1, **kw)
+        assert ei.value.code == 1

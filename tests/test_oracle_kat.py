@@ -1,0 +1,244 @@
+"""Known-answer tests that pin the CPU oracle without any library: the oracle is 'parity unpinned'
+against OpenFHE, so it is anchored on mathematics instead."""
+import numpy as np
+import pytest
+
+Q60 = None
+
+
+def _chain(orc, log_n=12, n_q=4, n_p=2):
+    q, p = orc.prime_chain(log_n, n_q, 55, 52, n_p, 60)
+    psi_q = np.array([orc.min_root(x, 2 << log_n) for x in q], dtype=np.uint64)
+    psi_p = np.array([orc.min_root(x, 2 << log_n) for x in p], dtype=np.uint64)
+    return q, p, psi_q, psi_p
+
+
+def test_prime_chain_properties(orc):
+    for log_n, n_q, n_p in [(12, 6, 2), (15, 28, 7), (16, 24, 6), (17, 30, 8)]:
+        q, p = orc.prime_chain(log_n, n_q, 55, 52, n_p, 60)
+        allp = [int(x) for x in q] + [int(x) for x in p]
+        assert len(set(allp)) == len(allp)
+        m = 2 << log_n
+        for x in allp:
+            assert orc.is_prime(x) and x % m == 1
+        assert int(q[0]).bit_length() == 55
+        assert all(int(x).bit_length() in (52, 53) for x in q[1:])
+        assert all(int(x).bit_length() == 60 for x in p)
+        # FLEXIBLEAUTO property: the real scaling factor stays within 2^-20 relative of 2^52 at every level
+        sf = float(q[-1])
+        for k in range(n_q - 2):
+            sf = sf * sf / float(q[n_q - 1 - k])
+            assert abs(sf / 2.0 ** 52 - 1.0) < 2.0 ** -18
+
+
+def test_known_small_primes(orc):
+    assert orc.is_prime(2 ** 61 - 1) and not orc.is_prime(2 ** 61 + 1)
+    assert orc.is_prime(0xFFFFFFFF00000001)  # Goldilocks
+    assert not orc.is_prime(3215031751)  # strong pseudoprime to bases 2,3,5,7
+
+
+def test_min_root_is_primitive_and_minimal(orc):
+    q, _, _, _ = _chain(orc, 12, 3, 1)
+    for x in q:
+        x = int(x)
+        r = orc.min_root(x, 8192)
+        assert pow(r, 4096, x) == x - 1
+        # no smaller primitive root: brute force over odd powers
+        roots = set()
+        cur, r2 = r, r * r % x
+        for _ in range(4096):
+            roots.add(cur)
+            cur = cur * r2 % x
+        assert min(roots) == r and len(roots) == 4096
+
+
+def test_ntt_matches_definition(orc):
+    q, _, psi, _ = _chain(orc, 12, 3, 1)
+    rng = np.random.default_rng(1)
+    for ql, ps in zip(q, psi):
+        a = rng.integers(0, int(ql), size=4096, dtype=np.uint64)
+        assert np.array_equal(orc.ntt_forward(a, ql, ps), orc.ntt_naive(a, ql, ps))
+
+
+def test_ntt_roundtrip_all_ring_sizes(orc):
+    rng = np.random.default_rng(2)
+    for log_n in (12, 13, 15, 16, 17):
+        q, p = orc.prime_chain(log_n, 3, 55, 52, 1, 60)
+        for ql in list(q) + list(p):
+            ps = orc.min_root(ql, 2 << log_n)
+            a = rng.integers(0, int(ql), size=1 << log_n, dtype=np.uint64)
+            f = orc.ntt_forward(a, ql, ps)
+            assert f.max() < ql
+            assert np.array_equal(orc.ntt_inverse(f, ql, ps), a)
+
+
+def test_ntt_edge_vectors(orc):
+    q, _, psi, _ = _chain(orc, 12, 2, 1)
+    ql, ps = int(q[1]), int(psi[1])
+    zero = np.zeros(4096, dtype=np.uint64)
+    assert not orc.ntt_forward(zero, ql, ps).any()
+    one = zero.copy(); one[0] = 1
+    assert np.all(orc.ntt_forward(one, ql, ps) == 1)  # constant polynomial evaluates to 1 everywhere
+    mx = np.full(4096, ql - 1, dtype=np.uint64)
+    assert np.array_equal(orc.ntt_inverse(orc.ntt_forward(mx, ql, ps), ql, ps), mx)
+    # X evaluates to psi^(2 br(j)+1): slot 0 holds psi itself
+    x = zero.copy(); x[1] = 1
+    assert int(orc.ntt_forward(x, ql, ps)[0]) == ps
+
+
+def test_convolution_theorem(orc):
+    q, _, psi, _ = _chain(orc, 12, 2, 1)
+    rng = np.random.default_rng(3)
+    ql, ps = q[0], psi[0]
+    a = rng.integers(0, int(ql), size=4096, dtype=np.uint64)
+    b = rng.integers(0, int(ql), size=4096, dtype=np.uint64)
+    fa_, fb = orc.ntt_forward(a, ql, ps), orc.ntt_forward(b, ql, ps)
+    prod = orc.mul(fa_[None], fb[None], [ql])[0]
+    assert np.array_equal(orc.ntt_inverse(prod, ql, ps), orc.negacyclic_mul_naive(a, b, ql))
+
+
+def test_automorphism_domains_agree(orc):
+    q, _, psi, _ = _chain(orc, 12, 2, 1)
+    rng = np.random.default_rng(4)
+    ql, ps = q[1], psi[1]
+    a = rng.integers(0, int(ql), size=4096, dtype=np.uint64)
+    for r in (1, 2, 128, -1, -64, 1023):
+        g = orc.galois(12, r)
+        assert g % 2 == 1
+        lhs = orc.automorph_ntt(orc.ntt_forward(a, ql, ps), g)
+        rhs = orc.ntt_forward(orc.automorph_coeff(a, g, ql), ql, ps)
+        assert np.array_equal(lhs, rhs)
+    assert orc.galois(12, 1) * orc.galois(12, -1) % 8192 == 1
+
+
+def _crt2(x0, x1, q0, q1):
+    """centred CRT lift of residues mod q0, q1 -> python ints"""
+    inv = pow(q0, -1, q1)
+    out = []
+    Q = q0 * q1
+    for a, b in zip(x0.tolist(), x1.tolist()):
+        v = a + q0 * (((b - a) * inv) % q1)
+        out.append(v - Q if v > Q // 2 else v)
+    return out
+
+
+def test_rescale_divides_by_last_prime(orc):
+    log_n, ell = 12, 3
+    q, _, psi, _ = _chain(orc, log_n, ell, 1)
+    rng = np.random.default_rng(5)
+    qs = [int(x) for x in q]
+    # a polynomial with small (|c| < 2^100) integer coefficients, known exactly
+    coeffs = [int(rng.integers(-2 ** 62, 2 ** 62)) * int(rng.integers(1, 2 ** 38)) for _ in range(1 << log_n)]
+    limbs = np.array([[c % m for c in coeffs] for m in qs], dtype=np.uint64)
+    ct = orc.ntt_batch(limbs, q, psi)[None]
+    out = orc.rescale(ct, q, psi)[0]
+    back = orc.ntt_batch(out, q[:-1], psi[:-1], inverse=True)
+    got = _crt2(back[0], back[1], qs[0], qs[1])
+    for c, g in zip(coeffs, got):
+        # exact division of (c - [c]_ql centred) by ql: |g - c/ql| <= 1/2
+        assert abs(g * qs[-1] - c) <= qs[-1] // 2 + 1
+
+
+def _toy_keys(orc, log_n, q, p, psi_q, psi_p, alpha, s_from, s_to, rng):
+    """Hybrid key-switching key from secret s_from to s_to (both small ternary coefficient vectors)."""
+    n = 1 << log_n
+    L1, k = len(q), len(p)
+    dnum = -(-L1 // alpha)
+    mods = [int(x) for x in q] + [int(x) for x in p]
+    psis = list(psi_q) + list(psi_p)
+    P = 1
+    for x in p:
+        P *= int(x)
+    Q = 1
+    for x in q:
+        Q *= int(x)
+
+    def to_ntt(coeffs):
+        limbs = np.array([[c % m for c in coeffs] for m in mods], dtype=np.uint64)
+        return orc.ntt_batch(limbs, mods, psis)
+
+    s_to_ntt = to_ntt(s_to)
+    s_from_ntt = to_ntt(s_from)
+    evk = np.zeros((dnum, 2, L1 + k, n), dtype=np.uint64)
+    for j in range(dnum):
+        Qj = 1
+        for x in q[j * alpha:(j + 1) * alpha]:
+            Qj *= int(x)
+        Qhat = Q // Qj
+        factor = P * Qhat * pow(Qhat, -1, Qj)
+        a = np.array([rng.integers(0, m, size=n, dtype=np.uint64) for m in mods])
+        e = to_ntt([int(v) for v in rng.integers(-3, 4, size=n)])
+        fs = orc.mul_scalar(s_from_ntt, np.array([factor % m for m in mods], dtype=np.uint64), mods)
+        b = orc.add(orc.sub(e, orc.mul(a, s_to_ntt, mods), mods), fs, mods)
+        evk[j, 0], evk[j, 1] = b, a
+    return evk, s_to_ntt
+
+
+@pytest.mark.parametrize("ell", [6, 4, 3])
+def test_keyswitch_correct_by_decryption(orc, ell):
+    """KeySwitch(c, evk(s'->s)) decrypts under s to c*s' up to small noise (hybrid, dnum=3, partial digits)."""
+    log_n, L1, k, alpha = 12, 6, 2, 2
+    q, p, psi_q, psi_p = _chain(orc, log_n, L1, k)
+    rng = np.random.default_rng(6)
+    n = 1 << log_n
+    s = [int(v) for v in rng.integers(-1, 2, size=n)]
+    s2 = [int(v) for v in rng.integers(-1, 2, size=n)]
+    evk, s_ntt_all = _toy_keys(orc, log_n, q, p, psi_q, psi_p, alpha, s2, s, rng)
+    ql = q[:ell]
+    c = np.array([rng.integers(0, int(m), size=n, dtype=np.uint64) for m in ql])
+    ks = orc.keyswitch(c, evk, alpha, q, p, psi_q, psi_p)
+    s_ntt = s_ntt_all[:ell]
+    s2_ntt = orc.ntt_batch(np.array([[v % int(m) for v in s2] for m in ql], dtype=np.uint64), ql, psi_q[:ell])
+    lhs = orc.add(ks[0], orc.mul(ks[1], s_ntt, ql), ql)          # <ks, (1, s)>
+    rhs = orc.mul(c, s2_ntt, ql)                                 # c * s'
+    diff = orc.ntt_batch(orc.sub(lhs, rhs, ql), ql, psi_q[:ell], inverse=True)
+    err = _crt2(diff[0], diff[1], int(ql[0]), int(ql[1]))
+    assert max(abs(e) for e in err) < 2 ** 40   # noise << q (2^52): ~ N * dnum * q_digit * e / P + rounding
+
+
+def test_rotate_matches_definition(orc):
+    """orc_rotate == automorphism of (c0 + ks0, ks1) and decrypts to the rotated message polynomial."""
+    log_n, L1, k, alpha, ell = 12, 4, 2, 2, 4
+    q, p, psi_q, psi_p = _chain(orc, log_n, L1, k)
+    rng = np.random.default_rng(7)
+    n = 1 << log_n
+    g = orc.galois(log_n, 3)
+    ginv = pow(g, -1, 2 * n)
+    s = [int(v) for v in rng.integers(-1, 2, size=n)]
+    # key from sigma_{g^-1}... we need KS from s to sigma_g^{-1}(s) so that after applying sigma_g the secret is s
+    s_coeff = np.array([v % int(q[0]) for v in s], dtype=np.uint64)
+    s_perm = orc.automorph_coeff(s_coeff, ginv, int(q[0]))
+    s_perm_int = [int(v) if v < int(q[0]) // 2 else int(v) - int(q[0]) for v in s_perm]
+    evk, _ = _toy_keys(orc, log_n, q, p, psi_q, psi_p, alpha, s, s_perm_int, rng)
+    ct = np.array([[rng.integers(0, int(m), size=n, dtype=np.uint64) for m in q] for _ in range(2)])
+    out = orc.rotate(ct, evk, g, alpha, q, p, psi_q, psi_p)
+    s_ntt = orc.ntt_batch(np.array([[v % int(m) for v in s] for m in q], dtype=np.uint64), q, psi_q)
+    dec_in = orc.add(ct[0], orc.mul(ct[1], s_ntt, q), q)
+    dec_out = orc.add(out[0], orc.mul(out[1], s_ntt, q), q)
+    expect = np.array([orc.automorph_ntt(x, g) for x in dec_in])
+    diff = orc.ntt_batch(orc.sub(dec_out, expect, q), q, psi_q, inverse=True)
+    err = _crt2(diff[0], diff[1], int(q[0]), int(q[1]))
+    assert max(abs(e) for e in err) < 2 ** 40
+
+
+def test_mult_relin_by_decryption(orc):
+    log_n, L1, k, alpha = 12, 4, 2, 2
+    q, p, psi_q, psi_p = _chain(orc, log_n, L1, k)
+    rng = np.random.default_rng(8)
+    n = 1 << log_n
+    s = [int(v) for v in rng.integers(-1, 2, size=n)]
+    s_q = np.array([[v % int(m) for v in s] for m in q], dtype=np.uint64)
+    s_ntt = orc.ntt_batch(s_q, q, psi_q)
+    s2_ntt = orc.mul(s_ntt, s_ntt, q)
+    s2_coeff = orc.ntt_batch(s2_ntt, q, psi_q, inverse=True)
+    s2 = _crt2(s2_coeff[0], s2_coeff[1], int(q[0]), int(q[1]))
+    evk, _ = _toy_keys(orc, log_n, q, p, psi_q, psi_p, alpha, s2, s, rng)
+    a = np.array([[rng.integers(0, int(m), size=n, dtype=np.uint64) for m in q] for _ in range(2)])
+    b = np.array([[rng.integers(0, int(m), size=n, dtype=np.uint64) for m in q] for _ in range(2)])
+    out = orc.mult_relin(a, b, evk, alpha, q, p, psi_q, psi_p)
+    da = orc.add(a[0], orc.mul(a[1], s_ntt, q), q)
+    db = orc.add(b[0], orc.mul(b[1], s_ntt, q), q)
+    dout = orc.add(out[0], orc.mul(out[1], s_ntt, q), q)
+    diff = orc.ntt_batch(orc.sub(dout, orc.mul(da, db, q), q), q, psi_q, inverse=True)
+    err = _crt2(diff[0], diff[1], int(q[0]), int(q[1]))
+    assert max(abs(e) for e in err) < 2 ** 40
