@@ -37,6 +37,25 @@ def parse():
     return ap.parse_args()
 
 
+def host_cpus():
+    """CPUs this process may actually use: min(affinity mask, cgroup cpu quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            pr = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // pr))
+        except Exception:
+            pass
+    return n
+
+
 def micro(fa):
     eng = fa.Engine("toy", device=0)
     names = ["v_mul_lo_u32 x8", "v_mul_hi_u32 x8", "v_mad_u64_u32 x8", "harvey butterfly x4", "v_fma_f64 x64",
@@ -57,7 +76,8 @@ def cpu_baseline(eng, orc, x_one_ct, seconds):
     """Oracle (CPU port) timed on this host: forward+inverse NTT of ONE ciphertext (48 limb vectors),
     OpenMP over limb vectors on all host cores, repeated for ~`seconds`."""
     import numpy as np
-    cores = orc.num_threads()
+    cores = host_cpus()
+    orc.set_threads(cores)
     d = np.ascontiguousarray(x_one_ct.reshape(-1, eng.N)).copy()
     orc.ntt_batch(d, eng.q, eng.psi_q, inplace=True)
     orc.ntt_batch(d, eng.q, eng.psi_q, inverse=True, inplace=True)  # warm tables
