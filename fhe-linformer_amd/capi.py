@@ -68,6 +68,35 @@ def load_library():
         "fhelin_dev_download": (i32, [vp, vp, vp, C.c_size_t]),
         "fhelin_ntt": (i32, [vp, vp, i32, i32, i32, i32]),
         "fhelin_microbench": (i32, [vp, i32, i32, i32, f32p]),
+        "fhelin_keygen": (i32, [vp]),
+        "fhelin_gen_relin_key": (i32, [vp]),
+        "fhelin_gen_rotation_keys": (i32, [vp, C.POINTER(i32), i32]),
+        "fhelin_gen_conj_key": (i32, [vp]),
+        "fhelin_secret_export": (i32, [vp, vp, C.c_size_t]),
+        "fhelin_secret_import": (i32, [vp, vp, C.c_size_t]),
+        "fhelin_key_export": (i32, [vp, i32, i32, vp, C.c_size_t]),
+        "fhelin_key_import": (i32, [vp, i32, i32, vp, C.c_size_t]),
+        "fhelin_encode": (i32, [vp, C.POINTER(C.c_double), i32, i32, i32, C.POINTER(vp)]),
+        "fhelin_pt_free": (None, [vp]),
+        "fhelin_encrypt": (i32, [vp, vp, C.POINTER(vp)]),
+        "fhelin_decrypt": (i32, [vp, vp, C.POINTER(C.c_double), i32]),
+        "fhelin_ct_import": (i32, [vp, vp, i32, i32, i32, C.c_double, i32, C.POINTER(vp)]),
+        "fhelin_ct_export": (i32, [vp, vp, vp, C.c_size_t]),
+        "fhelin_ct_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(i32)]),
+        "fhelin_ct_clone": (i32, [vp, vp, C.POINTER(vp)]),
+        "fhelin_ct_free": (None, [vp]),
+        "fhelin_add": (i32, [vp, vp, vp, C.POINTER(vp)]),
+        "fhelin_sub": (i32, [vp, vp, vp, C.POINTER(vp)]),
+        "fhelin_negate": (i32, [vp, vp, C.POINTER(vp)]),
+        "fhelin_add_plain": (i32, [vp, vp, vp, C.POINTER(vp)]),
+        "fhelin_mult_plain": (i32, [vp, vp, vp, C.POINTER(vp)]),
+        "fhelin_mult": (i32, [vp, vp, vp, C.POINTER(vp)]),
+        "fhelin_rotate": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "fhelin_rescale": (i32, [vp, vp, C.POINTER(vp)]),
+        "fhelin_level_reduce": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "fhelin_raw_rescale": (i32, [vp, vp, C.POINTER(vp)]),
+        "fhelin_raw_rotate": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "fhelin_raw_mult_relin": (i32, [vp, vp, vp, C.POINTER(vp)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -182,3 +211,157 @@ class Engine:
         ms = C.c_float()
         self._ck(self.lib.fhelin_microbench(self.h, variant, iters, blocks, C.byref(ms)))
         return ms.value
+
+    # ---- keys
+    def keygen(self):
+        self._ck(self.lib.fhelin_keygen(self.h))
+
+    def gen_relin_key(self):
+        self._ck(self.lib.fhelin_gen_relin_key(self.h))
+
+    def gen_rotation_keys(self, indices):
+        arr = (C.c_int32 * len(indices))(*indices)
+        self._ck(self.lib.fhelin_gen_rotation_keys(self.h, arr, len(indices)))
+
+    @property
+    def n_limbs(self):
+        return self.n_q + self.n_p
+
+    @property
+    def dnum_digits(self):
+        return -(-self.n_q // self.alpha)
+
+    def secret_export(self):
+        out = np.empty((self.n_limbs, self.N), dtype=np.uint64)
+        self._ck(self.lib.fhelin_secret_export(self.h, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def secret_import(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        self._ck(self.lib.fhelin_secret_import(self.h, arr.ctypes.data_as(C.c_void_p), arr.size))
+
+    def key_export(self, kind, index=0):
+        out = np.empty((self.dnum_digits, 2, self.n_limbs, self.N), dtype=np.uint64)
+        self._ck(self.lib.fhelin_key_export(self.h, kind, index, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def key_import(self, kind, index, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        assert arr.shape == (self.dnum_digits, 2, self.n_limbs, self.N)
+        self._ck(self.lib.fhelin_key_import(self.h, kind, index, arr.ctypes.data_as(C.c_void_p), arr.size))
+
+    # ---- plaintexts / ciphertexts
+    def encode(self, vals, level=0, slots=0):
+        v = np.ascontiguousarray(vals, dtype=np.float64)
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_encode(self.h, v.ctypes.data_as(C.POINTER(C.c_double)), v.size, level, slots, C.byref(h)))
+        return Pt(self, h)
+
+    def encrypt(self, vals, level=0, slots=0):
+        pt = vals if isinstance(vals, Pt) else self.encode(vals, level, slots)
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_encrypt(self.h, pt.h, C.byref(h)))
+        return Ct(self, h)
+
+    def decrypt(self, ct, slots=0):
+        n = slots or ct.slots or (1 << self.params.log_slots)
+        out = np.empty(n, dtype=np.float64)
+        self._ck(self.lib.fhelin_decrypt(self.h, ct.h, out.ctypes.data_as(C.POINTER(C.c_double)), n))
+        return out
+
+    def ct_import(self, limbs, deg=1, scale=None, slots=0):
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint64)
+        npoly, ell, n = limbs.shape
+        assert n == self.N
+        if scale is None:
+            scale = float(self.scaling_factors[self.n_q - ell])
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_ct_import(self.h, limbs.ctypes.data_as(C.c_void_p), npoly, ell, deg, scale, slots, C.byref(h)))
+        return Ct(self, h)
+
+    def _un(self, fn, a, *extra):
+        h = C.c_void_p()
+        self._ck(fn(self.h, a.h, *extra, C.byref(h)))
+        return Ct(self, h)
+
+    def add(self, a, b):
+        return self._un(self.lib.fhelin_add_plain if isinstance(b, Pt) else self.lib.fhelin_add, a, b.h)
+
+    def sub(self, a, b):
+        return self._un(self.lib.fhelin_sub, a, b.h)
+
+    def negate(self, a):
+        return self._un(self.lib.fhelin_negate, a)
+
+    def mult(self, a, b):
+        return self._un(self.lib.fhelin_mult_plain if isinstance(b, Pt) else self.lib.fhelin_mult, a, b.h)
+
+    def rotate(self, a, index):
+        return self._un(self.lib.fhelin_rotate, a, index)
+
+    def rescale(self, a):
+        return self._un(self.lib.fhelin_rescale, a)
+
+    def level_reduce(self, a, new_ell):
+        return self._un(self.lib.fhelin_level_reduce, a, new_ell)
+
+    def raw_rescale(self, a):
+        return self._un(self.lib.fhelin_raw_rescale, a)
+
+    def raw_rotate(self, a, index):
+        return self._un(self.lib.fhelin_raw_rotate, a, index)
+
+    def raw_mult_relin(self, a, b):
+        return self._un(self.lib.fhelin_raw_mult_relin, a, b.h)
+
+
+class Pt:
+    def __init__(self, eng, h):
+        self.eng, self.h = eng, h
+
+    def __del__(self):
+        try:
+            if self.h and self.eng.h:
+                self.eng.lib.fhelin_pt_free(self.h)
+        except Exception:
+            pass
+        self.h = None
+
+
+class Ct:
+    def __init__(self, eng, h):
+        self.eng, self.h = eng, h
+
+    def info(self):
+        i = [C.c_int32() for _ in range(5)]
+        sc = C.c_double()
+        self.eng._ck(self.eng.lib.fhelin_ct_info(self.h, C.byref(i[0]), C.byref(i[1]), C.byref(i[2]), C.byref(i[3]), C.byref(sc), C.byref(i[4])))
+        return dict(npoly=i[0].value, ell=i[1].value, level=i[2].value, deg=i[3].value, scale=sc.value, slots=i[4].value)
+
+    @property
+    def slots(self):
+        return self.info()["slots"]
+
+    @property
+    def level(self):
+        return self.info()["level"]
+
+    def export(self):
+        inf = self.info()
+        out = np.empty((inf["npoly"], inf["ell"], self.eng.N), dtype=np.uint64)
+        self.eng._ck(self.eng.lib.fhelin_ct_export(self.eng.h, self.h, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def clone(self):
+        return self.eng._un(self.eng.lib.fhelin_ct_clone, self)
+
+    def free(self):
+        if self.h and self.eng.h:
+            self.eng.lib.fhelin_ct_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

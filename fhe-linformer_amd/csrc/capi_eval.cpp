@@ -1,0 +1,210 @@
+// extern "C" boundary, part 2: keys, plaintexts, ciphertexts, leveled evaluation.
+#include "../../include/fhelin.h"
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include "capi_internal.h"
+
+using namespace fhelin;
+
+#define NEED(x) if (!(x)) return capi_fail(FHELIN_ERR_ARG, "null argument")
+
+static fhelin_ct* wrap(const CtPtr& p) {
+    auto* h = new fhelin_ct;
+    h->p = p;
+    return h;
+}
+
+static KeyPtr& key_slot(fhelin_ctx* c, int kind, int index) {
+    if (kind == 0) return c->ev.relin_key;
+    if (kind == 1) return c->ev.rot_keys[c->ctx.galois_element(index)];
+    throw Error(FHELIN_ERR_ARG, "unknown key kind");
+}
+
+extern "C" {
+
+int fhelin_keygen(fhelin_ctx* c) {
+    NEED(c);
+    FHELIN_TRY
+    c->cl.keygen();
+    FHELIN_CATCH
+}
+int fhelin_gen_relin_key(fhelin_ctx* c) {
+    NEED(c);
+    FHELIN_TRY
+    c->cl.gen_relin_key();
+    FHELIN_CATCH
+}
+int fhelin_gen_rotation_keys(fhelin_ctx* c, const int32_t* idx, int32_t n) {
+    NEED(c && (idx || n == 0));
+    FHELIN_TRY
+    for (int i = 0; i < n; ++i) c->cl.gen_rotation_key(idx[i]);
+    FHELIN_CATCH
+}
+int fhelin_gen_conj_key(fhelin_ctx* c) {
+    NEED(c);
+    FHELIN_TRY
+    c->cl.gen_conj_key();
+    FHELIN_CATCH
+}
+int fhelin_secret_export(fhelin_ctx* c, uint64_t* out, size_t cap) {
+    NEED(c && out);
+    FHELIN_TRY
+    if (cap < (size_t)(c->ctx.L + 1 + c->ctx.K) * c->ctx.N) throw Error(FHELIN_ERR_ARG, "buffer too small");
+    c->cl.export_secret(out);
+    FHELIN_CATCH
+}
+int fhelin_secret_import(fhelin_ctx* c, const uint64_t* in, size_t words) {
+    NEED(c && in);
+    FHELIN_TRY
+    if (words != (size_t)(c->ctx.L + 1 + c->ctx.K) * c->ctx.N) throw Error(FHELIN_ERR_ARG, "secret must be [L+1+k][N]");
+    c->cl.import_secret(in);
+    FHELIN_CATCH
+}
+int fhelin_key_export(fhelin_ctx* c, int32_t kind, int32_t index, uint64_t* out, size_t cap) {
+    NEED(c && out);
+    FHELIN_TRY
+    c->ctx.require_device();
+    KeyPtr k = key_slot(c, kind, index);
+    if (!k) throw Error(FHELIN_ERR_KEY, "key not present");
+    if (cap < k->words()) throw Error(FHELIN_ERR_ARG, "buffer too small");
+    hip_check(hipMemcpyAsync(out, k->d, k->words() * 8, hipMemcpyDeviceToHost, c->ctx.stream), "key export");
+    c->ctx.sync();
+    FHELIN_CATCH
+}
+int fhelin_key_import(fhelin_ctx* c, int32_t kind, int32_t index, const uint64_t* in, size_t words) {
+    NEED(c && in);
+    FHELIN_TRY
+    c->ctx.require_device();
+    KeyPtr k = c->ev.new_key();
+    if (words != k->words()) throw Error(FHELIN_ERR_ARG, "key must be [dnum][2][L+1+k][N]");
+    hip_check(hipMemcpyAsync(k->d, in, words * 8, hipMemcpyHostToDevice, c->ctx.stream), "key import");
+    c->ctx.sync();
+    key_slot(c, kind, index) = k;
+    FHELIN_CATCH
+}
+
+int fhelin_encode(fhelin_ctx* c, const double* vals, int32_t n, int32_t level, int32_t slots, fhelin_pt** out) {
+    NEED(c && out && (vals || n == 0));
+    FHELIN_TRY
+    auto* h = new fhelin_pt;
+    h->p = c->cl.encode(vals, n, level, slots);
+    *out = h;
+    FHELIN_CATCH
+}
+void fhelin_pt_free(fhelin_pt* p) { delete p; }
+
+int fhelin_encrypt(fhelin_ctx* c, const fhelin_pt* p, fhelin_ct** out) {
+    NEED(c && p && out);
+    FHELIN_TRY
+    *out = wrap(c->cl.encrypt(p->p));
+    FHELIN_CATCH
+}
+int fhelin_decrypt(fhelin_ctx* c, const fhelin_ct* ct, double* out, int32_t slots) {
+    NEED(c && ct && out);
+    FHELIN_TRY
+    auto v = c->cl.decrypt(ct->p, slots);
+    std::memcpy(out, v.data(), v.size() * sizeof(double));
+    FHELIN_CATCH
+}
+int fhelin_ct_import(fhelin_ctx* c, const uint64_t* limbs, int32_t npoly, int32_t ell, int32_t deg, double scale, int32_t slots,
+                     fhelin_ct** out) {
+    NEED(c && limbs && out);
+    FHELIN_TRY
+    CtPtr p = c->ev.new_ct(npoly, ell, deg, scale, slots);
+    hip_check(hipMemcpyAsync(p->d, limbs, p->words() * 8, hipMemcpyHostToDevice, c->ctx.stream), "ct import");
+    c->ctx.sync();
+    *out = wrap(p);
+    FHELIN_CATCH
+}
+int fhelin_ct_export(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* out, size_t cap) {
+    NEED(c && ct && out);
+    FHELIN_TRY
+    if (cap < ct->p->words()) throw Error(FHELIN_ERR_ARG, "buffer too small");
+    hip_check(hipMemcpyAsync(out, ct->p->d, ct->p->words() * 8, hipMemcpyDeviceToHost, c->ctx.stream), "ct export");
+    c->ctx.sync();
+    FHELIN_CATCH
+}
+int fhelin_ct_info(const fhelin_ct* ct, int32_t* npoly, int32_t* ell, int32_t* level, int32_t* deg, double* scale, int32_t* slots) {
+    NEED(ct);
+    if (npoly) *npoly = ct->p->npoly;
+    if (ell) *ell = ct->p->ell;
+    if (level) *level = ct->p->level();
+    if (deg) *deg = ct->p->deg;
+    if (scale) *scale = (double)ct->p->scale;
+    if (slots) *slots = ct->p->slots;
+    return FHELIN_OK;
+}
+int fhelin_ct_clone(fhelin_ctx* c, const fhelin_ct* ct, fhelin_ct** out) {
+    NEED(c && ct && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.clone(ct->p));
+    FHELIN_CATCH
+}
+void fhelin_ct_free(fhelin_ct* ct) { delete ct; }
+
+#define BINOP(name, expr)                                                                   \
+    int name(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b, fhelin_ct** out) {      \
+        NEED(c && a && b && out);                                                           \
+        FHELIN_TRY                                                                          \
+        *out = wrap(expr);                                                                  \
+        FHELIN_CATCH                                                                        \
+    }
+BINOP(fhelin_add, c->ev.add(a->p, b->p))
+BINOP(fhelin_sub, c->ev.sub(a->p, b->p))
+BINOP(fhelin_mult, c->ev.mult(a->p, b->p))
+BINOP(fhelin_raw_mult_relin, (c->ev.relin_key ? c->ev.raw_mult_relin(a->p, b->p, *c->ev.relin_key)
+                                              : throw Error(FHELIN_ERR_KEY, "no relinearisation key")))
+
+int fhelin_negate(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.negate(a->p));
+    FHELIN_CATCH
+}
+int fhelin_add_plain(fhelin_ctx* c, const fhelin_ct* a, const fhelin_pt* p, fhelin_ct** out) {
+    NEED(c && a && p && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.add_plain(a->p, p->p));
+    FHELIN_CATCH
+}
+int fhelin_mult_plain(fhelin_ctx* c, const fhelin_ct* a, const fhelin_pt* p, fhelin_ct** out) {
+    NEED(c && a && p && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.mult_plain(a->p, p->p));
+    FHELIN_CATCH
+}
+int fhelin_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.rotate(a->p, index));
+    FHELIN_CATCH
+}
+int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.rescale(a->p));
+    FHELIN_CATCH
+}
+int fhelin_level_reduce(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.level_reduce(a->p, new_ell));
+    FHELIN_CATCH
+}
+int fhelin_raw_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.raw_rescale(a->p));
+    FHELIN_CATCH
+}
+int fhelin_raw_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    const u64 g = c->ctx.galois_element(index);
+    auto it = c->ev.rot_keys.find(g);
+    if (it == c->ev.rot_keys.end() || !it->second) throw Error(FHELIN_ERR_KEY, "no rotation key for this index");
+    *out = wrap(c->ev.raw_rotate(a->p, g, *it->second));
+    FHELIN_CATCH
+}
+
+}  // extern "C"

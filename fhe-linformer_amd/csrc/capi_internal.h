@@ -3,11 +3,21 @@
 #include <exception>
 #include <string>
 #include "context.h"
+#include "evaluator.h"
+#include "client.h"
 
 // opaque handle behind include/fhelin.h's `fhelin_ctx`
 struct fhelin_ctx {
     fhelin::Context ctx;
-    explicit fhelin_ctx(const fhelin::Params& p) : ctx(p) {}
+    fhelin::Evaluator ev;
+    fhelin::Client cl;
+    explicit fhelin_ctx(const fhelin::Params& p) : ctx(p), ev(ctx), cl(ev, p.seed) {}
+};
+struct fhelin_ct {
+    fhelin::CtPtr p;
+};
+struct fhelin_pt {
+    fhelin::PtPtr p;
 };
 
 namespace fhelin {

@@ -1,0 +1,435 @@
+#include "client.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <map>
+#include <mutex>
+
+namespace fhelin {
+
+// ------------------------------------------------------------------------------------------------ PRNG
+static u64 splitmix(u64& x) {
+    u64 z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+Prng::Prng(u64 seed) {
+    for (auto& w : s) w = splitmix(seed);
+}
+static inline u64 rotl(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
+u64 Prng::next() {  // xoshiro256**
+    const u64 r = rotl(s[1] * 5, 7) * 9;
+    const u64 t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl(s[3], 45);
+    return r;
+}
+u64 Prng::uniform(u64 q) {
+    const u64 lim = ~0ull - (~0ull % q + 1) % q;  // largest multiple of q minus one
+    u64 x;
+    do {
+        x = next();
+    } while (x > lim);
+    return x % q;
+}
+double Prng::normal() {
+    if (have_spare) {
+        have_spare = false;
+        return spare;
+    }
+    double u1, u2;
+    do {
+        u1 = (next() >> 11) * (1.0 / 9007199254740992.0);
+    } while (u1 <= 0.0);
+    u2 = (next() >> 11) * (1.0 / 9007199254740992.0);
+    const double r = std::sqrt(-2.0 * std::log(u1)), th = 6.283185307179586476925 * u2;
+    spare = r * std::sin(th);
+    have_spare = true;
+    return r * std::cos(th);
+}
+
+// ------------------------------------------------------------------------------------------------ special FFT
+namespace {
+struct FftTables {
+    std::vector<u32> rot;                         // 5^j mod 4*slots
+    std::vector<std::complex<double>> ksi;        // exp(2 pi i k / (4*slots)), k in [0, 4*slots]
+};
+std::map<int, FftTables> g_fft;
+std::mutex g_fft_mu;
+const FftTables& fft_tables(int slots) {
+    std::lock_guard<std::mutex> lk(g_fft_mu);
+    auto it = g_fft.find(slots);
+    if (it != g_fft.end()) return it->second;
+    FftTables t;
+    const u32 m = 4u * slots;
+    t.rot.resize(slots);
+    u32 p = 1;
+    for (int j = 0; j < slots; ++j) {
+        t.rot[j] = p;
+        p = (u32)(((u64)p * 5) % m);
+    }
+    t.ksi.resize(m + 1);
+    for (u32 k = 0; k <= m; ++k) {
+        const long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)m;
+        t.ksi[k] = {(double)cosl(a), (double)sinl(a)};
+    }
+    return g_fft.emplace(slots, std::move(t)).first->second;
+}
+void bit_reverse(std::vector<std::complex<double>>& v) {
+    const size_t n = v.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j >= bit; bit >>= 1) j -= bit;
+        j += bit;
+        if (i < j) std::swap(v[i], v[j]);
+    }
+}
+}  // namespace
+
+// canonical embedding restricted to the rotation group <5>: forward = decode direction
+void ckks_fft_special(std::vector<std::pair<double, double>>& pv, bool inverse) {
+    const int size = (int)pv.size();
+    const FftTables& t = fft_tables(size);
+    const int m = 4 * size;
+    std::vector<std::complex<double>> v(size);
+    for (int i = 0; i < size; ++i) v[i] = {pv[i].first, pv[i].second};
+    if (!inverse) {
+        bit_reverse(v);
+        for (int len = 2; len <= size; len <<= 1) {
+            const int lenh = len >> 1, lenq = len << 2, gap = m / lenq;
+            for (int i = 0; i < size; i += len)
+                for (int j = 0; j < lenh; ++j) {
+                    const int idx = (t.rot[j] % lenq) * gap;
+                    const auto u = v[i + j], w = v[i + j + lenh] * t.ksi[idx];
+                    v[i + j] = u + w;
+                    v[i + j + lenh] = u - w;
+                }
+        }
+    } else {
+        for (int len = size; len >= 2; len >>= 1) {
+            const int lenh = len >> 1, lenq = len << 2, gap = m / lenq;
+            for (int i = 0; i < size; i += len)
+                for (int j = 0; j < lenh; ++j) {
+                    const int idx = (lenq - (t.rot[j] % lenq)) * gap;
+                    const auto u = v[i + j] + v[i + j + lenh];
+                    const auto w = (v[i + j] - v[i + j + lenh]) * t.ksi[idx];
+                    v[i + j] = u;
+                    v[i + j + lenh] = w;
+                }
+        }
+        bit_reverse(v);
+        const double inv = 1.0 / size;
+        for (auto& x : v) x *= inv;
+    }
+    for (int i = 0; i < size; ++i) pv[i] = {v[i].real(), v[i].imag()};
+}
+
+static void ld_to_i128(long double v, u64& lo, u64& hi) {
+    const bool neg = v < 0;
+    long double mag = roundl(fabsl(v));
+    const long double two64 = 18446744073709551616.0L;
+    u64 h = (u64)floorl(mag / two64);
+    u64 l = (u64)(mag - (long double)h * two64);
+    if (neg) {
+        l = ~l + 1;
+        h = ~h + (l == 0);
+    }
+    lo = l;
+    hi = h;
+}
+
+std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>& values, int slots, int ell, long double scale) {
+    c.require_device();
+    if (slots < 1 || (slots & (slots - 1)) || slots > c.N / 2) throw Error(FHELIN_ERR_ARG, "encode: slots must be a power of two <= N/2");
+    if (ell < 1 || ell > c.L + 1) throw Error(FHELIN_ERR_ARG, "encode: level out of range");
+    std::vector<std::pair<double, double>> v(slots, {0.0, 0.0});
+    for (int i = 0; i < slots && i < (int)values.size(); ++i) v[i].first = values[i];
+    ckks_fft_special(v, true);
+    const size_t N = c.N;
+    const size_t gap = (N / 2) / slots;
+    std::vector<u64> coeffs(2 * N, 0);
+    for (int i = 0; i < slots; ++i) {
+        ld_to_i128((long double)v[i].first * scale, coeffs[2 * (i * gap)], coeffs[2 * (i * gap) + 1]);
+        ld_to_i128((long double)v[i].second * scale, coeffs[2 * (i * gap + N / 2)], coeffs[2 * (i * gap + N / 2) + 1]);
+    }
+    u64* dco = c.dalloc<u64>(2 * N);
+    hip_check(hipMemcpyAsync(dco, coeffs.data(), 2 * N * 8, hipMemcpyHostToDevice, c.stream), "encode upload");
+    hip_check(hipStreamSynchronize(c.stream), "encode sync");  // coeffs is pageable host memory
+    auto e = std::make_shared<Encoding>();
+    e->ctx = &c;
+    e->ell = ell;
+    e->scale = scale;
+    e->d = c.dalloc<u64>((size_t)ell * N);
+    launch_reduce_i128(c.dt, e->d, dco, 0, ell, c.stream);
+    launch_ntt(c.dt, LimbBatch{e->d, ell, nullptr, 0, ell}, false, c.stream);
+    hip_check(hipGetLastError(), "encode kernels");
+    c.pool.free(dco);
+    return e;
+}
+
+std::shared_ptr<Encoding> Plaintext::at(int ell, long double scale) {
+    for (auto& e : cache)
+        if (e->ell == ell && fabsl(e->scale / scale - 1.0L) < 1e-12L) return e;
+    auto e = encode_to_device(*ctx, values, slots, ell, scale);
+    cache.push_back(e);
+    return e;
+}
+
+// ------------------------------------------------------------------------------------------------ Client
+Client::Client(Evaluator& ev, u64 seed) : ev_(ev), c_(ev.ctx()), rng_(seed) {}
+Client::~Client() {
+    try {
+        if (s_all) c_.pool.free(s_all);
+        if (pk) c_.pool.free(pk);
+    } catch (...) {
+    }
+}
+
+// sample a small polynomial on the host, reduce it into `nl` limbs on the GPU and transform to NTT form
+void Client::sample_small_to_ntt(u64* dst, int nlimbs_q, bool with_p, int kind) {
+    const size_t N = c_.N;
+    std::vector<u64> co(2 * N);
+    for (size_t i = 0; i < N; ++i) {
+        long v;
+        if (kind == 0) v = lround(rng_.normal() * 3.19);
+        else v = (long)(rng_.next() % 3) - 1;
+        co[2 * i] = (u64)v;
+        co[2 * i + 1] = v < 0 ? ~0ull : 0;
+    }
+    u64* dco = c_.dalloc<u64>(2 * N);
+    hip_check(hipMemcpyAsync(dco, co.data(), 2 * N * 8, hipMemcpyHostToDevice, c_.stream), "sample upload");
+    hip_check(hipStreamSynchronize(c_.stream), "sample sync");
+    launch_reduce_i128(c_.dt, dst, dco, 0, nlimbs_q, c_.stream);
+    launch_ntt(c_.dt, LimbBatch{dst, nlimbs_q, nullptr, 0, nlimbs_q}, false, c_.stream);
+    if (with_p && c_.K > 0) {
+        u64* dp = dst + (size_t)nlimbs_q * N;
+        launch_reduce_i128(c_.dt, dp, dco, c_.L + 1, c_.K, c_.stream);
+        launch_ntt(c_.dt, LimbBatch{dp, c_.K, nullptr, c_.L + 1, c_.K}, false, c_.stream);
+    }
+    c_.pool.free(dco);
+}
+
+void Client::keygen() {
+    c_.require_device();
+    const size_t N = c_.N;
+    const int L1 = c_.L + 1, nl = L1 + c_.K;
+    // sparse ternary secret of Hamming weight h (reference SetSecretKeyDist(SPARSE_TERNARY), :8)
+    std::vector<u64> co(2 * N, 0);
+    int h = std::min<int>(c_.prm.hamming, (int)N);
+    int placed = 0;
+    while (placed < h) {
+        size_t pos = rng_.uniform(N);
+        if (co[2 * pos] | co[2 * pos + 1]) continue;
+        if (rng_.next() & 1) {
+            co[2 * pos] = 1;
+        } else {
+            co[2 * pos] = ~0ull;
+            co[2 * pos + 1] = ~0ull;
+        }
+        ++placed;
+    }
+    if (!s_all) s_all = c_.dalloc<u64>((size_t)nl * N);
+    u64* dco = c_.dalloc<u64>(2 * N);
+    hip_check(hipMemcpyAsync(dco, co.data(), 2 * N * 8, hipMemcpyHostToDevice, c_.stream), "secret upload");
+    hip_check(hipStreamSynchronize(c_.stream), "secret sync");
+    launch_reduce_i128(c_.dt, s_all, dco, 0, nl, c_.stream);
+    launch_ntt(c_.dt, LimbBatch{s_all, nl, nullptr, 0, nl}, false, c_.stream);
+    c_.pool.free(dco);
+    // public key over Q: a uniform (sampled directly in NTT form), b = e - a s
+    if (!pk) pk = c_.dalloc<u64>((size_t)2 * L1 * N);
+    std::vector<u64> a((size_t)L1 * N);
+    for (int l = 0; l < L1; ++l)
+        for (size_t i = 0; i < N; ++i) a[(size_t)l * N + i] = rng_.uniform(c_.chain.q[l]);
+    u64* pa = pk + (size_t)L1 * N;
+    hip_check(hipMemcpyAsync(pa, a.data(), a.size() * 8, hipMemcpyHostToDevice, c_.stream), "pk upload");
+    hip_check(hipStreamSynchronize(c_.stream), "pk sync");
+    u64* e = c_.dalloc<u64>((size_t)L1 * N);
+    sample_small_to_ntt(e, L1, false, 0);
+    launch_ew_mul(c_.dt, pk, pa, s_all, L1, L1, 0, L1, c_.stream);
+    launch_ew_sub(c_.dt, pk, e, pk, L1, L1, 0, L1, c_.stream);
+    hip_check(hipGetLastError(), "keygen kernels");
+    c_.pool.free(e);
+}
+
+KeyPtr Client::make_switch_key(const u64* s_from_all, const u64* s_to_all) {
+    c_.require_device();
+    if (c_.K < 1) throw Error(FHELIN_ERR_STATE, "key switching keys need special primes (n_p >= 1)");
+    const size_t N = c_.N;
+    const int L1 = c_.L + 1, nl = L1 + c_.K;
+    KeyPtr key = ev_.new_key();
+    std::vector<u64> a((size_t)nl * N);
+    u64* e = c_.dalloc<u64>((size_t)nl * N);
+    u64* tmp = c_.dalloc<u64>((size_t)nl * N);
+    for (int j = 0; j < key->digits; ++j) {
+        u64* kb = key->d + (size_t)(2 * j) * nl * N;
+        u64* ka = key->d + (size_t)(2 * j + 1) * nl * N;
+        for (int l = 0; l < nl; ++l) {
+            const u64 m = c_.moduli[l];
+            for (size_t i = 0; i < N; ++i) a[(size_t)l * N + i] = rng_.uniform(m);
+        }
+        hip_check(hipMemcpyAsync(ka, a.data(), a.size() * 8, hipMemcpyHostToDevice, c_.stream), "evk upload");
+        hip_check(hipStreamSynchronize(c_.stream), "evk sync");
+        sample_small_to_ntt(e, L1, true, 0);
+        launch_ew_mul(c_.dt, tmp, ka, s_to_all, nl, nl, 0, nl, c_.stream);
+        launch_ew_sub(c_.dt, kb, e, tmp, nl, nl, 0, nl, c_.stream);
+        // + P * (Q/Q_j) * [(Q/Q_j)^{-1}]_{Q_j} * s_from  ==  (P mod q_t) * s_from on the limbs of digit j, 0 elsewhere
+        const int lo = j * c_.alpha, hi = std::min((j + 1) * c_.alpha, L1);
+        ScalarSet sc;
+        for (int t = lo; t < hi; ++t) {
+            const u64 qt = c_.chain.q[t];
+            u64 pm = 1;
+            for (u64 p : c_.chain.p) pm = h_mulmod(pm, p % qt, qt);
+            sc.v[2 * (t - lo)] = pm;
+            sc.v[2 * (t - lo) + 1] = h_shoup(pm, qt);
+        }
+        launch_ew_scalar(c_.dt, tmp, s_from_all + (size_t)lo * N, sc, hi - lo, lo, hi - lo, c_.stream);
+        launch_ew_add(c_.dt, kb + (size_t)lo * N, kb + (size_t)lo * N, tmp, hi - lo, hi - lo, lo, hi - lo, c_.stream);
+    }
+    hip_check(hipGetLastError(), "make_switch_key kernels");
+    c_.pool.free(e);
+    c_.pool.free(tmp);
+    return key;
+}
+
+void Client::gen_relin_key() {
+    if (!s_all) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
+    const int nl = c_.L + 1 + c_.K;
+    u64* s2 = c_.dalloc<u64>((size_t)nl * c_.N);
+    launch_ew_mul(c_.dt, s2, s_all, s_all, nl, nl, 0, nl, c_.stream);
+    ev_.relin_key = make_switch_key(s2, s_all);
+    c_.pool.free(s2);
+}
+
+void Client::gen_rotation_key(int index) {
+    if (!s_all) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
+    const u64 g = c_.galois_element(index);
+    if (ev_.rot_keys.count(g)) return;
+    const int nl = c_.L + 1 + c_.K;
+    // key switches from s to sigma_{g^-1}(s); applying sigma_g afterwards restores s (oracle orc_rotate)
+    const u64 ginv = c_.galois_element(-index);
+    u64* sp = c_.dalloc<u64>((size_t)nl * c_.N);
+    launch_automorph(c_.dt, sp, s_all, c_.automorph_map(ginv), nl, c_.stream);
+    ev_.rot_keys[g] = make_switch_key(s_all, sp);
+    c_.pool.free(sp);
+}
+
+void Client::gen_conj_key() {
+    if (!s_all) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
+    const u64 g = 2ull * c_.N - 1;  // X -> X^{-1}; its own inverse
+    const int nl = c_.L + 1 + c_.K;
+    u64* sp = c_.dalloc<u64>((size_t)nl * c_.N);
+    launch_automorph(c_.dt, sp, s_all, c_.automorph_map(g), nl, c_.stream);
+    ev_.conj_key = make_switch_key(s_all, sp);
+    ev_.rot_keys[g] = ev_.conj_key;
+    c_.pool.free(sp);
+}
+
+PtPtr Client::encode(const double* vals, int n, int level, int slots) {
+    if (slots <= 0) slots = 1 << c_.prm.log_slots;
+    if (slots & (slots - 1)) throw Error(FHELIN_ERR_ARG, "encode: slots must be a power of two");
+    if (level < 0 || level > c_.L) throw Error(FHELIN_ERR_ARG, "encode: level out of range");
+    auto p = std::make_shared<Plaintext>();
+    p->ctx = &c_;
+    p->slots = slots;
+    p->level = level;
+    p->values.assign(slots, 0.0);
+    for (int i = 0; i < n && i < slots; ++i) p->values[i] = vals[i];
+    return p;
+}
+
+CtPtr Client::encrypt(const PtPtr& p) {
+    if (!pk) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
+    const int L1 = c_.L + 1;
+    const int ell = L1 - p->level;
+    const size_t N = c_.N, pn = (size_t)ell * N;
+    auto enc = p->at(ell, c_.sf_real[p->level]);
+    CtPtr ct = ev_.new_ct(2, ell, 1, enc->scale, p->slots);
+    u64* u = c_.dalloc<u64>(pn);
+    u64* e = c_.dalloc<u64>(pn);
+    sample_small_to_ntt(u, ell, false, 1);
+    // c0 = b u + e0 + m ; c1 = a u + e1
+    sample_small_to_ntt(e, ell, false, 0);
+    launch_ew_muladd(c_.dt, ct->d, e, pk, u, ell, ell, 0, ell, c_.stream);
+    launch_ew_add(c_.dt, ct->d, ct->d, enc->d, ell, ell, 0, ell, c_.stream);
+    sample_small_to_ntt(e, ell, false, 0);
+    launch_ew_muladd(c_.dt, ct->d + pn, e, pk + (size_t)L1 * N, u, ell, ell, 0, ell, c_.stream);
+    hip_check(hipGetLastError(), "encrypt kernels");
+    c_.pool.free(u);
+    c_.pool.free(e);
+    return ct;
+}
+
+std::vector<double> Client::decrypt(const CtPtr& cin, int slots) {
+    if (!s_all) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
+    CtPtr ct = cin;
+    while (ct->deg > 1 && ct->ell > 2) ct = ev_.rescale(ct);
+    if (slots <= 0) slots = ct->slots > 0 ? ct->slots : (1 << c_.prm.log_slots);
+    const size_t N = c_.N;
+    const int ell = ct->ell, nl = std::min(ell, 2);
+    const size_t pn = (size_t)ell * N;
+    u64* m = c_.dalloc<u64>((size_t)nl * N);
+    // m = c0 + c1 s (+ c2 s^2) on the first nl limbs
+    launch_ew_muladd(c_.dt, m, ct->d, ct->d + pn, s_all, nl, nl, 0, nl, c_.stream);
+    if (ct->npoly == 3) {
+        u64* s2 = c_.dalloc<u64>((size_t)nl * N);
+        launch_ew_mul(c_.dt, s2, s_all, s_all, nl, nl, 0, nl, c_.stream);
+        launch_ew_muladd(c_.dt, m, m, ct->d + 2 * pn, s2, nl, nl, 0, nl, c_.stream);
+        c_.pool.free(s2);
+    }
+    launch_ntt(c_.dt, LimbBatch{m, nl, nullptr, 0, nl}, true, c_.stream);
+    std::vector<u64> h((size_t)nl * N);
+    hip_check(hipMemcpyAsync(h.data(), m, h.size() * 8, hipMemcpyDeviceToHost, c_.stream), "decrypt download");
+    hip_check(hipStreamSynchronize(c_.stream), "decrypt sync");
+    c_.pool.free(m);
+    const u64 q0 = c_.chain.q[0];
+    const size_t gap = (N / 2) / slots;
+    std::vector<std::pair<double, double>> v(slots);
+    auto lift = [&](size_t idx) -> long double {
+        if (nl == 1) {
+            u64 x = h[idx];
+            return x > q0 / 2 ? -(long double)(q0 - x) : (long double)x;
+        }
+        const u64 q1 = c_.chain.q[1];
+        const u64 x0 = h[idx], x1 = h[N + idx];
+        const u64 inv = h_invmod(q0 % q1, q1);
+        const u64 d = h_mulmod(sub_mod(x1, x0 % q1, q1), inv, q1);
+        const u128 Q = (u128)q0 * q1;
+        const u128 x = (u128)x0 + (u128)q0 * d;
+        if (x > Q / 2) {
+            const u128 mag = Q - x;
+            return -((long double)(u64)(mag >> 64) * 18446744073709551616.0L + (long double)(u64)mag);
+        }
+        return (long double)(u64)(x >> 64) * 18446744073709551616.0L + (long double)(u64)x;
+    };
+    for (int i = 0; i < slots; ++i) {
+        v[i].first = (double)(lift(i * gap) / ct->scale);
+        v[i].second = (double)(lift(i * gap + N / 2) / ct->scale);
+    }
+    ckks_fft_special(v, false);
+    std::vector<double> out(slots);
+    for (int i = 0; i < slots; ++i) out[i] = v[i].first;
+    return out;
+}
+
+void Client::export_secret(u64* out) {
+    if (!s_all) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
+    const size_t n = (size_t)(c_.L + 1 + c_.K) * c_.N;
+    hip_check(hipMemcpyAsync(out, s_all, n * 8, hipMemcpyDeviceToHost, c_.stream), "export secret");
+    hip_check(hipStreamSynchronize(c_.stream), "sync");
+}
+
+void Client::import_secret(const u64* in) {
+    c_.require_device();
+    const size_t n = (size_t)(c_.L + 1 + c_.K) * c_.N;
+    if (!s_all) s_all = c_.dalloc<u64>(n);
+    hip_check(hipMemcpyAsync(s_all, in, n * 8, hipMemcpyHostToDevice, c_.stream), "import secret");
+    hip_check(hipStreamSynchronize(c_.stream), "sync");
+}
+
+}  // namespace fhelin

@@ -1,0 +1,54 @@
+// Client-side CKKS: key generation, encode/decode (special FFT, fp64), public-key encryption, decryption.
+// Mirrors reference FHEController::generate_context / generate_*_keys / encode / encrypt / decrypt
+// (src/FHEController.cpp:47-49, :237-273, :348-404).  Sampling and the fp64 FFT run on the host (as in the
+// reference); every residue-polynomial operation (NTT, dyadic products) runs on the GPU kernels.
+#pragma once
+#include <vector>
+#include "evaluator.h"
+
+namespace fhelin {
+
+struct Prng {
+    u64 s[4];
+    explicit Prng(u64 seed);
+    u64 next();
+    u64 uniform(u64 q);        // unbiased in [0, q)
+    double normal();           // standard normal (Box-Muller)
+private:
+    bool have_spare = false;
+    double spare = 0;
+};
+
+class Client {
+public:
+    Client(Evaluator& ev, u64 seed);
+    ~Client();
+    void keygen();                       // secret (sparse ternary) + public key
+    bool has_keys() const { return s_all != nullptr; }
+    void gen_relin_key();                // EvalMultKeyGen
+    void gen_rotation_key(int index);    // EvalRotateKeyGen for one index
+    void gen_conj_key();
+    KeyPtr make_switch_key(const u64* s_from_all, const u64* s_to_all);  // device [L+1+k][N] NTT form
+
+    PtPtr encode(const double* vals, int n, int level, int slots);
+    CtPtr encrypt(const PtPtr& p);
+    std::vector<double> decrypt(const CtPtr& c, int slots);
+
+    // raw import/export of key material (parity tests feed identical arrays to the oracle)
+    void export_secret(u64* out);        // [L+1+k][N]
+    void import_secret(const u64* in);   // replaces the secret (NTT form) — tests only
+
+private:
+    Evaluator& ev_;
+    Context& c_;
+    Prng rng_;
+    u64* s_all = nullptr;   // secret, NTT form over Q and P limbs [L+1+k][N]
+    u64* pk = nullptr;      // [2][L+1][N]: b = -a s + e, a
+    void sample_small_to_ntt(u64* dst, int nlimbs_q, bool with_p, int kind);  // kind 0 gaussian, 1 ternary
+};
+
+// special FFT helpers (shared by encode/decode); slots must be a power of two
+void ckks_fft_special(std::vector<std::pair<double, double>>& v, bool inverse);
+std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>& values, int slots, int ell, long double scale);
+
+}  // namespace fhelin

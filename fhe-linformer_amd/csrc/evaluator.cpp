@@ -1,0 +1,282 @@
+#include "evaluator.h"
+#include <hip/hip_runtime.h>
+#include <cmath>
+
+namespace fhelin {
+
+Ciphertext::~Ciphertext() {
+    if (d && ctx) {
+        try { ctx->pool.free(d); } catch (...) {}
+    }
+}
+Encoding::~Encoding() {
+    if (d && ctx) {
+        try { ctx->pool.free(d); } catch (...) {}
+    }
+}
+EvalKey::~EvalKey() {
+    if (d && ctx) {
+        try { ctx->pool.free(d); } catch (...) {}
+    }
+}
+
+static void launch_ok(const char* what) { hip_check(hipGetLastError(), what); }
+
+CtPtr Evaluator::new_ct(int npoly, int ell, int deg, long double scale, int slots) {
+    c_.require_device();
+    if (ell < 1 || ell > c_.L + 1 || npoly < 1 || npoly > 3) throw Error(FHELIN_ERR_ARG, "new_ct: bad shape");
+    auto ct = std::make_shared<Ciphertext>();
+    ct->ctx = &c_;
+    ct->npoly = npoly;
+    ct->ell = ell;
+    ct->deg = deg;
+    ct->scale = scale;
+    ct->slots = slots;
+    ct->d = c_.dalloc<u64>(ct->words());
+    return ct;
+}
+
+CtPtr Evaluator::clone(const CtPtr& a) {
+    CtPtr o = new_ct(a->npoly, a->ell, a->deg, a->scale, a->slots);
+    hip_check(hipMemcpyAsync(o->d, a->d, a->words() * 8, hipMemcpyDeviceToDevice, c_.stream), "clone");
+    return o;
+}
+
+KeyPtr Evaluator::new_key() {
+    c_.require_device();
+    auto k = std::make_shared<EvalKey>();
+    k->ctx = &c_;
+    k->digits = c_.digits_at(c_.L + 1);
+    k->d = c_.dalloc<u64>(k->words());
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------------
+void Evaluator::keyswitch(const u64* c_ntt, int ell, const EvalKey& key, u64* out, const u64* add0, const u64* add1,
+                          const u32* map) {
+    c_.require_device();
+    if (c_.K < 1) throw Error(FHELIN_ERR_STATE, "hybrid key switching needs at least one special prime");
+    const size_t N = c_.N;
+    const int K = c_.K, L1 = c_.L + 1;
+    const LevelTables& lt = c_.lvl[ell];
+    KsShape sh{ell, K, c_.alpha, lt.beta, L1};
+    hipStream_t s = c_.stream;
+    u64* cc = c_.dalloc<u64>((size_t)ell * N);
+    hip_check(hipMemcpyAsync(cc, c_ntt, (size_t)ell * N * 8, hipMemcpyDeviceToDevice, s), "ks copy");
+    launch_ntt(c_.dt, LimbBatch{cc, ell, nullptr, 0, ell}, true, s);
+    u64* ext = c_.dalloc<u64>((size_t)lt.beta * (ell + K) * N);
+    launch_modup_conv(c_.dt, sh, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod, s);
+    launch_ntt(c_.dt, LimbBatch{ext, lt.beta * (ell + K), lt.ext_limb_tab, 0, 1}, false, s);
+    u64* accQ = c_.dalloc<u64>((size_t)2 * ell * N);
+    u64* accP = c_.dalloc<u64>((size_t)2 * K * N);
+    launch_ks_inner(c_.dt, sh, accQ, accP, ext, key.d, s);
+    launch_ntt(c_.dt, LimbBatch{accP, 2 * K, nullptr, L1, K}, true, s);
+    u64* conv = c_.dalloc<u64>((size_t)2 * ell * N);
+    launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
+    launch_ntt(c_.dt, LimbBatch{conv, 2 * ell, nullptr, 0, ell}, false, s);
+    launch_moddown_finish(c_.dt, sh, out, accQ, conv, c_.d_pinv, add0, add1, map, s);
+    launch_ok("keyswitch");
+    c_.pool.free(cc);
+    c_.pool.free(ext);
+    c_.pool.free(accQ);
+    c_.pool.free(accP);
+    c_.pool.free(conv);
+}
+
+// ------------------------------------------------------------------------------------------------ raw ops
+CtPtr Evaluator::raw_rescale(const CtPtr& a) {
+    const int ell = a->ell, P = a->npoly;
+    if (ell < 2) throw Error(FHELIN_ERR_STATE, "rescale: no limb left to drop");
+    const size_t N = c_.N;
+    hipStream_t s = c_.stream;
+    u64* last = c_.dalloc<u64>((size_t)P * N);
+    for (int p = 0; p < P; ++p)
+        hip_check(hipMemcpyAsync(last + p * N, a->d + ((size_t)p * ell + ell - 1) * N, N * 8, hipMemcpyDeviceToDevice, s), "rescale copy");
+    launch_ntt(c_.dt, LimbBatch{last, P, nullptr, ell - 1, 1}, true, s);
+    u64* lifted = c_.dalloc<u64>((size_t)P * (ell - 1) * N);
+    launch_rescale_lift(c_.dt, lifted, last, P, ell, c_.d_qlmod + (size_t)(ell - 1) * (c_.L + 1), s);
+    launch_ntt(c_.dt, LimbBatch{lifted, P * (ell - 1), nullptr, 0, ell - 1}, false, s);
+    CtPtr o = new_ct(P, ell - 1, a->deg, a->scale, a->slots);
+    launch_rescale_finish(c_.dt, o->d, a->d, lifted, P, ell, c_.d_qlinv + (size_t)(ell - 1) * (c_.L + 1) * 2, s);
+    launch_ok("rescale");
+    c_.pool.free(last);
+    c_.pool.free(lifted);
+    return o;
+}
+
+CtPtr Evaluator::raw_rotate(const CtPtr& a, u64 g, const EvalKey& key) {
+    if (a->npoly != 2) throw Error(FHELIN_ERR_STATE, "rotate: ciphertext must have 2 components");
+    const size_t pn = (size_t)a->ell * c_.N;
+    CtPtr o = new_ct(2, a->ell, a->deg, a->scale, a->slots);
+    keyswitch(a->d + pn, a->ell, key, o->d, a->d, nullptr, c_.automorph_map(g));
+    return o;
+}
+
+CtPtr Evaluator::raw_mult_relin(const CtPtr& a, const CtPtr& b, const EvalKey& key) {
+    if (a->npoly != 2 || b->npoly != 2 || a->ell != b->ell) throw Error(FHELIN_ERR_STATE, "mult: operands must be 2-component, same level");
+    const int ell = a->ell;
+    const size_t pn = (size_t)ell * c_.N;
+    u64* d = c_.dalloc<u64>(3 * pn);
+    launch_tensor(c_.dt, d, a->d, b->d, ell, c_.stream);
+    CtPtr o = new_ct(2, ell, a->deg + b->deg, a->scale * b->scale, a->slots);
+    keyswitch(d + 2 * pn, ell, key, o->d, d, d + pn, nullptr);
+    c_.pool.free(d);
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------ leveled ops
+CtPtr Evaluator::rescale(const CtPtr& a) {
+    CtPtr o = raw_rescale(a);
+    o->scale = a->scale / (long double)c_.chain.q[a->ell - 1];
+    o->deg = a->deg > 1 ? a->deg - 1 : 1;
+    return o;
+}
+
+CtPtr Evaluator::level_reduce(const CtPtr& a, int new_ell) {
+    if (new_ell == a->ell) return a;
+    if (new_ell < 1 || new_ell > a->ell) throw Error(FHELIN_ERR_ARG, "level_reduce: bad target");
+    CtPtr o = new_ct(a->npoly, new_ell, a->deg, a->scale, a->slots);
+    const size_t N = c_.N;
+    hip_check(hipMemcpy2DAsync(o->d, (size_t)new_ell * N * 8, a->d, (size_t)a->ell * N * 8, (size_t)new_ell * N * 8, a->npoly,
+                               hipMemcpyDeviceToDevice, c_.stream), "level_reduce");
+    return o;
+}
+
+CtPtr Evaluator::mult_int(const CtPtr& a, u64 k, bool raise_deg, long double new_scale) {
+    ScalarSet sc;
+    for (int i = 0; i < a->ell; ++i) {
+        u64 q = c_.chain.q[i];
+        u64 v = k % q;
+        sc.v[2 * i] = v;
+        sc.v[2 * i + 1] = h_shoup(v, q);
+    }
+    CtPtr o = new_ct(a->npoly, a->ell, raise_deg ? a->deg + 1 : a->deg, new_scale, a->slots);
+    launch_ew_scalar(c_.dt, o->d, a->d, sc, a->npoly * a->ell, 0, a->ell, c_.stream);
+    launch_ok("mult_int");
+    return o;
+}
+
+CtPtr Evaluator::adjust(const CtPtr& a, int ell, int deg, long double scale) {
+    CtPtr cur = a;
+    if (cur->ell < ell) throw Error(FHELIN_ERR_STATE, "adjust: cannot raise a ciphertext to a lower level");
+    if (cur->ell == ell) {
+        if (cur->deg == deg) return cur;
+        if (cur->deg == 1 && deg == 2) {
+            u64 k = (u64)llroundl(scale / cur->scale);
+            return mult_int(cur, k, true, scale);
+        }
+        throw Error(FHELIN_ERR_STATE, "adjust: cannot lower the scale degree without dropping a limb");
+    }
+    if (deg == 1) {
+        if (cur->deg == 2) cur = rescale(cur);
+        if (cur->ell == ell) return cur;
+        const long double qdrop = (long double)c_.chain.q[ell];
+        u64 k = (u64)llroundl(scale * qdrop / cur->scale);
+        cur = mult_int(cur, k, true, cur->scale * (long double)k);
+        cur = level_reduce(cur, ell + 1);
+        cur = rescale(cur);
+        cur->scale = scale;
+        return cur;
+    }
+    if (cur->deg == 2) cur = rescale(cur);
+    u64 k = (u64)llroundl(scale / cur->scale);
+    cur = mult_int(cur, k, true, scale);
+    return level_reduce(cur, ell);
+}
+
+void Evaluator::match(const CtPtr& a, const CtPtr& b, CtPtr& ao, CtPtr& bo) {
+    if (a->ell == b->ell && a->deg == b->deg) {
+        ao = a;
+        bo = b;
+        return;
+    }
+    // the operand with fewer limbs fixes the level; at equal level the degree-2 operand fixes the degree
+    const bool a_rules = a->ell < b->ell || (a->ell == b->ell && a->deg >= b->deg);
+    if (a_rules) {
+        ao = a;
+        bo = adjust(b, a->ell, a->deg, a->scale);
+    } else {
+        bo = b;
+        ao = adjust(a, b->ell, b->deg, b->scale);
+    }
+}
+
+CtPtr Evaluator::add(const CtPtr& a, const CtPtr& b) {
+    if (a->npoly != b->npoly) throw Error(FHELIN_ERR_STATE, "add: component count mismatch");
+    CtPtr x, y;
+    match(a, b, x, y);
+    CtPtr o = new_ct(x->npoly, x->ell, x->deg, x->scale, x->slots);
+    launch_ew_add(c_.dt, o->d, x->d, y->d, x->npoly * x->ell, x->npoly * x->ell, 0, x->ell, c_.stream);
+    launch_ok("add");
+    return o;
+}
+
+CtPtr Evaluator::sub(const CtPtr& a, const CtPtr& b) {
+    if (a->npoly != b->npoly) throw Error(FHELIN_ERR_STATE, "sub: component count mismatch");
+    CtPtr x, y;
+    match(a, b, x, y);
+    CtPtr o = new_ct(x->npoly, x->ell, x->deg, x->scale, x->slots);
+    launch_ew_sub(c_.dt, o->d, x->d, y->d, x->npoly * x->ell, x->npoly * x->ell, 0, x->ell, c_.stream);
+    launch_ok("sub");
+    return o;
+}
+
+CtPtr Evaluator::negate(const CtPtr& a) {
+    CtPtr o = new_ct(a->npoly, a->ell, a->deg, a->scale, a->slots);
+    launch_ew_neg(c_.dt, o->d, a->d, a->npoly * a->ell, 0, a->ell, c_.stream);
+    launch_ok("negate");
+    return o;
+}
+
+CtPtr Evaluator::add_plain(const CtPtr& a, const PtPtr& p) {
+    auto enc = p->at(a->ell, a->scale);
+    CtPtr o = clone(a);
+    launch_ew_add(c_.dt, o->d, a->d, enc->d, a->ell, a->ell, 0, a->ell, c_.stream);
+    launch_ok("add_plain");
+    return o;
+}
+
+CtPtr Evaluator::mult_plain(const CtPtr& a, const PtPtr& p) {
+    CtPtr x = a->deg >= 2 ? rescale(a) : a;
+    auto enc = p->at(x->ell, c_.sf_real[x->level()]);
+    CtPtr o = new_ct(x->npoly, x->ell, x->deg + 1, x->scale * enc->scale, x->slots);
+    launch_ew_mul(c_.dt, o->d, x->d, enc->d, x->npoly * x->ell, x->ell, 0, x->ell, c_.stream);
+    launch_ok("mult_plain");
+    return o;
+}
+
+CtPtr Evaluator::mult_no_relin(const CtPtr& a, const CtPtr& b) {
+    if (a->npoly != 2 || b->npoly != 2) throw Error(FHELIN_ERR_STATE, "mult: operands must have 2 components");
+    CtPtr x = a->deg >= 2 ? rescale(a) : a;
+    CtPtr y = b->deg >= 2 ? rescale(b) : b;
+    CtPtr xa, ya;
+    match(x, y, xa, ya);
+    CtPtr o = new_ct(3, xa->ell, xa->deg + ya->deg, xa->scale * ya->scale, xa->slots);
+    launch_tensor(c_.dt, o->d, xa->d, ya->d, xa->ell, c_.stream);
+    launch_ok("tensor");
+    return o;
+}
+
+CtPtr Evaluator::relinearize(const CtPtr& a) {
+    if (a->npoly == 2) return a;
+    if (!relin_key) throw Error(FHELIN_ERR_KEY, "no relinearisation key (EvalMultKeyGen not called)");
+    const size_t pn = (size_t)a->ell * c_.N;
+    CtPtr o = new_ct(2, a->ell, a->deg, a->scale, a->slots);
+    keyswitch(a->d + 2 * pn, a->ell, *relin_key, o->d, a->d, a->d + pn, nullptr);
+    return o;
+}
+
+CtPtr Evaluator::mult(const CtPtr& a, const CtPtr& b) { return relinearize(mult_no_relin(a, b)); }
+
+CtPtr Evaluator::rotate(const CtPtr& a, int index) {
+    const int ns = a->slots > 0 ? a->slots : (1 << c_.prm.log_slots);
+    int r = index % ns;
+    if (r == 0) return clone(a);
+    const u64 g = c_.galois_element(index);
+    auto it = rot_keys.find(g);
+    if (it == rot_keys.end())
+        throw Error(FHELIN_ERR_KEY, "no rotation key for index " + std::to_string(index) + " (EvalRotateKeyGen list)");
+    return raw_rotate(a, g, *it->second);
+}
+
+}  // namespace fhelin

@@ -1,0 +1,102 @@
+// RNS-CKKS evaluator on top of the gfx950 kernels: ciphertext / plaintext / key objects and the leveled
+// operations the reference reaches through OpenFHE's CryptoContext (reference src/FHEController.cpp
+// :409-436 add/mult/rotate, FLEXIBLEAUTO level + scale bookkeeping implied by :18-24).
+#pragma once
+#include <map>
+#include <memory>
+#include <vector>
+#include "context.h"
+#include "kernels_elem.h"
+
+namespace fhelin {
+
+// Device-resident ciphertext: d[npoly][ell][N], NTT (evaluation) form.
+struct Ciphertext {
+    Context* ctx = nullptr;
+    u64* d = nullptr;
+    int npoly = 2;
+    int ell = 0;          // live Q limbs; level (OpenFHE GetLevel) = L+1-ell
+    int deg = 1;          // noiseScaleDeg: 1 after rescale / fresh, 2 after a multiplication
+    long double scale = 0;
+    int slots = 0;
+    ~Ciphertext();
+    int level() const { return ctx->L + 1 - ell; }
+    size_t words() const { return (size_t)npoly * ell * ctx->N; }
+};
+typedef std::shared_ptr<Ciphertext> CtPtr;
+
+// One device encoding of a plaintext vector at a given (limb count, scale).
+struct Encoding {
+    Context* ctx = nullptr;
+    u64* d = nullptr;  // [ell][N] NTT form
+    int ell = 0;
+    long double scale = 0;
+    ~Encoding();
+};
+
+// Plaintext handle: keeps the slot values and lazily (re-)encodes them at whatever (level, scale) an
+// operation needs — the effect OpenFHE gets by adjusting plaintext levels inside EvalMult/EvalAdd.
+struct Plaintext {
+    Context* ctx = nullptr;
+    std::vector<double> values;  // real slot values, size == slots
+    int slots = 0;
+    int level = 0;               // level requested at encode time (reference encode(vec, level, slots))
+    std::vector<std::shared_ptr<Encoding>> cache;
+    std::shared_ptr<Encoding> at(int ell, long double scale);
+};
+typedef std::shared_ptr<Plaintext> PtPtr;
+
+struct EvalKey {
+    Context* ctx = nullptr;
+    u64* d = nullptr;  // [dnum][2][L+1+k][N] NTT form; component 0 = b, 1 = a
+    int digits = 0;
+    ~EvalKey();
+    size_t words() const { return (size_t)digits * 2 * (ctx->L + 1 + ctx->K) * ctx->N; }
+};
+typedef std::shared_ptr<EvalKey> KeyPtr;
+
+class Evaluator {
+public:
+    explicit Evaluator(Context& c) : c_(c) {}
+    Context& ctx() { return c_; }
+
+    // ---- allocation / import / export
+    CtPtr new_ct(int npoly, int ell, int deg, long double scale, int slots);
+    CtPtr clone(const CtPtr& a);
+    KeyPtr new_key();
+
+    // ---- keys
+    std::map<u64, KeyPtr> rot_keys;  // by galois element
+    KeyPtr relin_key;
+    KeyPtr conj_key;
+
+    // ---- K6-K8 composite: out[2][ell][N] = KeySwitch(c) (+ add0/add1, gathered through map if given)
+    void keyswitch(const u64* c_ntt, int ell, const EvalKey& key, u64* out, const u64* add0, const u64* add1, const u32* map);
+
+    // ---- leveled ops (functional: inputs are never modified)
+    CtPtr add(const CtPtr& a, const CtPtr& b);
+    CtPtr sub(const CtPtr& a, const CtPtr& b);
+    CtPtr negate(const CtPtr& a);
+    CtPtr add_plain(const CtPtr& a, const PtPtr& p);
+    CtPtr mult_plain(const CtPtr& a, const PtPtr& p);
+    CtPtr mult(const CtPtr& a, const CtPtr& b);             // tensor + relinearise (auto-rescale inputs of deg 2)
+    CtPtr mult_no_relin(const CtPtr& a, const CtPtr& b);    // 3-component result
+    CtPtr relinearize(const CtPtr& a);
+    CtPtr mult_int(const CtPtr& a, u64 k, bool raise_deg, long double new_scale);  // by an integer constant
+    CtPtr rotate(const CtPtr& a, int index);
+    CtPtr rescale(const CtPtr& a);                           // drop one limb, divide the scale by it
+    CtPtr level_reduce(const CtPtr& a, int new_ell);         // drop limbs without scaling
+    // bring `a` to (ell, deg) with scale `scale` following the FLEXIBLEAUTO rules
+    CtPtr adjust(const CtPtr& a, int ell, int deg, long double scale);
+
+    // raw, no bookkeeping (parity tests): exactly the residue functions of the oracle
+    CtPtr raw_rescale(const CtPtr& a);
+    CtPtr raw_rotate(const CtPtr& a, u64 galois, const EvalKey& key);
+    CtPtr raw_mult_relin(const CtPtr& a, const CtPtr& b, const EvalKey& key);
+
+private:
+    Context& c_;
+    void match(const CtPtr& a, const CtPtr& b, CtPtr& ao, CtPtr& bo);
+};
+
+}  // namespace fhelin

@@ -1,0 +1,48 @@
+// Launchers of the element-wise, rescale and key-switch kernels (kernels_elem.hip, kernels_ks.hip).
+#pragma once
+#include "kernels.h"
+
+namespace fhelin {
+
+// per-limb Shoup scalars passed by value in the kernarg segment: v[2*i] = s mod q_i, v[2*i+1] = shoup
+struct ScalarSet {
+    u64 v[128];
+};
+
+// out[v] = a[v] (op) b[v % b_mod] for v < nvec; vector v uses limb limb_first + v % limb_count
+void launch_ew_mul(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s);
+void launch_ew_add(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s);
+void launch_ew_sub(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s);
+void launch_ew_muladd(const DeviceTables& t, u64* out, const u64* acc, const u64* a, const u64* b, int nvec, int b_mod, int limb_first,
+                      int limb_count, hipStream_t s);
+void launch_ew_neg(const DeviceTables& t, u64* out, const u64* a, int nvec, int limb_first, int limb_count, hipStream_t s);
+void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s);
+void launch_tensor(const DeviceTables& t, u64* d, const u64* a, const u64* b, int ell, hipStream_t s);
+void launch_automorph(const DeviceTables& t, u64* out, const u64* in, const u32* map, int nvec, hipStream_t s);
+void launch_rescale_lift(const DeviceTables& t, u64* lifted, const u64* last, int npoly, int ell, const u64* qlmod_row, hipStream_t s);
+void launch_rescale_finish(const DeviceTables& t, u64* out, const u64* c, const u64* lifted, int npoly, int ell, const u64* qlinv_row,
+                           hipStream_t s);
+void launch_reduce_i128(const DeviceTables& t, u64* out, const u64* coeffs, int limb_first, int nlimbs, hipStream_t s);
+
+// ---- hybrid key switching (K6-K8)
+struct KsShape {
+    int ell;     // live Q limbs
+    int k;       // special limbs
+    int alpha;   // limbs per digit
+    int beta;    // digits at this level
+    int L1;      // total Q limbs (evk limb stride is L1 + k)
+};
+// K6: cc [ell][N] coefficient form, c_ntt [ell][N] NTT form -> ext [beta][ell+k][N]
+//     (own-digit slots receive c_ntt, the others the fast-basis-extended values in coefficient form)
+void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const u64* cc, const u64* c_ntt, const u64* hatinv,
+                       const u64* hatmod, hipStream_t s);
+// K7: accQ [2][ell][N], accP [2][k][N] <- sum_j ext[j][t] * evk[j][comp][limb(t)]
+void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* evk, hipStream_t s);
+// K8a: accP coefficient form [2][k][N] -> conv [2][ell][N] (coefficient form)
+void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
+                         hipStream_t s);
+// K8b: out[c][t][j] = (accQ[c][t][m] - conv[c][t][m]) * P^{-1} + add_c[t][m],  m = map ? map[j] : j
+void launch_moddown_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* pinv,
+                           const u64* add0, const u64* add1, const u32* map, hipStream_t s);
+
+}  // namespace fhelin

@@ -1,0 +1,240 @@
+// K2/K3/K4/K5/K9 — element-wise residue kernels for gfx950: dyadic multiply / tensor, add / sub / negate /
+// per-limb scalar multiply, NTT-domain automorphism gather, rescale lift/finish, int128 -> RNS reduction.
+//
+// Reference side: the DCRTPoly operator*=, +=, -=, AutomorphismTransform and DropLastElementAndScale loops
+// that run inside OpenFHE under context->EvalMult / EvalAdd / EvalRotate (reference src/FHEController.cpp
+// :410,:414,:423-435).  SURVEY.md §8(a) rows K2-K5, K9.
+//
+// All of these are HBM-bound streaming kernels: limb-major [vec][N] u64 arrays, 16-byte accesses per lane,
+// grid = (N / 512, vectors); per-limb constants (q, Barrett ratio, Shoup scalars) are wave-uniform and come
+// in through scalar loads.  No MFMA (64-bit modular integers).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "kernels_elem.h"
+
+namespace fhelin {
+namespace {
+
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ Barrett load_barrett(const DeviceTables& t, int limb) {
+    Barrett b;
+    b.q = t.moduli[limb];
+    b.r0 = t.barrett[2 * limb];
+    b.r1 = t.barrett[2 * limb + 1];
+    return b;
+}
+
+// out[v] = a[v] (op) b[v % b_mod]
+template <int OP>  // 0 mul, 1 add, 2 sub
+__global__ __launch_bounds__(256) void ew_binary_kernel(DeviceTables t, u64* out, const u64* a, const u64* b, int b_mod,
+                                                        int limb_first, int limb_count) {
+    const int v = blockIdx.y;
+    const int limb = limb_first + v % limb_count;
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;  // index in u64x2 units
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const u64x2 x = reinterpret_cast<const u64x2*>(a)[(size_t)v * row + n2];
+    const u64x2 y = reinterpret_cast<const u64x2*>(b)[(size_t)(v % b_mod) * row + n2];
+    u64x2 r;
+    if (OP == 0) {
+        const Barrett br = load_barrett(t, limb);
+        r.x = mul_mod(x.x, y.x, br);
+        r.y = mul_mod(x.y, y.y, br);
+    } else if (OP == 1) {
+        const u64 q = t.moduli[limb];
+        r.x = add_mod(x.x, y.x, q);
+        r.y = add_mod(x.y, y.y, q);
+    } else {
+        const u64 q = t.moduli[limb];
+        r.x = sub_mod(x.x, y.x, q);
+        r.y = sub_mod(x.y, y.y, q);
+    }
+    reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
+}
+
+// out[v] = acc[v] + a[v] * b[v % b_mod]
+__global__ __launch_bounds__(256) void ew_muladd_kernel(DeviceTables t, u64* out, const u64* acc, const u64* a, const u64* b,
+                                                        int b_mod, int limb_first, int limb_count) {
+    const int v = blockIdx.y;
+    const int limb = limb_first + v % limb_count;
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const Barrett br = load_barrett(t, limb);
+    const u64x2 x = reinterpret_cast<const u64x2*>(a)[(size_t)v * row + n2];
+    const u64x2 y = reinterpret_cast<const u64x2*>(b)[(size_t)(v % b_mod) * row + n2];
+    const u64x2 c = reinterpret_cast<const u64x2*>(acc)[(size_t)v * row + n2];
+    u64x2 r;
+    r.x = add_mod(c.x, mul_mod(x.x, y.x, br), br.q);
+    r.y = add_mod(c.y, mul_mod(x.y, y.y, br), br.q);
+    reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
+}
+
+__global__ __launch_bounds__(256) void ew_neg_kernel(DeviceTables t, u64* out, const u64* a, int limb_first, int limb_count) {
+    const int v = blockIdx.y;
+    const u64 q = t.moduli[limb_first + v % limb_count];
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const u64x2 x = reinterpret_cast<const u64x2*>(a)[(size_t)v * row + n2];
+    u64x2 r;
+    r.x = neg_mod(x.x, q);
+    r.y = neg_mod(x.y, q);
+    reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
+}
+
+// out[v] = a[v] * s[limb]   (s given with Shoup companion: sc[2*i], sc[2*i+1] for i = v % limb_count)
+__global__ __launch_bounds__(256) void ew_scalar_kernel(DeviceTables t, u64* out, const u64* a, ScalarSet sc, int limb_first,
+                                                        int limb_count) {
+    const int v = blockIdx.y;
+    const int li = v % limb_count;
+    const u64 q = t.moduli[limb_first + li];
+    const u64 w = sc.v[2 * li], ws = sc.v[2 * li + 1];
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const u64x2 x = reinterpret_cast<const u64x2*>(a)[(size_t)v * row + n2];
+    u64x2 r;
+    r.x = mul_shoup(x.x, w, ws, q);
+    r.y = mul_shoup(x.y, w, ws, q);
+    reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
+}
+
+// tensor product of two 2-component ciphertexts a, b [2][ell][N] -> d [3][ell][N]
+__global__ __launch_bounds__(256) void tensor_kernel(DeviceTables t, u64* d, const u64* a, const u64* b, int ell) {
+    const int l = blockIdx.y;
+    const Barrett br = load_barrett(t, l);
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const size_t poly = (size_t)ell * row;
+    const u64x2* A = reinterpret_cast<const u64x2*>(a);
+    const u64x2* B = reinterpret_cast<const u64x2*>(b);
+    const u64x2 a0 = A[l * row + n2], a1 = A[poly + l * row + n2];
+    const u64x2 b0 = B[l * row + n2], b1 = B[poly + l * row + n2];
+    u64x2 d0, d1, d2;
+    d0.x = mul_mod(a0.x, b0.x, br);
+    d0.y = mul_mod(a0.y, b0.y, br);
+    d2.x = mul_mod(a1.x, b1.x, br);
+    d2.y = mul_mod(a1.y, b1.y, br);
+    d1.x = add_mod(mul_mod(a0.x, b1.x, br), mul_mod(a1.x, b0.x, br), br.q);
+    d1.y = add_mod(mul_mod(a0.y, b1.y, br), mul_mod(a1.y, b0.y, br), br.q);
+    u64x2* D = reinterpret_cast<u64x2*>(d);
+    D[l * row + n2] = d0;
+    D[poly + l * row + n2] = d1;
+    D[2 * poly + l * row + n2] = d2;
+}
+
+// K4: out[v][j] = in[v][map[j]]
+__global__ __launch_bounds__(256) void automorph_kernel(int log_n, u64* out, const u64* in, const u32* map) {
+    const int v = blockIdx.y;
+    const size_t n = (size_t)1 << log_n;
+    const size_t j = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const u32 m0 = map[j], m1 = map[j + 1];
+    u64x2 r;
+    r.x = in[v * n + m0];
+    r.y = in[v * n + m1];
+    reinterpret_cast<u64x2*>(out)[(v * n + j) >> 1] = r;
+}
+
+// K5 step 2: centred lift of the dropped limb (coefficient form, modulus q_l) into every remaining limb.
+// last [npoly][N] -> lifted [npoly][ell-1][N]
+__global__ __launch_bounds__(256) void rescale_lift_kernel(DeviceTables t, u64* lifted, const u64* last, int ell1 /* = ell-1 */,
+                                                           const u64* qlmod_row) {
+    const int v = blockIdx.y;  // p * ell1 + tq
+    const int p = v / ell1, tq = v % ell1;
+    const Barrett br = load_barrett(t, tq);
+    const u64 ql = t.moduli[ell1];
+    const u64 half = ql >> 1;
+    const u64 qlm = qlmod_row[tq];
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const u64x2 x = reinterpret_cast<const u64x2*>(last)[(size_t)p * row + n2];
+    u64x2 r;
+    r.x = barrett_reduce128(x.x, 0, br);
+    r.y = barrett_reduce128(x.y, 0, br);
+    if (x.x > half) r.x = sub_mod(r.x, qlm, br.q);
+    if (x.y > half) r.y = sub_mod(r.y, qlm, br.q);
+    reinterpret_cast<u64x2*>(lifted)[(size_t)v * row + n2] = r;
+}
+
+// K5 step 4: out[p][t] = (c[p][t] - lifted[p][t]) * q_l^{-1}   (c has ell limbs per poly, out ell-1)
+__global__ __launch_bounds__(256) void rescale_finish_kernel(DeviceTables t, u64* out, const u64* c, const u64* lifted, int ell1,
+                                                             const u64* qlinv_row) {
+    const int v = blockIdx.y;
+    const int p = v / ell1, tq = v % ell1;
+    const u64 q = t.moduli[tq];
+    const u64 w = qlinv_row[2 * tq], ws = qlinv_row[2 * tq + 1];
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const u64x2 x = reinterpret_cast<const u64x2*>(c)[((size_t)p * (ell1 + 1) + tq) * row + n2];
+    const u64x2 y = reinterpret_cast<const u64x2*>(lifted)[(size_t)v * row + n2];
+    u64x2 r;
+    r.x = mul_shoup(sub_mod(x.x, y.x, q), w, ws, q);
+    r.y = mul_shoup(sub_mod(x.y, y.y, q), w, ws, q);
+    reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
+}
+
+// encode helper: signed 128-bit integer coefficients (lo, hi two's complement) -> residues of nlimbs limbs
+__global__ __launch_bounds__(256) void reduce_i128_kernel(DeviceTables t, u64* out, const u64* coeffs, int limb_first) {
+    const int v = blockIdx.y;
+    const Barrett br = load_barrett(t, limb_first + v);
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t N = (size_t)1 << t.log_n;
+    u64 lo = coeffs[2 * n], hi = coeffs[2 * n + 1];
+    const bool neg = (hi >> 63) != 0;
+    if (neg) {  // magnitude = -(hi:lo)
+        lo = ~lo + 1;
+        hi = ~hi + (lo == 0);
+    }
+    // |x| < 2^126: reduce the high word first so that the 128-bit Barrett input is < q * 2^64
+    const u64 h = barrett_reduce128(hi, 0, br);
+    u64 r = barrett_reduce128(lo, h, br);
+    if (neg) r = neg_mod(r, br.q);
+    out[(size_t)v * N + n] = r;
+}
+
+inline dim3 grid2(int log_n, int nvec) { return dim3((1u << log_n) / 512, (unsigned)nvec); }
+
+}  // namespace
+
+void launch_ew_mul(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s) {
+    if (nvec <= 0) return;
+    hipLaunchKernelGGL((ew_binary_kernel<0>), grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, b, b_mod, limb_first, limb_count);
+}
+void launch_ew_add(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s) {
+    if (nvec <= 0) return;
+    hipLaunchKernelGGL((ew_binary_kernel<1>), grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, b, b_mod, limb_first, limb_count);
+}
+void launch_ew_sub(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s) {
+    if (nvec <= 0) return;
+    hipLaunchKernelGGL((ew_binary_kernel<2>), grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, b, b_mod, limb_first, limb_count);
+}
+void launch_ew_muladd(const DeviceTables& t, u64* out, const u64* acc, const u64* a, const u64* b, int nvec, int b_mod, int limb_first,
+                      int limb_count, hipStream_t s) {
+    if (nvec <= 0) return;
+    hipLaunchKernelGGL(ew_muladd_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, acc, a, b, b_mod, limb_first, limb_count);
+}
+void launch_ew_neg(const DeviceTables& t, u64* out, const u64* a, int nvec, int limb_first, int limb_count, hipStream_t s) {
+    if (nvec <= 0) return;
+    hipLaunchKernelGGL(ew_neg_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, limb_first, limb_count);
+}
+void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s) {
+    if (nvec <= 0) return;
+    hipLaunchKernelGGL(ew_scalar_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, sc, limb_first, limb_count);
+}
+void launch_tensor(const DeviceTables& t, u64* d, const u64* a, const u64* b, int ell, hipStream_t s) {
+    hipLaunchKernelGGL(tensor_kernel, grid2(t.log_n, ell), dim3(256), 0, s, t, d, a, b, ell);
+}
+void launch_automorph(const DeviceTables& t, u64* out, const u64* in, const u32* map, int nvec, hipStream_t s) {
+    if (nvec <= 0) return;
+    hipLaunchKernelGGL(automorph_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t.log_n, out, in, map);
+}
+void launch_rescale_lift(const DeviceTables& t, u64* lifted, const u64* last, int npoly, int ell, const u64* qlmod_row, hipStream_t s) {
+    hipLaunchKernelGGL(rescale_lift_kernel, grid2(t.log_n, npoly * (ell - 1)), dim3(256), 0, s, t, lifted, last, ell - 1, qlmod_row);
+}
+void launch_rescale_finish(const DeviceTables& t, u64* out, const u64* c, const u64* lifted, int npoly, int ell, const u64* qlinv_row,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(rescale_finish_kernel, grid2(t.log_n, npoly * (ell - 1)), dim3(256), 0, s, t, out, c, lifted, ell - 1, qlinv_row);
+}
+void launch_reduce_i128(const DeviceTables& t, u64* out, const u64* coeffs, int limb_first, int nlimbs, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_i128_kernel, dim3((1u << t.log_n) / 256, (unsigned)nlimbs), dim3(256), 0, s, t, out, coeffs, limb_first);
+}
+
+}  // namespace fhelin

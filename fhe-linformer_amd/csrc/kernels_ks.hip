@@ -1,0 +1,195 @@
+// K6/K7/K8 — hybrid (dnum-digit) key switching on gfx950: ModUp fast basis extension, evaluation-key inner
+// product, ModDown.  Together with K1 these implement what OpenFHE's KeySwitchHYBRID does underneath
+// context->EvalRotate / context->EvalMult(ct,ct) (reference src/FHEController.cpp:431,:435,:833,:843; HYBRID
+// with SetNumLargeDigits(4), :11).  SURVEY.md §8(a) rows K6-K8.
+//
+// Exact functions computed (shared with oracle/fhe_oracle.c orc_keyswitch):
+//   ModUp   d_j[t] = sum_{i in D_j} [c_i * (Q_j/q_i)^{-1}]_{q_i} * [(Q_j/q_i)]_t   mod t      (t outside digit j)
+//   inner   acc_c[t] = sum_j d_j[t] * evk_j,c[t]                                    mod t
+//   ModDown out_c[t] = (acc_c[t] - sum_p [acc_c[p] * (P/p)^{-1}]_p * [(P/p)]_t) * P^{-1}  mod q_t
+// The sums are accumulated in 128 bits and reduced once (Barrett), so the results are canonical residues and
+// independent of evaluation order.  Limb-major arrays, one thread per coefficient column, per-limb constants
+// through scalar loads; no MFMA (u64 modular integers).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "kernels_elem.h"
+
+namespace fhelin {
+namespace {
+
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ Barrett load_barrett(const DeviceTables& t, int limb) {
+    Barrett b;
+    b.q = t.moduli[limb];
+    b.r0 = t.barrett[2 * limb];
+    b.r1 = t.barrett[2 * limb + 1];
+    return b;
+}
+
+// grid (N/256, beta)
+template <int MAXA>
+__global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape sh, u64* ext, const u64* cc, const u64* c_ntt,
+                                                         const u64* hatinv, const u64* hatmod) {
+    const int j = blockIdx.y;
+    const size_t N = (size_t)1 << t.log_n;
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int lo = j * sh.alpha;
+    const int cnt = min(sh.alpha, sh.ell - lo);
+    const int nt = sh.ell + sh.k;
+    u64 y[MAXA];
+#pragma unroll
+    for (int i = 0; i < MAXA; ++i) {
+        if (i < cnt) {
+            const int li = lo + i;
+            y[i] = mul_shoup(cc[(size_t)li * N + n], hatinv[2 * li], hatinv[2 * li + 1], t.moduli[li]);
+        } else {
+            y[i] = 0;
+        }
+    }
+    u64* dst = ext + (size_t)j * nt * N + n;
+    for (int tt = 0; tt < nt; ++tt) {
+        if (tt >= lo && tt < lo + cnt) {
+            dst[(size_t)tt * N] = c_ntt[(size_t)tt * N + n];
+            continue;
+        }
+        const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
+        const Barrett br = load_barrett(t, limb);
+        Acc128 acc = {0, 0};
+#pragma unroll
+        for (int i = 0; i < MAXA; ++i)
+            if (i < cnt) acc_mac(acc, y[i], hatmod[(size_t)(lo + i) * nt + tt]);
+        dst[(size_t)tt * N] = barrett_reduce128(acc.lo, acc.hi, br);
+    }
+}
+
+// grid (N/512, ell + k)
+__global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape sh, u64* accQ, u64* accP, const u64* ext,
+                                                       const u64* evk) {
+    const int tt = blockIdx.y;
+    const int nt = sh.ell + sh.k;
+    const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
+    const Barrett br = load_barrett(t, limb);
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t kstride = (size_t)(sh.L1 + sh.k) * row;  // one evk component, in u64x2 units
+    const u64x2* E = reinterpret_cast<const u64x2*>(ext);
+    const u64x2* K = reinterpret_cast<const u64x2*>(evk);
+    Acc128 b0 = {0, 0}, b1 = {0, 0}, a0 = {0, 0}, a1 = {0, 0};
+    for (int j = 0; j < sh.beta; ++j) {
+        const u64x2 d = E[((size_t)j * nt + tt) * row + n2];
+        const u64x2 kb = K[(size_t)(2 * j) * kstride + (size_t)limb * row + n2];
+        const u64x2 ka = K[(size_t)(2 * j + 1) * kstride + (size_t)limb * row + n2];
+        acc_mac(b0, d.x, kb.x);
+        acc_mac(b1, d.y, kb.y);
+        acc_mac(a0, d.x, ka.x);
+        acc_mac(a1, d.y, ka.y);
+    }
+    u64x2 rb, ra;
+    rb.x = barrett_reduce128(b0.lo, b0.hi, br);
+    rb.y = barrett_reduce128(b1.lo, b1.hi, br);
+    ra.x = barrett_reduce128(a0.lo, a0.hi, br);
+    ra.y = barrett_reduce128(a1.lo, a1.hi, br);
+    if (tt < sh.ell) {
+        u64x2* O = reinterpret_cast<u64x2*>(accQ);
+        O[(size_t)tt * row + n2] = rb;
+        O[(size_t)(sh.ell + tt) * row + n2] = ra;
+    } else {
+        u64x2* O = reinterpret_cast<u64x2*>(accP);
+        const int pj = tt - sh.ell;
+        O[(size_t)pj * row + n2] = rb;
+        O[(size_t)(sh.k + pj) * row + n2] = ra;
+    }
+}
+
+// grid (N/256, 2)
+template <int MAXK>
+__global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsShape sh, u64* conv, const u64* accP, const u64* phatinv,
+                                                           const u64* phatmod) {
+    const int c = blockIdx.y;
+    const size_t N = (size_t)1 << t.log_n;
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u64 z[MAXK];
+#pragma unroll
+    for (int p = 0; p < MAXK; ++p) {
+        if (p < sh.k) {
+            z[p] = mul_shoup(accP[((size_t)c * sh.k + p) * N + n], phatinv[2 * p], phatinv[2 * p + 1], t.moduli[sh.L1 + p]);
+        } else {
+            z[p] = 0;
+        }
+    }
+    u64* dst = conv + (size_t)c * sh.ell * N + n;
+    for (int tt = 0; tt < sh.ell; ++tt) {
+        const Barrett br = load_barrett(t, tt);
+        Acc128 acc = {0, 0};
+#pragma unroll
+        for (int p = 0; p < MAXK; ++p)
+            if (p < sh.k) acc_mac(acc, z[p], phatmod[(size_t)p * sh.L1 + tt]);
+        dst[(size_t)tt * N] = barrett_reduce128(acc.lo, acc.hi, br);
+    }
+}
+
+// grid (N/512, 2*ell)
+__global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsShape sh, u64* out, const u64* accQ, const u64* conv,
+                                                             const u64* pinv, const u64* add0, const u64* add1, const u32* map) {
+    const int v = blockIdx.y;
+    const int c = v / sh.ell, tt = v % sh.ell;
+    const u64 q = t.moduli[tt];
+    const u64 w = pinv[2 * tt], ws = pinv[2 * tt + 1];
+    const size_t N = (size_t)1 << t.log_n;
+    const size_t j = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const u64* add = c == 0 ? add0 : add1;
+    u64x2 r;
+    if (map) {
+        const u32 m0 = map[j], m1 = map[j + 1];
+        r.x = mul_shoup(sub_mod(accQ[(size_t)v * N + m0], conv[(size_t)v * N + m0], q), w, ws, q);
+        r.y = mul_shoup(sub_mod(accQ[(size_t)v * N + m1], conv[(size_t)v * N + m1], q), w, ws, q);
+        if (add) {
+            r.x = add_mod(r.x, add[(size_t)tt * N + m0], q);
+            r.y = add_mod(r.y, add[(size_t)tt * N + m1], q);
+        }
+    } else {
+        const u64x2 a = reinterpret_cast<const u64x2*>(accQ)[((size_t)v * N + j) >> 1];
+        const u64x2 b = reinterpret_cast<const u64x2*>(conv)[((size_t)v * N + j) >> 1];
+        r.x = mul_shoup(sub_mod(a.x, b.x, q), w, ws, q);
+        r.y = mul_shoup(sub_mod(a.y, b.y, q), w, ws, q);
+        if (add) {
+            const u64x2 d = reinterpret_cast<const u64x2*>(add)[((size_t)tt * N + j) >> 1];
+            r.x = add_mod(r.x, d.x, q);
+            r.y = add_mod(r.y, d.y, q);
+        }
+    }
+    reinterpret_cast<u64x2*>(out)[((size_t)v * N + j) >> 1] = r;
+}
+
+}  // namespace
+
+void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const u64* cc, const u64* c_ntt, const u64* hatinv,
+                       const u64* hatmod, hipStream_t s) {
+    dim3 g((1u << t.log_n) / 256, (unsigned)sh.beta);
+    if (sh.alpha <= 4)
+        hipLaunchKernelGGL((modup_conv_kernel<4>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod);
+    else if (sh.alpha <= 8)
+        hipLaunchKernelGGL((modup_conv_kernel<8>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod);
+    else
+        hipLaunchKernelGGL((modup_conv_kernel<16>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod);
+}
+void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* evk, hipStream_t s) {
+    dim3 g((1u << t.log_n) / 512, (unsigned)(sh.ell + sh.k));
+    hipLaunchKernelGGL(ks_inner_kernel, g, dim3(256), 0, s, t, sh, accQ, accP, ext, evk);
+}
+void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
+                         hipStream_t s) {
+    dim3 g((1u << t.log_n) / 256, 2);
+    if (sh.k <= 8)
+        hipLaunchKernelGGL((moddown_conv_kernel<8>), g, dim3(256), 0, s, t, sh, conv, accP, phatinv, phatmod);
+    else
+        hipLaunchKernelGGL((moddown_conv_kernel<16>), g, dim3(256), 0, s, t, sh, conv, accP, phatinv, phatmod);
+}
+void launch_moddown_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* pinv,
+                           const u64* add0, const u64* add1, const u32* map, hipStream_t s) {
+    dim3 g((1u << t.log_n) / 512, (unsigned)(2 * sh.ell));
+    hipLaunchKernelGGL(moddown_finish_kernel, g, dim3(256), 0, s, t, sh, out, accQ, conv, pinv, add0, add1, map);
+}
+
+}  // namespace fhelin

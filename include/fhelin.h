@@ -84,6 +84,50 @@ int fhelin_ntt(fhelin_ctx* c, uint64_t* d_data, int32_t nvec, int32_t limb_first
 /* instruction-rate probe (bench.py --micro): variant 0..7, see csrc/kernels_micro.hip */
 int fhelin_microbench(fhelin_ctx* c, int32_t variant, int32_t iters, int32_t blocks, float* ms);
 
+
+/* ---- keys (client side; sampling on the host, polynomial arithmetic on the GPU) ---------------- */
+int fhelin_keygen(fhelin_ctx* c);                       /* context->KeyGen()                  FHEController.cpp:47  */
+int fhelin_gen_relin_key(fhelin_ctx* c);                /* context->EvalMultKeyGen(sk)        :49                   */
+int fhelin_gen_rotation_keys(fhelin_ctx* c, const int32_t* indices, int32_t n);  /* EvalRotateKeyGen  :248       */
+int fhelin_gen_conj_key(fhelin_ctx* c);
+/* raw key material, [L+1+k][N] (secret, NTT form) and [dnum][2][L+1+k][N] (switching keys): parity tests
+ * hand the same arrays to the oracle.  kind: 0 = relinearisation key, 1 = rotation key for `index`. */
+int fhelin_secret_export(fhelin_ctx* c, uint64_t* out, size_t cap_words);
+int fhelin_secret_import(fhelin_ctx* c, const uint64_t* in, size_t words);
+int fhelin_key_export(fhelin_ctx* c, int32_t kind, int32_t index, uint64_t* out, size_t cap_words);
+int fhelin_key_import(fhelin_ctx* c, int32_t kind, int32_t index, const uint64_t* in, size_t words);
+
+/* ---- plaintexts: context->MakeCKKSPackedPlaintext(vec, 1, level, nullptr, slots)  :353,:368 ---- */
+int fhelin_encode(fhelin_ctx* c, const double* vals, int32_t n, int32_t level, int32_t slots, fhelin_pt** out);
+void fhelin_pt_free(fhelin_pt* p);
+
+/* ---- ciphertexts ----------------------------------------------------------------------------- */
+int fhelin_encrypt(fhelin_ctx* c, const fhelin_pt* p, fhelin_ct** out);                 /* context->Encrypt   :380,:384 */
+int fhelin_decrypt(fhelin_ctx* c, const fhelin_ct* ct, double* out, int32_t slots);     /* context->Decrypt + GetRealPackedValue :387-404 */
+int fhelin_ct_import(fhelin_ctx* c, const uint64_t* limbs, int32_t npoly, int32_t ell, int32_t deg, double scale,
+                     int32_t slots, fhelin_ct** out);
+int fhelin_ct_export(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* out, size_t cap_words);
+int fhelin_ct_info(const fhelin_ct* ct, int32_t* npoly, int32_t* ell, int32_t* level, int32_t* deg, double* scale,
+                   int32_t* slots);                                                     /* ct->GetLevel() / GetSlots()  */
+int fhelin_ct_clone(fhelin_ctx* c, const fhelin_ct* ct, fhelin_ct** out);                /* ct->Clone()  (main.cpp:223) */
+void fhelin_ct_free(fhelin_ct* ct);
+
+/* ---- leveled evaluation (FLEXIBLEAUTO bookkeeping included) ------------------------------------ */
+int fhelin_add(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b, fhelin_ct** out);          /* EvalAdd(ct,ct)   :410 */
+int fhelin_sub(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b, fhelin_ct** out);
+int fhelin_negate(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);
+int fhelin_add_plain(fhelin_ctx* c, const fhelin_ct* a, const fhelin_pt* p, fhelin_ct** out);    /* EvalAdd(ct,pt)   :414 */
+int fhelin_mult_plain(fhelin_ctx* c, const fhelin_ct* a, const fhelin_pt* p, fhelin_ct** out);   /* EvalMult(ct,pt)  :427 */
+int fhelin_mult(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b, fhelin_ct** out);         /* EvalMult(ct,ct)  :431 */
+int fhelin_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** out);            /* EvalRotate       :435,:833,:843 */
+int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);                          /* ModReduce (implicit in :427/:431) */
+int fhelin_level_reduce(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhelin_ct** out);
+
+/* ---- the same residue functions without scale/level bookkeeping (bit-exact parity vs oracle/) -- */
+int fhelin_raw_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);                      /* K5            */
+int fhelin_raw_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** out);        /* K4 + K6-K8    */
+int fhelin_raw_mult_relin(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b, fhelin_ct** out);/* K2 + K6-K8   */
+
 #ifdef __cplusplus
 }
 #endif
