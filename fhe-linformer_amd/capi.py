@@ -97,6 +97,24 @@ def load_library():
         "fhelin_raw_rescale": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_raw_rotate": (i32, [vp, vp, i32, C.POINTER(vp)]),
         "fhelin_raw_mult_relin": (i32, [vp, vp, vp, C.POINTER(vp)]),
+        "fhelin_fc_mult_const": (i32, [vp, vp, C.c_double, C.POINTER(vp)]),
+        "fhelin_fc_mask": (i32, [vp, vp, i32, i32, i32, C.c_double, C.POINTER(vp)]),
+        "fhelin_fc_rotsum": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "fhelin_fc_repeat": (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+        "fhelin_fc_add_many": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp)]),
+        "fhelin_fc_matmul_pt": (i32, [vp, C.POINTER(vp), i32, vp, vp, i32, i32, C.POINTER(vp)]),
+        "fhelin_fc_matmul_ct": (i32, [vp, C.POINTER(vp), i32, vp, i32, i32, C.POINTER(vp)]),
+        "fhelin_fc_matmulRElarge": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp), i32, vp, C.c_double, C.POINTER(vp)]),
+        "fhelin_fc_matmulCRlarge": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp), vp, C.POINTER(vp)]),
+        "fhelin_fc_matmulScores": (i32, [vp, C.POINTER(vp), i32, vp, C.POINTER(vp)]),
+        "fhelin_fc_wrapUpRepeated": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp)]),
+        "fhelin_fc_wrapUpExpanded": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp)]),
+        "fhelin_fc_unwrapExpanded": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "fhelin_fc_unwrapScoresExpanded": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "fhelin_fc_unwrap_512_in_4_128": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "fhelin_fc_unwrapRepeatedLarge": (i32, [vp, C.POINTER(vp), i32, i32, C.POINTER(vp)]),
+        "fhelin_fc_generate_containers": (i32, [vp, C.POINTER(vp), i32, vp, C.POINTER(vp), C.POINTER(i32)]),
+        "fhelin_fc_wrap_containers": (i32, [vp, C.POINTER(vp), i32, i32, C.POINTER(vp)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -313,6 +331,129 @@ class Engine:
 
     def raw_mult_relin(self, a, b):
         return self._un(self.lib.fhelin_raw_mult_relin, a, b.h)
+
+    # ---- FHEController composites (names follow the reference methods)
+    @staticmethod
+    def _harr(objs):
+        return (C.c_void_p * len(objs))(*[o.h for o in objs])
+
+    def _outs(self, n):
+        return (C.c_void_p * n)()
+
+    def _cts(self, arr, n):
+        return [Ct(self, C.c_void_p(arr[i])) for i in range(n)]
+
+    def mult_const(self, a, d):
+        return self._un(self.lib.fhelin_fc_mult_const, a, float(d))
+
+    def mask_block(self, a, frm, to, v=1.0):
+        return self._un(self.lib.fhelin_fc_mask, a, 0, frm, to, float(v))
+
+    def mask_heads(self, a, v=1.0):
+        return self._un(self.lib.fhelin_fc_mask, a, 1, 0, 0, float(v))
+
+    def mask_heads_128(self, a, v=1.0):
+        return self._un(self.lib.fhelin_fc_mask, a, 2, 0, 0, float(v))
+
+    def mask_mod_n(self, a, n, padding=0):
+        return self._un(self.lib.fhelin_fc_mask, a, 3, n, padding, 1.0)
+
+    def mask_first_n(self, a, n, v=1.0):
+        return self._un(self.lib.fhelin_fc_mask, a, 4, n, 0, float(v))
+
+    def rotsum(self, a, slots, padding):
+        return self._un(self.lib.fhelin_fc_rotsum, a, slots, padding)
+
+    def repeat(self, a, slots, padding=1):
+        return self._un(self.lib.fhelin_fc_repeat, a, slots, padding)
+
+    def add_many(self, v):
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_fc_add_many(self.h, self._harr(v), len(v), C.byref(h)))
+        return Ct(self, h)
+
+    def matmul_pt(self, rows, w, bias, slots, padding):
+        outs = self._outs(len(rows))
+        self._ck(self.lib.fhelin_fc_matmul_pt(self.h, self._harr(rows), len(rows), w.h, bias.h if bias else None, slots, padding, outs))
+        return self._cts(outs, len(rows))
+
+    def matmulRE(self, rows, w, bias=None, row_size=128, padding=128):
+        if isinstance(w, Ct):
+            return self.matmul_ct(rows, w, row_size, padding)
+        return self.matmul_pt(rows, w, bias, row_size, padding)
+
+    def matmulCR(self, rows, w, bias=None):
+        if isinstance(w, Ct):
+            return self.matmul_ct(rows, w, 64, 1)
+        return self.matmul_pt(rows, w, bias, 128, 1)
+
+    def matmulCR_128(self, rows, w):
+        return self.matmul_ct(rows, w, 128, 1)
+
+    def matmul_ct(self, rows, w, slots, padding):
+        outs = self._outs(len(rows))
+        self._ck(self.lib.fhelin_fc_matmul_ct(self.h, self._harr(rows), len(rows), w.h, slots, padding, outs))
+        return self._cts(outs, len(rows))
+
+    def matmulRElarge(self, rows, weights, bias, mask_val=1.0):
+        outs = self._outs(len(rows))
+        self._ck(self.lib.fhelin_fc_matmulRElarge(self.h, self._harr(rows), len(rows), self._harr(weights), len(weights),
+                                                  bias.h if bias else None, float(mask_val), outs))
+        return self._cts(outs, len(rows))
+
+    def matmulCRlarge(self, rows, weights, bias):
+        flat = [c for r in rows for c in r]
+        outs = self._outs(len(rows))
+        self._ck(self.lib.fhelin_fc_matmulCRlarge(self.h, self._harr(flat), len(rows), self._harr(weights), bias.h if bias else None, outs))
+        return self._cts(outs, len(rows))
+
+    def matmulScores(self, queries, key):
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_fc_matmulScores(self.h, self._harr(queries), len(queries), key.h, C.byref(h)))
+        return Ct(self, h)
+
+    def wrapUpRepeated(self, v):
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_fc_wrapUpRepeated(self.h, self._harr(v), len(v), C.byref(h)))
+        return Ct(self, h)
+
+    def wrapUpExpanded(self, v):
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_fc_wrapUpExpanded(self.h, self._harr(v), len(v), C.byref(h)))
+        return Ct(self, h)
+
+    def unwrapExpanded(self, c, n):
+        outs = self._outs(n)
+        self._ck(self.lib.fhelin_fc_unwrapExpanded(self.h, c.h, n, outs))
+        return self._cts(outs, n)
+
+    def unwrapScoresExpanded(self, c, n):
+        outs = self._outs(n)
+        self._ck(self.lib.fhelin_fc_unwrapScoresExpanded(self.h, c.h, n, outs))
+        return self._cts(outs, n)
+
+    def unwrap_512_in_4_128(self, c, index):
+        outs = self._outs(4)
+        self._ck(self.lib.fhelin_fc_unwrap_512_in_4_128(self.h, c.h, index, outs))
+        return self._cts(outs, 4)
+
+    def unwrapRepeatedLarge(self, containers, input_number):
+        outs = self._outs(4 * input_number)
+        self._ck(self.lib.fhelin_fc_unwrapRepeatedLarge(self.h, self._harr(containers), len(containers), input_number, outs))
+        flat = self._cts(outs, 4 * input_number)
+        return [flat[4 * i: 4 * i + 4] for i in range(input_number)]
+
+    def generate_containers(self, inputs, bias=None):
+        cap = (len(inputs) + 31) // 32
+        outs = self._outs(cap)
+        n = C.c_int32()
+        self._ck(self.lib.fhelin_fc_generate_containers(self.h, self._harr(inputs), len(inputs), bias.h if bias else None, outs, C.byref(n)))
+        return self._cts(outs, n.value)
+
+    def wrap_containers(self, v, inputs_number):
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_fc_wrap_containers(self.h, self._harr(v), len(v), inputs_number, C.byref(h)))
+        return Ct(self, h)
 
 
 class Pt:

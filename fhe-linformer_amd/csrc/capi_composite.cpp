@@ -1,0 +1,166 @@
+// extern "C" boundary, part 3: one entry point per FHEController composite method.
+#include "../../include/fhelin.h"
+#include "capi_internal.h"
+
+using namespace fhelin;
+
+#define NEED(x) if (!(x)) return capi_fail(FHELIN_ERR_ARG, "null argument")
+
+static fhelin_ct* wrap(const CtPtr& p) {
+    auto* h = new fhelin_ct;
+    h->p = p;
+    return h;
+}
+static CtVec vec_of(const fhelin_ct* const* v, int n) {
+    CtVec out;
+    for (int i = 0; i < n; ++i) {
+        if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext handle in array");
+        out.push_back(v[i]->p);
+    }
+    return out;
+}
+static void emit(const CtVec& v, fhelin_ct** outs) {
+    for (size_t i = 0; i < v.size(); ++i) outs[i] = wrap(v[i]);
+}
+static PtPtr opt(const fhelin_pt* p) { return p ? p->p : PtPtr(); }
+
+extern "C" {
+
+int fhelin_fc_mult_const(fhelin_ctx* c, const fhelin_ct* a, double d, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->comp.mult_const(a->p, d));
+    FHELIN_CATCH
+}
+int fhelin_fc_mask(fhelin_ctx* c, const fhelin_ct* a, int32_t kind, int32_t x, int32_t y, double v, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    switch (kind) {
+        case 0: *out = wrap(c->comp.mask_block(a->p, x, y, v)); break;
+        case 1: *out = wrap(c->comp.mask_heads(a->p, v)); break;
+        case 2: *out = wrap(c->comp.mask_heads_128(a->p, v)); break;
+        case 3: *out = wrap(c->comp.mask_mod_n(a->p, x, y)); break;
+        case 4: *out = wrap(c->comp.mask_first_n(a->p, x, v)); break;
+        default: throw Error(FHELIN_ERR_ARG, "unknown mask kind");
+    }
+    FHELIN_CATCH
+}
+int fhelin_fc_rotsum(fhelin_ctx* c, const fhelin_ct* a, int32_t slots, int32_t padding, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->comp.rotsum(a->p, slots, padding));
+    FHELIN_CATCH
+}
+int fhelin_fc_repeat(fhelin_ctx* c, const fhelin_ct* a, int32_t slots, int32_t padding, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->comp.repeat(a->p, slots, padding));
+    FHELIN_CATCH
+}
+int fhelin_fc_add_many(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
+    NEED(c && v && out);
+    FHELIN_TRY
+    *out = wrap(c->comp.add_many(vec_of(v, n)));
+    FHELIN_CATCH
+}
+int fhelin_fc_matmul_pt(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* w, const fhelin_pt* bias,
+                        int32_t slots, int32_t padding, fhelin_ct** outs) {
+    NEED(c && rows && w && outs);
+    FHELIN_TRY
+    emit(c->comp.matmul_pt(vec_of(rows, n), w->p, opt(bias), slots, padding), outs);
+    FHELIN_CATCH
+}
+int fhelin_fc_matmul_ct(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_ct* w, int32_t slots,
+                        int32_t padding, fhelin_ct** outs) {
+    NEED(c && rows && w && outs);
+    FHELIN_TRY
+    emit(c->comp.matmul_ct(vec_of(rows, n), w->p, slots, padding), outs);
+    FHELIN_CATCH
+}
+int fhelin_fc_matmulRElarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* const* weights, int32_t nw,
+                            const fhelin_pt* bias, double mask_val, fhelin_ct** outs) {
+    NEED(c && rows && weights && outs);
+    FHELIN_TRY
+    std::vector<PtPtr> w;
+    for (int i = 0; i < nw; ++i) {
+        if (!weights[i]) throw Error(FHELIN_ERR_ARG, "null weight");
+        w.push_back(weights[i]->p);
+    }
+    emit(c->comp.matmulRElarge(vec_of(rows, n), w, opt(bias), mask_val), outs);
+    FHELIN_CATCH
+}
+int fhelin_fc_matmulCRlarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* const* weights,
+                            const fhelin_pt* bias, fhelin_ct** outs) {
+    NEED(c && rows && weights && outs);
+    FHELIN_TRY
+    std::vector<PtPtr> w;
+    for (int i = 0; i < 4; ++i) {
+        if (!weights[i]) throw Error(FHELIN_ERR_ARG, "null weight");
+        w.push_back(weights[i]->p);
+    }
+    std::vector<CtVec> r;
+    for (int i = 0; i < n; ++i) r.push_back(vec_of(rows + 4 * i, 4));
+    emit(c->comp.matmulCRlarge(r, w, opt(bias)), outs);
+    FHELIN_CATCH
+}
+int fhelin_fc_matmulScores(fhelin_ctx* c, const fhelin_ct* const* queries, int32_t n, const fhelin_ct* key, fhelin_ct** out) {
+    NEED(c && queries && key && out);
+    FHELIN_TRY
+    *out = wrap(c->comp.matmulScores(vec_of(queries, n), key->p));
+    FHELIN_CATCH
+}
+int fhelin_fc_wrapUpRepeated(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
+    NEED(c && v && out);
+    FHELIN_TRY
+    *out = wrap(c->comp.wrapUpRepeated(vec_of(v, n)));
+    FHELIN_CATCH
+}
+int fhelin_fc_wrapUpExpanded(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
+    NEED(c && v && out);
+    FHELIN_TRY
+    *out = wrap(c->comp.wrapUpExpanded(vec_of(v, n)));
+    FHELIN_CATCH
+}
+int fhelin_fc_unwrapExpanded(fhelin_ctx* c, const fhelin_ct* a, int32_t n, fhelin_ct** outs) {
+    NEED(c && a && outs);
+    FHELIN_TRY
+    emit(c->comp.unwrapExpanded(a->p, n), outs);
+    FHELIN_CATCH
+}
+int fhelin_fc_unwrapScoresExpanded(fhelin_ctx* c, const fhelin_ct* a, int32_t n, fhelin_ct** outs) {
+    NEED(c && a && outs);
+    FHELIN_TRY
+    emit(c->comp.unwrapScoresExpanded(a->p, n), outs);
+    FHELIN_CATCH
+}
+int fhelin_fc_unwrap_512_in_4_128(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** outs4) {
+    NEED(c && a && outs4);
+    FHELIN_TRY
+    emit(c->comp.unwrap_512_in_4_128(a->p, index), outs4);
+    FHELIN_CATCH
+}
+int fhelin_fc_unwrapRepeatedLarge(fhelin_ctx* c, const fhelin_ct* const* containers, int32_t nc, int32_t input_number,
+                                  fhelin_ct** outs) {
+    NEED(c && containers && outs);
+    FHELIN_TRY
+    auto r = c->comp.unwrapRepeatedLarge(vec_of(containers, nc), input_number);
+    for (size_t i = 0; i < r.size(); ++i) emit(r[i], outs + 4 * i);
+    FHELIN_CATCH
+}
+int fhelin_fc_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs, int32_t n, const fhelin_pt* bias,
+                                  fhelin_ct** outs, int32_t* n_out) {
+    NEED(c && inputs && outs);
+    FHELIN_TRY
+    auto r = c->comp.generate_containers(vec_of(inputs, n), opt(bias));
+    emit(r, outs);
+    if (n_out) *n_out = (int)r.size();
+    FHELIN_CATCH
+}
+int fhelin_fc_wrap_containers(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t inputs_number, fhelin_ct** out) {
+    NEED(c && v && out);
+    FHELIN_TRY
+    *out = wrap(c->comp.wrap_containers(vec_of(v, n), inputs_number));
+    FHELIN_CATCH
+}
+
+}  // extern "C"

@@ -5,13 +5,15 @@
 #include "context.h"
 #include "evaluator.h"
 #include "client.h"
+#include "composite.h"
 
 // opaque handle behind include/fhelin.h's `fhelin_ctx`
 struct fhelin_ctx {
     fhelin::Context ctx;
     fhelin::Evaluator ev;
     fhelin::Client cl;
-    explicit fhelin_ctx(const fhelin::Params& p) : ctx(p), ev(ctx), cl(ev, p.seed) {}
+    fhelin::Composite comp;
+    explicit fhelin_ctx(const fhelin::Params& p) : ctx(p), ev(ctx), cl(ev, p.seed), comp(ev, cl) {}
 };
 struct fhelin_ct {
     fhelin::CtPtr p;

@@ -1,0 +1,291 @@
+#include "composite.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace fhelin {
+
+PtPtr Composite::encode_vec(const std::vector<double>& v, int level) {
+    return cl_.encode(v.data(), (int)v.size(), level, num_slots());
+}
+
+PtPtr Composite::encode_const(double val, int level) {
+    std::vector<double> v(num_slots(), val);
+    return encode_vec(v, level);
+}
+
+CtPtr Composite::mult_const(const CtPtr& c, double d) {
+    char key[64];
+    uint64_t bits;
+    std::memcpy(&bits, &d, 8);
+    snprintf(key, sizeof key, "const:%016llx", (unsigned long long)bits);
+    auto it = mask_cache_.find(key);
+    PtPtr p = it != mask_cache_.end() ? it->second : (mask_cache_[key] = encode_const(d, c->level()));
+    return ev_.mult_plain(c, p);
+}
+
+PtPtr Composite::mask_plain(const std::string& key, const std::vector<double>& v) {
+    auto it = mask_cache_.find(key);
+    if (it != mask_cache_.end()) return it->second;
+    PtPtr p = encode_vec(v, 0);
+    mask_cache_[key] = p;
+    return p;
+}
+
+static std::string mkey(const char* kind, long a, long b, double v) {
+    char key[96];
+    uint64_t bits;
+    std::memcpy(&bits, &v, 8);
+    snprintf(key, sizeof key, "%s:%ld:%ld:%016llx", kind, a, b, (unsigned long long)bits);
+    return key;
+}
+
+CtPtr Composite::mask_block(const CtPtr& c, int from, int to, double val) {
+    const std::string key = mkey("block", from, to, val);
+    if (!mask_cache_.count(key)) {
+        std::vector<double> m(num_slots(), 0.0);
+        for (int i = std::max(from, 0); i < to && i < num_slots(); ++i) m[i] = val;
+        mask_plain(key, m);
+    }
+    return ev_.mult_plain(c, mask_cache_[key]);
+}
+
+CtPtr Composite::mask_heads(const CtPtr& c, double val) {
+    const std::string key = mkey("mod", 64, 0, val);
+    if (!mask_cache_.count(key)) {
+        std::vector<double> m(num_slots(), 0.0);
+        for (int i = 0; i < num_slots(); i += 64) m[i] = val;
+        mask_plain(key, m);
+    }
+    return ev_.mult_plain(c, mask_cache_[key]);
+}
+
+CtPtr Composite::mask_heads_128(const CtPtr& c, double val) {
+    const std::string key = mkey("mod", 128, 0, val);
+    if (!mask_cache_.count(key)) {
+        std::vector<double> m(num_slots(), 0.0);
+        for (int i = 0; i < num_slots(); i += 128) m[i] = val;
+        mask_plain(key, m);
+    }
+    return ev_.mult_plain(c, mask_cache_[key]);
+}
+
+CtPtr Composite::mask_mod_n(const CtPtr& c, int n, int padding) {
+    if (n <= 0) throw Error(FHELIN_ERR_ARG, "mask_mod_n: n must be positive");
+    const std::string key = mkey("mod", n, padding, 1.0);
+    if (!mask_cache_.count(key)) {
+        std::vector<double> m(num_slots(), 0.0);
+        for (int i = 0; i < num_slots(); ++i)
+            if (i % n == padding) m[i] = 1.0;
+        mask_plain(key, m);
+    }
+    return ev_.mult_plain(c, mask_cache_[key]);
+}
+
+CtPtr Composite::mask_first_n(const CtPtr& c, int n, double val) {
+    const std::string key = mkey("first", n, 0, val);
+    if (!mask_cache_.count(key)) {
+        std::vector<double> m(num_slots(), 0.0);
+        for (int i = 0; i < n && i < num_slots(); ++i) m[i] = val;
+        mask_plain(key, m);
+    }
+    return ev_.mult_plain(c, mask_cache_[key]);
+}
+
+// the reference loops `for (int i = 0; i < log2(slots); i++)` with a floating-point bound (:832,:842,:852,:862)
+static int log_steps(int slots) {
+    int n = 0;
+    while ((double)n < std::log2((double)slots)) ++n;
+    return n;
+}
+
+CtPtr Composite::rotsum(const CtPtr& in, int slots, int padding) {
+    CtPtr r = ev_.clone(in);
+    const int n = log_steps(slots);
+    for (int i = 0; i < n; ++i) r = ev_.add(r, ev_.rotate(r, padding * (1 << i)));
+    return r;
+}
+
+CtPtr Composite::rotsum_padded(const CtPtr& in, int slots) { return rotsum(in, slots, slots); }
+
+CtPtr Composite::repeat(const CtPtr& in, int slots, int padding) {
+    CtPtr r = ev_.clone(in);
+    const int n = log_steps(slots);
+    for (int i = 0; i < n; ++i) r = ev_.add(r, ev_.rotate(r, padding * -(1 << i)));
+    return r;
+}
+
+CtPtr Composite::add_many(const CtVec& v) {
+    if (v.empty()) throw Error(FHELIN_ERR_ARG, "add_many: empty vector");
+    CtVec cur = v;
+    while (cur.size() > 1) {  // binary tree like EvalAddMany
+        CtVec nxt;
+        for (size_t i = 0; i + 1 < cur.size(); i += 2) nxt.push_back(ev_.add(cur[i], cur[i + 1]));
+        if (cur.size() & 1) nxt.push_back(cur.back());
+        cur.swap(nxt);
+    }
+    return cur[0];
+}
+
+CtVec Composite::matmul_pt(const CtVec& rows, const PtPtr& w, const PtPtr& bias, int slots, int padding) {
+    CtVec out;
+    for (const CtPtr& row : rows) {
+        CtPtr m = ev_.mult_plain(row, w);
+        m = rotsum(m, slots, padding);
+        if (bias) m = ev_.add_plain(m, bias);
+        out.push_back(m);
+    }
+    return out;
+}
+
+CtVec Composite::matmul_ct(const CtVec& rows, const CtPtr& w, int slots, int padding) {
+    CtVec out;
+    for (const CtPtr& row : rows) out.push_back(rotsum(ev_.mult(row, w), slots, padding));
+    return out;
+}
+
+CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias, double mask_val) {
+    CtVec densed;
+    for (const CtPtr& in : inputs) {
+        CtPtr res;
+        for (int j = (int)weights.size() - 1; j >= 0; --j) {
+            CtPtr out = ev_.mult_plain(in, weights[j]);
+            out = rotsum(out, 128, 128);
+            out = mask_first_n(out, 128, mask_val);
+            if (j == (int)weights.size() - 1) {
+                res = out;
+            } else {
+                res = ev_.rotate(res, -64);
+                res = ev_.rotate(res, -64);
+                res = ev_.add(res, out);
+            }
+        }
+        if (bias) res = ev_.add_plain(res, bias);
+        densed.push_back(res);
+    }
+    return densed;
+}
+
+CtVec Composite::matmulCRlarge(const std::vector<CtVec>& rows, const std::vector<PtPtr>& weights, const PtPtr& bias) {
+    CtVec out;
+    for (const CtVec& r : rows) {
+        if (r.size() < 4 || weights.size() < 4) throw Error(FHELIN_ERR_ARG, "matmulCRlarge: need 4 blocks");
+        CtVec parts;
+        for (int j = 0; j < 4; ++j) parts.push_back(ev_.mult_plain(r[j], weights[j]));
+        CtPtr res = rotsum(add_many(parts), 128, 1);
+        if (bias) res = ev_.add_plain(res, bias);
+        out.push_back(res);
+    }
+    return out;
+}
+
+CtPtr Composite::matmulScores(const CtVec& queries, const CtPtr& key) {
+    if (queries.empty()) throw Error(FHELIN_ERR_ARG, "matmulScores: no queries");
+    CtVec scores = matmul_ct(queries, key, 128, 1);
+    const double r = 1 / 8.0;  // "later corrected with e^(x/r)"  (:1031)
+    if (scores.size() == 1) return mask_heads_128(scores[0], 1 / 8.0 * r);
+    CtPtr wrapped = mask_heads_128(scores.back(), 1 / 8.0 * r);
+    wrapped = ev_.rotate(wrapped, -1);
+    for (int i = (int)scores.size() - 2; i >= 0; --i) {
+        wrapped = ev_.add(wrapped, mask_heads_128(scores[i], 1 / 8.0 * r));
+        if (i > 0) wrapped = ev_.rotate(wrapped, -1);
+    }
+    return wrapped;
+}
+
+CtPtr Composite::wrapUpRepeated(const CtVec& v) {
+    CtVec masked;
+    for (size_t i = 0; i < v.size(); ++i) masked.push_back(mask_block(v[i], 128 * (int)i, 128 * ((int)i + 1), 1));
+    return add_many(masked);
+}
+
+CtPtr Composite::wrapUpExpanded(const CtVec& v) {
+    if (v.empty()) throw Error(FHELIN_ERR_ARG, "wrapUpExpanded: empty vector");
+    CtPtr masked = mask_mod_n(v.back(), 128, 0);
+    if (v.size() > 1) masked = ev_.rotate(masked, -1);
+    for (int i = (int)v.size() - 2; i >= 0; --i) {
+        masked = ev_.add(masked, mask_mod_n(v[i], 128, 0));
+        if (i > 0) masked = ev_.rotate(masked, -1);
+    }
+    return masked;
+}
+
+CtVec Composite::unwrapExpanded(CtPtr c, int n) {
+    CtVec result;
+    for (int i = 0; i < n; ++i) {
+        CtPtr out = mask_mod_n(c, 128, 0);
+        out = repeat(out, 128, 1);
+        if (i < n - 1) c = ev_.rotate(c, 1);
+        result.push_back(out);
+    }
+    return result;
+}
+
+CtVec Composite::unwrapScoresExpanded(CtPtr c, int n) {
+    CtVec result;
+    for (int i = 0; i < n; ++i) {
+        CtPtr a = repeat(mask_mod_n(c, 128, 0), 64, 1);
+        CtPtr b = repeat(mask_mod_n(c, 128, 64), 64, 1);
+        if (i < n - 1) c = ev_.rotate(c, 1);
+        result.push_back(ev_.add(a, b));
+    }
+    return result;
+}
+
+CtVec Composite::unwrap_512_in_4_128(const CtPtr& c, int index) {
+    CtVec result;
+    const int shift = index * 512;
+    for (int k = 0; k < 4; ++k) {
+        CtPtr s = mask_block(c, shift + 128 * k, shift + 128 * (k + 1), 1);
+        result.push_back(repeat(s, 128, -128));
+    }
+    return result;
+}
+
+std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int input_number) {
+    std::vector<CtVec> out;
+    std::vector<int> quantities;
+    for (int i = 0; i < input_number / 32.0; ++i) {
+        int q = 32;
+        if ((i + 1) * 32 > input_number) q = input_number - i * 32;
+        quantities.push_back(q);
+    }
+    for (size_t i = 0; i < containers.size() && i < quantities.size(); ++i)
+        for (int j = 0; j < quantities[i]; ++j) out.push_back(unwrap_512_in_4_128(containers[i], j));
+    return out;
+}
+
+CtPtr Composite::wrap_containers(const CtVec& c, int n) {
+    if (c.empty() || n > (int)c.size()) throw Error(FHELIN_ERR_ARG, "wrap_containers: bad input count");
+    CtPtr result = c[0];
+    for (int i = 1; i < n; ++i) {
+        result = ev_.rotate(result, -512);
+        result = ev_.add(result, c[i]);
+    }
+    return result;
+}
+
+CtVec Composite::generate_containers(const CtVec& inputs, const PtPtr& bias) {
+    CtVec containers;
+    const int total = (int)inputs.size();
+    for (int i = 0; i < total / 32.0; ++i) {
+        int quantity = 32;
+        if ((i + 1) * 32 > total) quantity = total - i * 32;
+        // slicing(inputs, 32 i, 32 (i+1))  (:1338-1357): returns the whole vector when it has <= 32 entries
+        int X = i * 32, Y = (i + 1) * 32;
+        CtVec sliced;
+        if (Y - X >= total) {
+            sliced = inputs;
+        } else {
+            if (Y > total) Y = total;
+            sliced.assign(inputs.begin() + X, inputs.begin() + Y);
+        }
+        std::reverse(sliced.begin(), sliced.end());
+        CtPtr part = wrap_containers(sliced, quantity);
+        if (bias) part = ev_.add_plain(part, bias);
+        containers.push_back(part);
+    }
+    return containers;
+}
+
+}  // namespace fhelin

@@ -1,0 +1,63 @@
+// Composite circuit operations of the reference's FHEController, re-expressed on the GPU evaluator:
+// rotate-and-sum reductions, the rotation-based 128x128 matmuls, slot masks, wrap/unwrap layout shuffles.
+// Each method cites the reference function it mirrors (all in reference src/FHEController.cpp).
+// These are the CALLERS of the hot path; they fix the kernel mix.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+#include "client.h"
+#include "evaluator.h"
+
+namespace fhelin {
+
+typedef std::vector<CtPtr> CtVec;
+
+class Composite {
+public:
+    Composite(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {}
+    int num_slots() const { return 1 << ev_.ctx().prm.log_slots; }
+
+    // leaf helpers
+    PtPtr encode_vec(const std::vector<double>& v, int level);
+    PtPtr encode_const(double val, int level);                          // encode(double,...)        :358-371
+    CtPtr mult_const(const CtPtr& c, double d);                         // mult(ct,double)           :421-424
+
+    // masks (plaintexts cached per pattern; the Plaintext re-encodes per level lazily)      :1207-1286
+    CtPtr mask_block(const CtPtr& c, int from, int to, double v);
+    CtPtr mask_heads(const CtPtr& c, double v);
+    CtPtr mask_heads_128(const CtPtr& c, double v);
+    CtPtr mask_mod_n(const CtPtr& c, int n, int padding);
+    CtPtr mask_first_n(const CtPtr& c, int n, double v);
+
+    // log-tree reductions                                                                     :829-867
+    CtPtr rotsum(const CtPtr& in, int slots, int padding);
+    CtPtr rotsum_padded(const CtPtr& in, int slots);
+    CtPtr repeat(const CtPtr& in, int slots, int padding);              // repeat(in,slots) == padding 1
+    CtPtr add_many(const CtVec& v);                                     // EvalAddMany               :417-419
+
+    // matmuls                                                                                 :869-1058
+    CtVec matmul_pt(const CtVec& rows, const PtPtr& w, const PtPtr& bias, int slots, int padding);   // RE / CR with plaintext weight
+    CtVec matmul_ct(const CtVec& rows, const CtPtr& w, int slots, int padding);                      // RE / CR with ciphertext weight
+    CtVec matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias, double mask_val);
+    CtVec matmulCRlarge(const std::vector<CtVec>& rows, const std::vector<PtPtr>& weights, const PtPtr& bias);
+    CtPtr matmulScores(const CtVec& queries, const CtPtr& key);
+
+    // layout shuffles                                                                         :1060-1205
+    CtPtr wrapUpRepeated(const CtVec& v);
+    CtPtr wrapUpExpanded(const CtVec& v);
+    CtVec unwrapExpanded(CtPtr c, int inputs_num);
+    CtVec unwrapScoresExpanded(CtPtr c, int inputs_num);
+    CtVec unwrap_512_in_4_128(const CtPtr& c, int index);
+    std::vector<CtVec> unwrapRepeatedLarge(const CtVec& containers, int input_number);
+    CtVec generate_containers(const CtVec& inputs, const PtPtr& bias);
+    CtPtr wrap_containers(const CtVec& c, int inputs_number);
+
+private:
+    Evaluator& ev_;
+    Client& cl_;
+    std::map<std::string, PtPtr> mask_cache_;
+    PtPtr mask_plain(const std::string& key, const std::vector<double>& v);
+};
+
+}  // namespace fhelin

@@ -128,6 +128,41 @@ int fhelin_raw_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);     
 int fhelin_raw_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** out);        /* K4 + K6-K8    */
 int fhelin_raw_mult_relin(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b, fhelin_ct** out);/* K2 + K6-K8   */
 
+/* ---- FHEController composite circuit ops (callers of the hot path) --------
+ * One entry point per reference method; `vector<Ctxt>` travels as (array of handles, count); outputs are
+ * written to caller-provided handle arrays.  A NULL bias means `bias == nullptr` in the reference. */
+int fhelin_fc_mult_const(fhelin_ctx* c, const fhelin_ct* a, double d, fhelin_ct** out);                 /* mult(ct,double) :421 */
+/* kind 0 mask_block(from=a,to=b,v) :1207 | 1 mask_heads(v) :1221 | 2 mask_heads_128(v) :1235 |
+ *      3 mask_mod_n(n=a,padding=b) :1249,:1262 | 4 mask_first_n(n=a,v) :1275 */
+int fhelin_fc_mask(fhelin_ctx* c, const fhelin_ct* a, int32_t kind, int32_t x, int32_t y, double v, fhelin_ct** out);
+int fhelin_fc_rotsum(fhelin_ctx* c, const fhelin_ct* a, int32_t slots, int32_t padding, fhelin_ct** out);  /* rotsum :829, rotsum_padded :839 */
+int fhelin_fc_repeat(fhelin_ctx* c, const fhelin_ct* a, int32_t slots, int32_t padding, fhelin_ct** out);  /* repeat :849,:859 */
+int fhelin_fc_add_many(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out);            /* add(vector) :417 */
+/* matmulRE :869,:885 (slots=row_size, padding) and matmulCR :982 (slots=128, padding=1), plaintext weight */
+int fhelin_fc_matmul_pt(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* w, const fhelin_pt* bias,
+                        int32_t slots, int32_t padding, fhelin_ct** outs);
+/* matmulRE(ct weight) :901, matmulCR(ct) :946 (64,1), matmulCR_128 :960,:974 (128,1) */
+int fhelin_fc_matmul_ct(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_ct* w, int32_t slots,
+                        int32_t padding, fhelin_ct** outs);
+int fhelin_fc_matmulRElarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* const* weights,
+                            int32_t nw, const fhelin_pt* bias, double mask_val, fhelin_ct** outs);      /* :915 */
+/* rows: n x 4 handles, row-major */
+int fhelin_fc_matmulCRlarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* const* weights,
+                            const fhelin_pt* bias, fhelin_ct** outs);                                   /* :998 */
+int fhelin_fc_matmulScores(fhelin_ctx* c, const fhelin_ct* const* queries, int32_t n, const fhelin_ct* key, fhelin_ct** out); /* :1028,:1050 */
+int fhelin_fc_wrapUpRepeated(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out);       /* :1060 */
+int fhelin_fc_wrapUpExpanded(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out);       /* :1070 */
+int fhelin_fc_unwrapExpanded(fhelin_ctx* c, const fhelin_ct* a, int32_t inputs_num, fhelin_ct** outs);    /* :1086 */
+int fhelin_fc_unwrapScoresExpanded(fhelin_ctx* c, const fhelin_ct* a, int32_t inputs_num, fhelin_ct** outs); /* :1125 */
+int fhelin_fc_unwrap_512_in_4_128(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** outs4);   /* :1142 */
+/* outs: input_number x 4 handles, row-major */
+int fhelin_fc_unwrapRepeatedLarge(fhelin_ctx* c, const fhelin_ct* const* containers, int32_t nc, int32_t input_number,
+                                  fhelin_ct** outs);                                                    /* :1102 */
+/* outs must hold ceil(n/32) handles; *n_out receives the count */
+int fhelin_fc_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs, int32_t n, const fhelin_pt* bias,
+                                  fhelin_ct** outs, int32_t* n_out);                                    /* :1164 */
+int fhelin_fc_wrap_containers(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t inputs_number, fhelin_ct** out); /* :1193 */
+
 #ifdef __cplusplus
 }
 #endif

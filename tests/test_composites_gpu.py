@@ -1,0 +1,164 @@
+"""FHEController composite ops on the GPU vs the slot-level restatement
+oracle/slotsim.py: decrypted results within 1e-5 (CKKS noise after <= 3 multiplicative levels and <= 40
+key switches at Delta=2^52 is ~1e-9; 1e-5 leaves margin for sums over 128 slots), plus the linear-algebra
+meaning of the two matmul layouts and a bit-exact residue check of rotsum against oracle rotate+add."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+ROTS = sorted(set([2 ** i for i in range(14)] + [-(2 ** i) for i in range(14)]))
+
+
+@pytest.fixture(scope="module")
+def eng(fa):
+    # reference slot count (16384 = 128 x 128) on the BASELINE ring, shallow chain so that the test is quick
+    e = fa.Engine("bench", seed=99, n_q=8, n_p=2, dnum=4)
+    e.keygen()
+    e.gen_relin_key()
+    e.gen_rotation_keys(ROTS)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def sim():
+    from oracle import slotsim
+    return slotsim
+
+
+def _v(seed, n=16384, lo=-1, hi=1):
+    return np.random.default_rng(seed).uniform(lo, hi, n)
+
+
+def _close(eng, ct, want, tol=TOL):
+    got = eng.decrypt(ct)
+    err = np.max(np.abs(got - want))
+    assert err < tol, err
+
+
+def test_rotsum_repeat_masks(eng, sim):
+    x = _v(1)
+    c = eng.encrypt(x)
+    _close(eng, eng.rotsum(c, 128, 128), sim.rotsum(x, 128, 128))
+    _close(eng, eng.rotsum(c, 128, 1), sim.rotsum(x, 128, 1))
+    _close(eng, eng.rotsum(c, 32, 128), sim.rotsum(x, 32, 128))
+    _close(eng, eng.repeat(c, 128), sim.repeat(x, 128))
+    _close(eng, eng.repeat(c, 128, -128), sim.repeat(x, 128, -128))
+    _close(eng, eng.mask_block(c, 256, 384, 0.5), sim.mask_block(x, 256, 384, 0.5))
+    _close(eng, eng.mask_heads(c, 2.0), sim.mask_mod_n(x, 64, 0, 2.0))
+    _close(eng, eng.mask_heads_128(c, 1 / 64), sim.mask_mod_n(x, 128, 0, 1 / 64))
+    _close(eng, eng.mask_mod_n(c, 128, 64), sim.mask_mod_n(x, 128, 64))
+    _close(eng, eng.mask_first_n(c, 128, 3.0), sim.mask_first_n(x, 128, 3.0))
+    _close(eng, eng.mult_const(c, -0.25), -0.25 * x)
+
+
+def test_matmulRE_is_x_times_W(eng, sim):
+    rng = np.random.default_rng(2)
+    W = rng.uniform(-1, 1, (128, 128)) / 8
+    b = rng.uniform(-1, 1, 128)
+    xs = [rng.uniform(-1, 1, 128) for _ in range(2)]
+    rows = [eng.encrypt(np.repeat(x, 128)) for x in xs]          # expanded: slot j*128+i = x[j]
+    w_pt, b_pt = eng.encode(W.reshape(-1)), eng.encode(np.tile(b, 128))
+    outs = eng.matmulRE(rows, w_pt, b_pt)
+    for x, o in zip(xs, outs):
+        y = x @ W + b
+        _close(eng, o, np.tile(y, 128))                          # repeated: slot j*128+i = y[i]
+    sim_out = sim.matmul([np.repeat(x, 128) for x in xs], W.reshape(-1), np.tile(b, 128), 128, 128)
+    for o, s in zip(outs, sim_out):
+        _close(eng, o, s)
+
+
+def test_matmulCR_is_W_times_y(eng, sim):
+    rng = np.random.default_rng(3)
+    W = rng.uniform(-1, 1, (128, 128)) / 8
+    b = rng.uniform(-1, 1, 128)
+    y = rng.uniform(-1, 1, 128)
+    row = eng.encrypt(np.tile(y, 128))                            # repeated
+    out = eng.matmulCR([row], eng.encode(W.reshape(-1)), eng.encode(np.repeat(b, 128)))[0]
+    got = eng.decrypt(out)
+    assert np.max(np.abs(got[::128] - (W @ y + b))) < TOL        # (Wy)[r] valid at slot r*128
+    # ciphertext-weight variants: matmulCR(ct) uses rotsum(64,1), matmulCR_128 rotsum(128,1)
+    cw = eng.encrypt(W.reshape(-1))
+    _close(eng, eng.matmulCR([row], cw)[0], sim.rotsum(np.tile(y, 128) * W.reshape(-1), 64, 1))
+    _close(eng, eng.matmulCR_128([row], cw)[0], sim.rotsum(np.tile(y, 128) * W.reshape(-1), 128, 1))
+    _close(eng, eng.matmulRE([row], cw, None, 128, 128)[0], sim.rotsum(np.tile(y, 128) * W.reshape(-1), 128, 128))
+
+
+def test_matmul_large_variants(eng, sim):
+    rng = np.random.default_rng(4)
+    ws = [rng.uniform(-1, 1, 16384) / 8 for _ in range(4)]
+    bias = rng.uniform(-1, 1, 16384)
+    xs = [_v(40 + i) for i in range(2)]
+    rows = [eng.encrypt(x) for x in xs]
+    wp = [eng.encode(w) for w in ws]
+    outs = eng.matmulRElarge(rows, wp, eng.encode(bias), 0.5)
+    for o, s in zip(outs, sim.matmulRElarge(xs, ws, bias, 0.5)):
+        _close(eng, o, s)
+    blocks = [[_v(50 + 4 * i + j) for j in range(4)] for i in range(2)]
+    cts = [[eng.encrypt(b) for b in r] for r in blocks]
+    outs = eng.matmulCRlarge(cts, wp, eng.encode(bias))
+    for o, s in zip(outs, sim.matmulCRlarge(blocks, ws, bias)):
+        _close(eng, o, s)
+
+
+def test_matmulScores(eng, sim):
+    key = _v(60)
+    qs = [_v(61 + i) for i in range(3)]
+    ck = eng.encrypt(key)
+    cq = [eng.encrypt(q) for q in qs]
+    _close(eng, eng.matmulScores(cq, ck), sim.matmulScores(qs, key))
+    _close(eng, eng.matmulScores(cq[:1], ck), sim.matmulScores(qs[:1], key))
+
+
+def test_wrap_unwrap(eng, sim):
+    vs = [_v(70 + i) for i in range(3)]
+    cs = [eng.encrypt(v) for v in vs]
+    _close(eng, eng.wrapUpRepeated(cs), sim.wrapUpRepeated(vs))
+    w = eng.wrapUpExpanded(cs)
+    ws = sim.wrapUpExpanded(vs)
+    _close(eng, w, ws)
+    for o, s in zip(eng.unwrapExpanded(w, 3), sim.unwrapExpanded(ws, 3)):
+        _close(eng, o, s)
+    for o, s in zip(eng.unwrapScoresExpanded(w, 2), sim.unwrapScoresExpanded(ws, 2)):
+        _close(eng, o, s)
+    for o, s in zip(eng.unwrap_512_in_4_128(cs[0], 1), sim.unwrap_512_in_4_128(vs[0], 1)):
+        _close(eng, o, s)
+    _close(eng, eng.add_many(cs), sum(vs))
+
+
+def test_containers(eng, sim):
+    # 34 inputs -> two containers (32 + 2), the ragged case of generate_containers / unwrapRepeatedLarge
+    n = 34
+    vs = [mask for mask in (sim.mask_block(_v(80 + i), 0, 512) for i in range(n))]
+    cs = [eng.encrypt(v, level=4) for v in vs]
+    bias = _v(200)
+    conts = eng.generate_containers(cs, eng.encode(bias))
+    sims = sim.generate_containers(vs, bias)
+    assert len(conts) == len(sims) == 2
+    for o, s in zip(conts, sims):
+        _close(eng, o, s)
+    un = eng.unwrapRepeatedLarge(conts, n)
+    us = sim.unwrapRepeatedLarge(sims, n)
+    assert len(un) == len(us) == n
+    for i in (0, 31, 33):
+        for o, s in zip(un[i], us[i]):
+            _close(eng, o, s)
+    _close(eng, eng.wrap_containers(cs[:3], 3), sim.wrap_containers(vs[:3], 3))
+
+
+def test_rotsum_bit_exact_vs_oracle(eng, orc):
+    """rotsum = (rotate, add) x log2(slots): the composite's residues equal the oracle's composition
+    bit for bit when both use the engine's exported key material."""
+    ell = 5
+    x = np.stack([orc.uniform_residues(7 + 1000 * p, eng.q[:ell], eng.N) for p in range(2)])
+    c = eng.ct_import(x)
+    got = eng.rotsum(c, 8, 128).export()
+    want = x
+    for i in range(3):
+        r = 128 * 2 ** i
+        evk = eng.key_export(1, r)
+        rotated = orc.rotate(want, evk, orc.galois(eng.log_n, r), eng.alpha, eng.q, eng.p, eng.psi_q, eng.psi_p)
+        want = np.stack([orc.add(want[p], rotated[p], eng.q[:ell]) for p in range(2)])
+    assert np.array_equal(got, want)
