@@ -115,6 +115,13 @@ def load_library():
         "fhelin_fc_unwrapRepeatedLarge": (i32, [vp, C.POINTER(vp), i32, i32, C.POINTER(vp)]),
         "fhelin_fc_generate_containers": (i32, [vp, C.POINTER(vp), i32, vp, C.POINTER(vp), C.POINTER(i32)]),
         "fhelin_fc_wrap_containers": (i32, [vp, C.POINTER(vp), i32, i32, C.POINTER(vp)]),
+        "fhelin_mult_real": (i32, [vp, vp, C.c_double, C.POINTER(vp)]),
+        "fhelin_add_real": (i32, [vp, vp, C.c_double, C.POINTER(vp)]),
+        "fhelin_mult_many": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp)]),
+        "fhelin_eval_poly": (i32, [vp, vp, C.POINTER(C.c_double), i32, C.POINTER(vp)]),
+        "fhelin_eval_chebyshev": (i32, [vp, vp, C.POINTER(C.c_double), i32, C.c_double, C.c_double, C.POINTER(vp)]),
+        "fhelin_bootstrap_setup": (i32, [vp, i32, i32, i32]),
+        "fhelin_bootstrap": (i32, [vp, vp, C.POINTER(vp)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -342,6 +349,28 @@ class Engine:
 
     def _cts(self, arr, n):
         return [Ct(self, C.c_void_p(arr[i])) for i in range(n)]
+
+    def mult_real(self, a, k):
+        return self._un(self.lib.fhelin_mult_real, a, float(k))
+
+    def add_real(self, a, k):
+        return self._un(self.lib.fhelin_add_real, a, float(k))
+
+    def mult_many(self, v):
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_mult_many(self.h, self._harr(v), len(v), C.byref(h)))
+        return Ct(self, h)
+
+    def eval_poly(self, x, coeffs):
+        cf = np.ascontiguousarray(coeffs, dtype=np.float64)
+        return self._un(self.lib.fhelin_eval_poly, x, cf.ctypes.data_as(C.POINTER(C.c_double)), cf.size)
+
+    def eval_chebyshev(self, x, coeffs, a=-1.0, b=1.0):
+        cf = np.ascontiguousarray(coeffs, dtype=np.float64)
+        return self._un(self.lib.fhelin_eval_chebyshev, x, cf.ctypes.data_as(C.POINTER(C.c_double)), cf.size, float(a), float(b))
+
+    def bootstrap(self, a):
+        return self._un(self.lib.fhelin_bootstrap, a)
 
     def mult_const(self, a, d):
         return self._un(self.lib.fhelin_fc_mult_const, a, float(d))

@@ -163,4 +163,43 @@ int fhelin_fc_wrap_containers(fhelin_ctx* c, const fhelin_ct* const* v, int32_t 
     FHELIN_CATCH
 }
 
+int fhelin_mult_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.mult_real(a->p, k));
+    FHELIN_CATCH
+}
+int fhelin_add_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.add_real(a->p, k));
+    FHELIN_CATCH
+}
+int fhelin_mult_many(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
+    NEED(c && v && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.mult_many(vec_of(v, n)));
+    FHELIN_CATCH
+}
+int fhelin_eval_poly(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, int32_t n, fhelin_ct** out) {
+    NEED(c && x && coeffs && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.eval_poly(x->p, std::vector<double>(coeffs, coeffs + n)));
+    FHELIN_CATCH
+}
+int fhelin_eval_chebyshev(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, int32_t n, double a, double b, fhelin_ct** out) {
+    NEED(c && x && coeffs && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.eval_chebyshev(x->p, std::vector<double>(coeffs, coeffs + n), a, b));
+    FHELIN_CATCH
+}
+int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t, int32_t, int32_t) {
+    NEED(c);
+    return capi_fail(FHELIN_ERR_STATE, "CKKS bootstrapping is not built yet (SURVEY.md §8 row a15; see DESIGN.md §9)");
+}
+int fhelin_bootstrap(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
+    NEED(c && a && out);
+    return capi_fail(FHELIN_ERR_STATE, "CKKS bootstrapping is not built yet (SURVEY.md §8 row a15; see DESIGN.md §9)");
+}
+
 }  // extern "C"

@@ -83,7 +83,14 @@ public:
     CtPtr mult_no_relin(const CtPtr& a, const CtPtr& b);    // 3-component result
     CtPtr relinearize(const CtPtr& a);
     CtPtr mult_int(const CtPtr& a, u64 k, bool raise_deg, long double new_scale);  // by an integer constant
+    CtPtr mult_real(const CtPtr& a, double c);              // by a real constant: per-limb scalar round(c * Delta_level)
+    CtPtr add_real(const CtPtr& a, double c);               // add a real constant to every slot
     CtPtr rotate(const CtPtr& a, int index);
+    CtPtr conjugate(const CtPtr& a);
+    // polynomial evaluation (EvalPoly :1291, EvalMultMany :1297, EvalChebyshevFunction :1319-1335)
+    CtPtr eval_poly(const CtPtr& x, const std::vector<double>& coeffs);                 // power basis
+    CtPtr eval_chebyshev(const CtPtr& x, const std::vector<double>& coeffs, double a, double b);  // sum' c_k T_k(u), u = affine map of [a,b] to [-1,1]
+    CtPtr mult_many(const std::vector<CtPtr>& v);
     CtPtr rescale(const CtPtr& a);                           // drop one limb, divide the scale by it
     CtPtr level_reduce(const CtPtr& a, int new_ell);         // drop limbs without scaling
     // bring `a` to (ell, deg) with scale `scale` following the FLEXIBLEAUTO rules
@@ -96,6 +103,7 @@ public:
 
 private:
     Context& c_;
+    CtPtr cheb_recurse(const std::vector<double>& c, const std::vector<CtPtr>& T, const std::map<int, CtPtr>& G, int baby);
     void match(const CtPtr& a, const CtPtr& b, CtPtr& ao, CtPtr& bo);
 };
 

@@ -17,6 +17,7 @@ void launch_ew_muladd(const DeviceTables& t, u64* out, const u64* acc, const u64
                       int limb_count, hipStream_t s);
 void launch_ew_neg(const DeviceTables& t, u64* out, const u64* a, int nvec, int limb_first, int limb_count, hipStream_t s);
 void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s);
+void launch_ew_addscalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s);
 void launch_tensor(const DeviceTables& t, u64* d, const u64* a, const u64* b, int ell, hipStream_t s);
 void launch_automorph(const DeviceTables& t, u64* out, const u64* in, const u32* map, int nvec, hipStream_t s);
 void launch_rescale_lift(const DeviceTables& t, u64* lifted, const u64* last, int npoly, int ell, const u64* qlmod_row, hipStream_t s);

@@ -97,6 +97,22 @@ __global__ __launch_bounds__(256) void ew_scalar_kernel(DeviceTables t, u64* out
     reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
 }
 
+// out[v] = a[v] + s[limb]   (adds a constant to every NTT slot == adds the constant polynomial)
+__global__ __launch_bounds__(256) void ew_addscalar_kernel(DeviceTables t, u64* out, const u64* a, ScalarSet sc, int limb_first,
+                                                           int limb_count) {
+    const int v = blockIdx.y;
+    const int li = v % limb_count;
+    const u64 q = t.moduli[limb_first + li];
+    const u64 w = sc.v[2 * li];
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const u64x2 x = reinterpret_cast<const u64x2*>(a)[(size_t)v * row + n2];
+    u64x2 r;
+    r.x = add_mod(x.x, w, q);
+    r.y = add_mod(x.y, w, q);
+    reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
+}
+
 // tensor product of two 2-component ciphertexts a, b [2][ell][N] -> d [3][ell][N]
 __global__ __launch_bounds__(256) void tensor_kernel(DeviceTables t, u64* d, const u64* a, const u64* b, int ell) {
     const int l = blockIdx.y;
@@ -218,6 +234,10 @@ void launch_ew_neg(const DeviceTables& t, u64* out, const u64* a, int nvec, int 
 void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s) {
     if (nvec <= 0) return;
     hipLaunchKernelGGL(ew_scalar_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, sc, limb_first, limb_count);
+}
+void launch_ew_addscalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s) {
+    if (nvec <= 0) return;
+    hipLaunchKernelGGL(ew_addscalar_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, sc, limb_first, limb_count);
 }
 void launch_tensor(const DeviceTables& t, u64* d, const u64* a, const u64* b, int ell, hipStream_t s) {
     hipLaunchKernelGGL(tensor_kernel, grid2(t.log_n, ell), dim3(256), 0, s, t, d, a, b, ell);

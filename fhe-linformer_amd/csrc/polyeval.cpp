@@ -1,0 +1,177 @@
+// Polynomial evaluation on ciphertexts: real-constant multiply/add, power-basis EvalPoly, EvalMultMany and
+// Chebyshev-series evaluation (baby-step/giant-step with the identity T_i = 2 T_m T_{i-m} - T_{2m-i}).
+// Mirrors what the reference obtains from OpenFHE's EvalPoly / EvalMultMany / EvalChebyshevFunction
+// (reference src/FHEController.cpp:1289-1336).  All arithmetic runs through the GPU evaluator ops.
+#include <cmath>
+#include <map>
+#include "evaluator.h"
+
+namespace fhelin {
+
+static void real_to_scalars(const Context& c, long double v, int ell, ScalarSet& sc) {
+    const bool neg = v < 0;
+    const long double mag = roundl(fabsl(v));
+    const long double two64 = 18446744073709551616.0L;
+    const u64 hi = (u64)floorl(mag / two64);
+    const u64 lo = (u64)(mag - (long double)hi * two64);
+    for (int i = 0; i < ell; ++i) {
+        const u64 q = c.chain.q[i];
+        u64 r = (u64)((((u128)(hi % q) << 64) | lo) % q);
+        if (neg) r = neg_mod(r, q);
+        sc.v[2 * i] = r;
+        sc.v[2 * i + 1] = h_shoup(r, q);
+    }
+}
+
+CtPtr Evaluator::mult_real(const CtPtr& a, double cst) {
+    CtPtr x = a->deg >= 2 ? rescale(a) : a;
+    const long double sf = c_.sf_real[x->level()];
+    ScalarSet sc;
+    real_to_scalars(c_, (long double)cst * sf, x->ell, sc);
+    CtPtr o = new_ct(x->npoly, x->ell, x->deg + 1, x->scale * sf, x->slots);
+    launch_ew_scalar(c_.dt, o->d, x->d, sc, x->npoly * x->ell, 0, x->ell, c_.stream);
+    hip_check(hipGetLastError(), "mult_real");
+    return o;
+}
+
+CtPtr Evaluator::add_real(const CtPtr& a, double cst) {
+    ScalarSet sc;
+    real_to_scalars(c_, (long double)cst * a->scale, a->ell, sc);
+    CtPtr o = clone(a);
+    launch_ew_addscalar(c_.dt, o->d, a->d, sc, a->ell, 0, a->ell, c_.stream);
+    hip_check(hipGetLastError(), "add_real");
+    return o;
+}
+
+CtPtr Evaluator::conjugate(const CtPtr& a) {
+    if (!conj_key) throw Error(FHELIN_ERR_KEY, "no conjugation key");
+    return raw_rotate(a, 2ull * c_.N - 1, *conj_key);
+}
+
+CtPtr Evaluator::mult_many(const std::vector<CtPtr>& v) {
+    if (v.empty()) throw Error(FHELIN_ERR_ARG, "mult_many: empty vector");
+    std::vector<CtPtr> cur = v;
+    while (cur.size() > 1) {
+        std::vector<CtPtr> nxt;
+        for (size_t i = 0; i + 1 < cur.size(); i += 2) {
+            // identical operand pairs give identical products: reuse (EvalMultMany({r,r,...}) squares repeatedly)
+            if (i >= 2 && cur[i] == cur[i - 2] && cur[i + 1] == cur[i - 1]) nxt.push_back(nxt.back());
+            else nxt.push_back(mult(cur[i], cur[i + 1]));
+        }
+        if (cur.size() & 1) nxt.push_back(cur.back());
+        cur.swap(nxt);
+    }
+    return cur[0];
+}
+
+// bring a set of ciphertexts to one common (level, degree 1)
+static void align_deg1(Evaluator& ev, std::vector<CtPtr>& v, int from) {
+    int ell = 1 << 30;
+    for (size_t i = from; i < v.size(); ++i) {
+        if (v[i]->deg >= 2) v[i] = ev.rescale(v[i]);
+        ell = std::min(ell, v[i]->ell);
+    }
+    const long double sf = ev.ctx().sf_real[ev.ctx().L + 1 - ell];
+    for (size_t i = from; i < v.size(); ++i) v[i] = ev.adjust(v[i], ell, 1, sf);
+}
+
+CtPtr Evaluator::eval_poly(const CtPtr& x, const std::vector<double>& coeffs) {
+    int n = (int)coeffs.size() - 1;
+    while (n > 0 && coeffs[n] == 0.0) --n;
+    if (n < 1) throw Error(FHELIN_ERR_ARG, "eval_poly: need degree >= 1");
+    std::vector<CtPtr> pw(n + 1);
+    pw[1] = x->deg >= 2 ? rescale(x) : x;
+    for (int i = 2; i <= n; ++i) {
+        int hi = 1;
+        while (hi * 2 <= i) hi *= 2;
+        pw[i] = (hi == i) ? mult(pw[i / 2], pw[i / 2]) : mult(pw[hi], pw[i - hi]);
+    }
+    align_deg1(*this, pw, 1);
+    CtPtr acc;
+    for (int i = 1; i <= n; ++i) {
+        if (coeffs[i] == 0.0) continue;
+        CtPtr t = mult_real(pw[i], coeffs[i]);
+        acc = acc ? add(acc, t) : t;
+    }
+    if (!acc) throw Error(FHELIN_ERR_ARG, "eval_poly: all non-constant coefficients are zero");
+    return coeffs[0] != 0.0 ? add_real(acc, coeffs[0]) : acc;
+}
+
+CtPtr Evaluator::cheb_recurse(const std::vector<double>& c, const std::vector<CtPtr>& T, const std::map<int, CtPtr>& G, int baby) {
+    int n = (int)c.size() - 1;
+    while (n > 0 && c[n] == 0.0) --n;
+    if (n < baby) {
+        CtPtr acc;
+        for (int k = 1; k <= n; ++k) {
+            if (c[k] == 0.0) continue;
+            CtPtr t = mult_real(T[k], c[k]);
+            acc = acc ? add(acc, t) : t;
+        }
+        if (!acc) {  // constant polynomial: c0 as an encryption-free shift of 0 * T_1
+            acc = mult_real(T[1], 0.0);
+        }
+        return c[0] != 0.0 ? add_real(acc, c[0]) : acc;
+    }
+    int m = baby;
+    while (m * 2 <= n) m *= 2;
+    std::vector<double> q(n - m + 1, 0.0), r(m, 0.0);
+    for (int i = 0; i < m; ++i) r[i] = c[i];
+    q[0] = c[m];
+    for (int i = m + 1; i <= n; ++i) {
+        q[i - m] = 2 * c[i];
+        r[2 * m - i] -= c[i];
+    }
+    CtPtr qv = cheb_recurse(q, T, G, baby);
+    CtPtr res = mult(qv, G.at(m));
+    bool r_zero = true;
+    for (double v : r) r_zero = r_zero && v == 0.0;
+    if (r_zero) return res;
+    return add(res, cheb_recurse(r, T, G, baby));
+}
+
+CtPtr Evaluator::eval_chebyshev(const CtPtr& x, const std::vector<double>& coeffs_in, double a, double b) {
+    std::vector<double> c = coeffs_in;
+    int n = (int)c.size() - 1;
+    while (n > 0 && c[n] == 0.0) --n;
+    c.resize(n + 1);
+    if (n < 1) throw Error(FHELIN_ERR_ARG, "eval_chebyshev: need degree >= 1");
+    c[0] *= 0.5;  // series convention: c0/2 + sum_{k>=1} c_k T_k  (OpenFHE EvalChebyshevSeries)
+    // affine map of [a,b] onto [-1,1]
+    CtPtr u = x;
+    if (!(a == -1.0 && b == 1.0)) {
+        u = mult_real(x, 2.0 / (b - a));
+        u = add_real(u, -(a + b) / (b - a));
+    }
+    if (u->deg >= 2) u = rescale(u);
+    int l = 0;
+    while ((1 << (2 * l)) < n + 1) ++l;  // baby = 2^ceil(log2(n+1)/2)
+    int baby = std::max(2, 1 << l);
+    std::vector<CtPtr> T(baby + 1);
+    T[1] = u;
+    for (int k = 2; k <= baby; ++k) {
+        CtPtr t;
+        if (k % 2 == 0) {
+            t = mult(T[k / 2], T[k / 2]);
+            t = add(t, t);
+            t = add_real(t, -1.0);
+        } else {
+            t = mult(T[k / 2], T[k / 2 + 1]);
+            t = add(t, t);
+            t = sub(t, T[1]);
+        }
+        T[k] = rescale(t);
+    }
+    std::map<int, CtPtr> G;
+    G[baby] = T[baby];
+    for (int m = baby; m * 2 <= n; m *= 2) {
+        CtPtr t = mult(G[m], G[m]);
+        t = add(t, t);
+        t = add_real(t, -1.0);
+        G[2 * m] = rescale(t);
+    }
+    std::vector<CtPtr> babies(T.begin(), T.begin() + baby);  // T[0] unused, T[1..baby-1]
+    align_deg1(*this, babies, 1);
+    return cheb_recurse(c, babies, G, baby);
+}
+
+}  // namespace fhelin

@@ -163,6 +163,19 @@ int fhelin_fc_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs,
                                   fhelin_ct** outs, int32_t* n_out);                                    /* :1164 */
 int fhelin_fc_wrap_containers(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t inputs_number, fhelin_ct** out); /* :1193 */
 
+/* ---- polynomial evaluation (ADVANCEDSHE) -------------------------------------------------------- */
+int fhelin_mult_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out);              /* EvalMult(ct, double)            */
+int fhelin_add_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out);               /* EvalAdd(ct, double)             */
+int fhelin_mult_many(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out);      /* EvalMultMany       :1297        */
+/* power-basis polynomial sum_i coeffs[i] x^i                                                      EvalPoly           :1291        */
+int fhelin_eval_poly(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, int32_t n, fhelin_ct** out);
+/* Chebyshev series coeffs[0]/2 + sum_{k>=1} coeffs[k] T_k(u), u = (2x-(a+b))/(b-a)     EvalChebyshevFunction :1319-1335
+ * (the shim computes the coefficients from the C++ lambda exactly like EvalChebyshevCoefficients) */
+int fhelin_eval_chebyshev(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, int32_t n, double a, double b, fhelin_ct** out);
+/* CKKS bootstrapping: EvalBootstrapSetup/KeyGen :238-239 and EvalBootstrap :445 */
+int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t level_budget_enc, int32_t level_budget_dec, int32_t slots);
+int fhelin_bootstrap(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);
+
 #ifdef __cplusplus
 }
 #endif
