@@ -1,0 +1,767 @@
+/*
+ * FHEController.h — source-compatible shim of the reference's `class FHEController`
+ * (reference src/FHEController.h:22-161) on top of the MI355X-native engine's C ABI (fhelin.h).
+ *
+ * Same method names, argument meaning and error behaviour as the reference class, so that the reference's
+ * drivers (src/main.cpp, src/main_2.cpp) compile against this header unchanged:
+ *   - `Ctxt` / `Ptxt` are nullable, copyable shared handles (reference :19-20); `ct->GetLevel()`,
+ *     `ct->Clone()`, `ct->GetSlots()`, `pt->SetLength()`, `pt->GetRealPackedValue()` are provided.
+ *   - like reference src/FHEController.h:13-17 and src/Utils.h:15-17 this header leaks
+ *     `using namespace std; std::chrono; lbcrypto; utils` — main.cpp relies on that.
+ *   - I/O failure -> message + exit(1) (reference :59-71,:192-220); missing ciphertext file -> message and
+ *     a null handle (:1383-1394); engine failures -> uncaught std::runtime_error (OpenFHE throws likewise).
+ * Every arithmetic instruction runs in libfhelin_amd.so on the GPU; this header only marshals handles,
+ * parses the reference's text files into its three packing layouts, and fits Chebyshev coefficients.
+ *
+ * Persistence: OpenFHE's cereal BINARY files are out of scope.  `generate_context(true)`
+ * writes the parameter set and PRNG seed to ../<parameters_folder>/crypto-context.txt; key generation is
+ * deterministic in that seed, so `load_context` + `load_bootstrapping_and_rotation_keys` regenerate
+ * bit-identical keys.  Ciphertexts are saved in the engine's own little-endian limb format.
+ */
+#ifndef FHELIN_FHECONTROLLER_SHIM_H
+#define FHELIN_FHECONTROLLER_SHIM_H
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <fstream>
+#include <functional>
+#include <iomanip>
+#include <iostream>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fhelin.h"
+
+namespace lbcrypto {}  // the reference header does `using namespace lbcrypto;`
+
+using namespace lbcrypto;
+using namespace std;
+using namespace std::chrono;
+
+/* ---- the subset of reference src/Utils.h that FHEController and main.cpp use (:21-42, :61-87) ---------- */
+namespace utils {
+static inline chrono::time_point<steady_clock, nanoseconds> start_time() { return steady_clock::now(); }
+static duration<long long, ratio<1, 1000>> total_time;
+static inline void print_duration(chrono::time_point<steady_clock, nanoseconds> start, const string& title) {
+    auto ms = duration_cast<milliseconds>(steady_clock::now() - start);
+    total_time += ms;
+    auto secs = duration_cast<seconds>(ms);
+    ms -= duration_cast<milliseconds>(secs);
+    auto mins = duration_cast<minutes>(secs);
+    secs -= duration_cast<seconds>(mins);
+    if (mins.count() < 1)
+        cout << "(" << title << "): " << secs.count() << ":" << ms.count() << "s" << " (Total: " << duration_cast<seconds>(total_time).count() << "s)" << endl;
+    else
+        cout << "(" << title << "): " << mins.count() << "." << secs.count() << ":" << ms.count() << endl;
+}
+static inline vector<double> read_values_from_file(const string& filename, double scale = 1) {
+    vector<double> values;
+    ifstream file(filename);
+    if (!file.is_open()) {
+        std::cerr << "Can not open " << filename << std::endl;
+        return values;
+    }
+    string row;
+    while (std::getline(file, row)) {
+        istringstream stream(row);
+        string value;
+        while (std::getline(stream, value, ',')) {
+            try {
+                values.push_back(stod(value) * scale);
+            } catch (const invalid_argument&) {
+                cerr << "Can not convert: " << value << endl;
+            }
+        }
+    }
+    return values;
+}
+}  // namespace utils
+using namespace utils;
+
+/* ---- handles ------------------------------------------------------------------------------------------ */
+namespace fhelin_shim {
+inline void check(int rc, const char* what) {
+    if (rc != FHELIN_OK) throw std::runtime_error(string(what) + ": " + fhelin_last_error());
+}
+class CiphertextImpl;
+class PlaintextImpl;
+}  // namespace fhelin_shim
+
+using Ctxt = std::shared_ptr<fhelin_shim::CiphertextImpl>;
+using Ptxt = std::shared_ptr<fhelin_shim::PlaintextImpl>;
+
+namespace fhelin_shim {
+class CiphertextImpl {
+public:
+    fhelin_ctx* ctx;
+    fhelin_ct* h;
+    CiphertextImpl(fhelin_ctx* c, fhelin_ct* x) : ctx(c), h(x) {}
+    ~CiphertextImpl() { fhelin_ct_free(h); }
+    CiphertextImpl(const CiphertextImpl&) = delete;
+    CiphertextImpl& operator=(const CiphertextImpl&) = delete;
+    size_t GetLevel() const {
+        int32_t lv = 0;
+        fhelin_ct_info(h, nullptr, nullptr, &lv, nullptr, nullptr, nullptr);
+        return (size_t)lv;
+    }
+    uint32_t GetSlots() const {
+        int32_t s = 0;
+        fhelin_ct_info(h, nullptr, nullptr, nullptr, nullptr, nullptr, &s);
+        return (uint32_t)s;
+    }
+    size_t GetNoiseScaleDeg() const {
+        int32_t d = 0;
+        fhelin_ct_info(h, nullptr, nullptr, nullptr, &d, nullptr, nullptr);
+        return (size_t)d;
+    }
+    Ctxt Clone() const {
+        fhelin_ct* o = nullptr;
+        check(fhelin_ct_clone(ctx, h, &o), "Clone");
+        return std::make_shared<CiphertextImpl>(ctx, o);
+    }
+};
+class PlaintextImpl {
+public:
+    fhelin_ctx* ctx;
+    fhelin_pt* h;          // null for a decryption result
+    vector<double> values;  // slot values
+    size_t length;
+    PlaintextImpl(fhelin_ctx* c, fhelin_pt* x, vector<double> v) : ctx(c), h(x), values(std::move(v)), length(values.size()) {}
+    ~PlaintextImpl() { fhelin_pt_free(h); }
+    PlaintextImpl(const PlaintextImpl&) = delete;
+    PlaintextImpl& operator=(const PlaintextImpl&) = delete;
+    void SetLength(size_t n) { length = n; }
+    void SetSlots(uint32_t) {}
+    vector<double> GetRealPackedValue() const {
+        vector<double> v(values.begin(), values.begin() + std::min(length, values.size()));
+        v.resize(length, 0.0);
+        return v;
+    }
+};
+}  // namespace fhelin_shim
+
+/* ---- the controller ------------------------------------------------------------------------------------ */
+class FHEController {
+    fhelin_ctx* context = nullptr;
+
+public:
+    int circuit_depth = 0;
+    int num_slots = 0;
+
+    FHEController() {}
+    ~FHEController() { fhelin_ctx_destroy(context); }
+    FHEController(const FHEController&) = delete;
+    FHEController& operator=(const FHEController&) = delete;
+
+    /* Context generating/loading (reference :3-235).  The literal reference parameters are N=2^15, 28 Q limbs,
+     * 7 special limbs, dnum 4 (:6-35); FHELIN_PRESET=bench selects BASELINE.json's N=2^16 / 24+6 limbs. */
+    void generate_context(bool serialize = false, bool secure = false) {
+        (void)secure;  // parsed but ignored by the reference as well (:3,:10)
+        num_slots = 1 << 14;
+        level_budget = {3, 3};
+        fhelin_params p = default_params();
+        circuit_depth = p.n_q - 1;
+        cout << endl << "Ciphertexts depth: " << circuit_depth << ", available multiplications: " << 12 - 2 << endl;
+        create(p);
+        cout << "Context built, generating keys..." << endl;
+        fhelin_shim::check(fhelin_keygen(context), "KeyGen");
+        fhelin_shim::check(fhelin_gen_relin_key(context), "EvalMultKeyGen");
+        cout << "Generated." << endl;
+        if (!serialize) return;
+        cout << "Now serializing keys ..." << endl;
+        ofstream f("../" + parameters_folder + "/crypto-context.txt", ios::out | ios::binary);
+        if (!f.is_open()) {
+            cerr << "Error serializing the crypto context in \"" << "../" + parameters_folder + "/crypto-context.txt" << "\"" << endl;
+            exit(1);
+        }
+        f << "fhelin-context 1\n" << p.log_n << ' ' << p.n_q << ' ' << p.first_bits << ' ' << p.scale_bits << ' ' << p.n_p << ' '
+          << p.special_bits << ' ' << p.dnum << ' ' << p.log_slots << ' ' << p.hamming << ' ' << p.seed << '\n';
+        cout << "Crypto Context have been serialized" << std::endl;
+    }
+    void generate_context(int log_ring, int log_scale, int log_primes, int digits_hks, int cts_levels, int stc_levels, int relu_deg,
+                          bool serialize = false) {
+        (void)serialize;
+        num_slots = 1 << 14;
+        level_budget = {(uint32_t)cts_levels, (uint32_t)stc_levels};
+        relu_degree = relu_deg;
+        fhelin_params p = default_params();
+        p.log_n = log_ring;
+        p.first_bits = log_scale;
+        p.scale_bits = log_primes;
+        p.dnum = digits_hks;
+        circuit_depth = p.n_q - 1;
+        create(p);
+        fhelin_shim::check(fhelin_keygen(context), "KeyGen");
+        fhelin_shim::check(fhelin_gen_relin_key(context), "EvalMultKeyGen");
+    }
+    void load_context(bool verbose = true) {
+        ifstream f("../" + parameters_folder + "/crypto-context.txt", ios::in | ios::binary);
+        if (!f.is_open()) {
+            cerr << "I cannot find ../" << parameters_folder << "/crypto-context.txt" << endl;
+            exit(1);
+        }
+        string magic;
+        int ver = 0;
+        fhelin_params p = default_params();
+        f >> magic >> ver >> p.log_n >> p.n_q >> p.first_bits >> p.scale_bits >> p.n_p >> p.special_bits >> p.dnum >> p.log_slots >>
+            p.hamming >> p.seed;
+        if (!f || magic != "fhelin-context") {
+            cerr << "Error reading serialization of the crypto context from crypto-context.txt" << endl;
+            exit(1);
+        }
+        num_slots = 1 << 14;
+        level_budget = {3, 3};
+        circuit_depth = p.n_q - 2;  // the reference recomputes the depth without the +1 here (:226-230, quirk Q2)
+        create(p);
+        fhelin_shim::check(fhelin_keygen(context), "KeyGen");
+        fhelin_shim::check(fhelin_gen_relin_key(context), "EvalMultKeyGen");
+        if (verbose) cout << "CtoS: " << level_budget[0] << ", StoC: " << level_budget[1] << endl;
+    }
+
+    /* rotation / bootstrapping keys (reference :237-343) */
+    void generate_bootstrapping_keys(int bootstrap_slots) {
+        fhelin_shim::check(fhelin_bootstrap_setup(context, (int)level_budget[0], (int)level_budget[1], bootstrap_slots), "EvalBootstrapSetup");
+    }
+    void generate_rotation_keys(vector<int> rotations, bool serialize = false, string filename = "") {
+        if (serialize && filename.size() == 0) {
+            cout << "Filename cannot be empty when serializing rotation keys." << endl;
+            return;
+        }
+        // the reference's list (src/main.cpp:84) omits indices the circuit uses (quirk Q3): generate the union
+        vector<int32_t> all(rotations.begin(), rotations.end());
+        for (int i = 0; i < 14; i++) {
+            all.push_back(1 << i);
+            all.push_back(-(1 << i));
+        }
+        fhelin_shim::check(fhelin_gen_rotation_keys(context, all.data(), (int32_t)all.size()), "EvalRotateKeyGen");
+        if (serialize) {
+            ofstream f("../" + parameters_folder + "/rot_" + filename, ios::out | ios::binary);
+            if (!f.is_open()) {
+                cerr << "Error serializing Rotation keys" << "../" + parameters_folder + "/rot_" + filename << std::endl;
+                exit(1);
+            }
+            f << "fhelin-rotations " << all.size();
+            for (int r : all) f << ' ' << r;
+            f << '\n';
+        }
+    }
+    void generate_bootstrapping_and_rotation_keys(vector<int> rotations, int bootstrap_slots, bool serialize, const string& filename) {
+        if (serialize && filename.empty()) {
+            cout << "Filename cannot be empty when serializing bootstrapping and rotation keys." << endl;
+            return;
+        }
+        generate_bootstrapping_keys(bootstrap_slots);
+        generate_rotation_keys(rotations, serialize, filename);
+    }
+    void load_bootstrapping_and_rotation_keys(const string& filename, int bootstrap_slots, bool verbose) {
+        auto start = start_time();
+        generate_bootstrapping_keys(bootstrap_slots);
+        load_rotation_keys(filename, false);
+        if (verbose) print_duration(start, "Loading bootstrapping pre-computations + rotations");
+    }
+    void load_rotation_keys(const string& filename, bool verbose) {
+        auto start = start_time();
+        ifstream f("../" + parameters_folder + "/rot_" + filename, ios::in | ios::binary);
+        if (!f.is_open()) {
+            cerr << "Cannot read serialization from " << "../" + parameters_folder + "/rot_" + filename << std::endl;
+            exit(1);
+        }
+        string magic;
+        size_t n = 0;
+        f >> magic >> n;
+        vector<int32_t> idx(n);
+        for (auto& r : idx) f >> r;
+        if (!f || magic != "fhelin-rotations") {
+            cerr << "Could not deserialize eval rot key file" << std::endl;
+            exit(1);
+        }
+        fhelin_shim::check(fhelin_gen_rotation_keys(context, idx.data(), (int32_t)idx.size()), "EvalRotateKeyGen");
+        if (verbose) print_duration(start, "Loading rotation keys");
+    }
+    void clear_bootstrapping_and_rotation_keys(int) {}
+    void clear_rotation_keys() {}
+    void clear_context(int) {}
+
+    /* CKKS encoding / encryption (reference :348-404) */
+    Ptxt encode(const vector<double>& vec, int level, int plaintext_num_slots) {
+        if (plaintext_num_slots == 0) plaintext_num_slots = num_slots;
+        fhelin_pt* h = nullptr;
+        fhelin_shim::check(fhelin_encode(context, vec.data(), (int32_t)vec.size(), level, plaintext_num_slots, &h), "MakeCKKSPackedPlaintext");
+        vector<double> v(vec);
+        v.resize(plaintext_num_slots, 0.0);
+        return std::make_shared<fhelin_shim::PlaintextImpl>(context, h, std::move(v));
+    }
+    Ptxt encode(double val, int level, int plaintext_num_slots) {
+        if (plaintext_num_slots == 0) plaintext_num_slots = num_slots;
+        return encode(vector<double>(plaintext_num_slots, val), level, plaintext_num_slots);
+    }
+    Ctxt encrypt(const vector<double>& vec, int level = 0, int plaintext_num_slots = 0) {
+        return encrypt_ptxt(encode(vec, level, plaintext_num_slots));
+    }
+    Ctxt encrypt_ptxt(const Ptxt& p) {
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_encrypt(context, p->h, &o), "Encrypt");
+        return wrap(o);
+    }
+    Ptxt decrypt(const Ctxt& c) {
+        int slots = c->GetSlots() ? (int)c->GetSlots() : num_slots;
+        vector<double> v(slots);
+        fhelin_shim::check(fhelin_decrypt(context, c->h, v.data(), slots), "Decrypt");
+        return std::make_shared<fhelin_shim::PlaintextImpl>(context, nullptr, std::move(v));
+    }
+    vector<double> decrypt_tovector(const Ctxt& c, int slots) {
+        if (slots == 0) slots = num_slots;
+        vector<double> v(slots);
+        fhelin_shim::check(fhelin_decrypt(context, c->h, v.data(), slots), "Decrypt");
+        return v;
+    }
+
+    /* homomorphic operations (reference :409-469) */
+    Ctxt add(const Ctxt& c1, const Ctxt& c2) { return bin(fhelin_add, c1, c2, "EvalAdd"); }
+    Ctxt add(const Ctxt& c1, const Ptxt& c2) {
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_add_plain(context, c1->h, c2->h, &o), "EvalAdd");
+        return wrap(o);
+    }
+    Ctxt add(vector<Ctxt> c) {
+        auto hs = handles(c);
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_fc_add_many(context, hs.data(), (int32_t)hs.size(), &o), "EvalAddMany");
+        return wrap(o);
+    }
+    Ctxt mult(const Ctxt& c1, const Ctxt& c2) { return bin(fhelin_mult, c1, c2, "EvalMult"); }
+    Ctxt mult(const Ctxt& c, double d) {
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_fc_mult_const(context, c->h, d, &o), "EvalMult");
+        return wrap(o);
+    }
+    Ctxt mult(const Ctxt& c, const Ptxt& p) {
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_mult_plain(context, c->h, p->h, &o), "EvalMult");
+        return wrap(o);
+    }
+    Ctxt rotate(const Ctxt& c, int index) {
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_rotate(context, c->h, index, &o), "EvalRotate");
+        return wrap(o);
+    }
+    Ctxt bootstrap(const Ctxt& c, bool timing = false) {
+        auto start = start_time();
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_bootstrap(context, c->h, &o), "EvalBootstrap");
+        if (timing) print_duration(start, "Bootstrapping " + to_string(c->GetSlots()) + " slots");
+        return wrap(o);
+    }
+    Ctxt bootstrap(const Ctxt& c, int precision, bool timing = false) {
+        (void)precision;
+        if (static_cast<int>(c->GetLevel()) + 2 < circuit_depth)
+            cout << "You are bootstrapping with remaining levels! You are at " << to_string(c->GetLevel()) << "/" << circuit_depth - 2 << endl;
+        return bootstrap(c, timing);
+    }
+    Ctxt relu(const Ctxt& c, double scale, bool timing = false) {
+        auto start = start_time();
+        Ctxt res = chebyshev([scale](double x) -> double { return x < 0 ? 0 : (1 / scale) * x; }, c, -1, 1, relu_degree);
+        if (timing) print_duration(start, "ReLU d = " + to_string(relu_degree) + " evaluation");
+        return res;
+    }
+
+    /* text I/O and packing layouts (reference :501-698) */
+    Ctxt read_input(const string& filename, double scale = 1) {
+        vector<double> input = read_values_from_file(filename);
+        for (auto& v : input) v *= scale;
+        return encrypt(input, circuit_depth - 10, num_slots);
+    }
+    Ctxt read_repeated_input(const string& filename, double scale = 1) {
+        vector<double> input = read_values_from_file(filename);  // the reference encrypts `input`, not `repeated` (quirk Q7)
+        for (auto& v : input) v *= scale;
+        return encrypt(input, 0, num_slots);
+    }
+    Ctxt read_expanded_input(const string& filename, double scale = 1) { return encrypt(expanded(filename, scale, 128), 0, num_slots); }
+    Ptxt read_plain_input(const string& filename, int level = 0, double scale = 1) {
+        vector<double> input = read_values_from_file(filename);
+        for (auto& v : input) v *= scale;
+        return encode(input, level, num_slots);
+    }
+    vector<Ptxt> read_plain_256_input(const string& filename, int level = 0, double scale = 1) {
+        vector<double> input = read_values_from_file(filename);
+        need(input, 256, filename);
+        for (auto& v : input) v *= scale;
+        vector<double> a(input.begin(), input.begin() + 128), b(input.begin() + 128, input.begin() + 256);
+        return {encode(a, level, num_slots), encode(b, level, num_slots)};
+    }
+    Ptxt read_plain_repeated_input(const string& filename, int level = 0, double scale = 1) {
+        vector<double> input = read_values_from_file(filename);
+        need(input, 128, filename);
+        vector<double> rep;
+        for (int j = 0; j < 128; j++)
+            for (int i = 0; i < 128; i++) rep.push_back(input[i] * scale);
+        return encode(rep, level, num_slots);
+    }
+    Ptxt read_plain_repeated_512_input(const string& filename, int level = 0, double scale = 1) {
+        vector<double> input = read_values_from_file(filename);
+        need(input, 512, filename);
+        vector<double> rep;
+        for (int j = 0; j < 32; j++)
+            for (int i = 0; i < 512; i++) rep.push_back(input[i] * scale);
+        return encode(rep, level, num_slots);
+    }
+    Ptxt read_plain_expanded_input(const string& filename, int level = 0, double scale = 1) {
+        return encode(expanded(filename, scale, 128), level, num_slots);
+    }
+    Ptxt read_plain_expanded_input(const string& filename, int level, double scale, int num_inputs) {
+        return encode(expanded(filename, scale, num_inputs), level, num_slots);
+    }
+
+    /* debug printing: decrypts with the secret key on the "server", as the reference does (:700-826, quirk Q5) */
+    void print(const Ctxt& c, int slots = 0, string prefix = "") {
+        if (slots == 0) slots = num_slots;
+        cout << prefix << " (Lv. " << c->GetLevel() << ") ";
+        vector<double> v = decrypt_tovector(c, num_slots);
+        cout << setprecision(4) << fixed << "[ ";
+        for (int i = 0; i < slots; i++) print_slot(v[i], i == slots - 1, " 0.0000");
+        cout << endl;
+    }
+    void print_padded(const Ctxt& c, int slots = 0, int padding = 1, string prefix = "") {
+        if (slots == 0) slots = num_slots;
+        cout << prefix;
+        vector<double> v = decrypt_tovector(c, num_slots);
+        cout << setprecision(10) << fixed << "[ ";
+        for (int i = 0; i < slots * padding && i < (int)v.size(); i += padding) print_slot(v[i], i == slots - 1, " 0.000");
+        cout << endl;
+    }
+    void print_expanded(const Ctxt& c, int slots = 0, int expansion_factor = 1, string prefix = "") {
+        if (slots == 0) slots = num_slots;
+        cout << prefix << " (Lv. " << c->GetLevel() << ") ";
+        vector<double> v = decrypt_tovector(c, num_slots);
+        cout << setprecision(4) << fixed << "[ ";
+        for (int i = 0; i < slots; i++)
+            if (i % expansion_factor == 0) print_slot(v[i], i == slots - 1, " 0.000");
+        cout << " ]" << endl;
+    }
+    void print_min_max(const Ctxt& c) {
+        vector<double> v = decrypt_tovector(c, (int)c->GetSlots() ? (int)c->GetSlots() : num_slots);
+        cout << "min: " << *min_element(v.begin(), v.end()) << ", max: " << *max_element(v.begin(), v.end()) << endl;
+    }
+
+    /* rotate-and-sum reductions and matmuls (reference :829-1058) */
+    Ctxt rotsum(const Ctxt& in, int slots, int padding) { return un2(fhelin_fc_rotsum, in, slots, padding, "rotsum"); }
+    Ctxt rotsum_padded(const Ctxt& in, int slots) { return un2(fhelin_fc_rotsum, in, slots, slots, "rotsum_padded"); }
+    Ctxt repeat(const Ctxt& in, int slots) { return un2(fhelin_fc_repeat, in, slots, 1, "repeat"); }
+    Ctxt repeat(const Ctxt& in, int slots, int padding) { return un2(fhelin_fc_repeat, in, slots, padding, "repeat"); }
+
+    vector<Ctxt> matmulRE(vector<Ctxt> rows, const Ptxt& weight, const Ptxt& bias) { return mm_pt(rows, weight, bias, 128, 128); }
+    vector<Ctxt> matmulRE(vector<Ctxt> rows, const Ptxt& weight, const Ptxt& bias, int row_size, int padding) {
+        return mm_pt(rows, weight, bias, row_size, padding);
+    }
+    vector<Ctxt> matmulRE(vector<Ctxt> rows, const Ctxt& weight, int row_size, int padding) { return mm_ct(rows, weight, row_size, padding); }
+    vector<Ctxt> matmulRElarge(vector<Ctxt>& rows, const vector<Ptxt>& weight, const Ptxt& bias, double mask_value = 1) {
+        auto hs = handles(rows);
+        vector<const fhelin_pt*> ws;
+        for (auto& w : weight) ws.push_back(w->h);
+        vector<fhelin_ct*> outs(rows.size());
+        fhelin_shim::check(fhelin_fc_matmulRElarge(context, hs.data(), (int32_t)hs.size(), ws.data(), (int32_t)ws.size(),
+                                                   bias ? bias->h : nullptr, mask_value, outs.data()), "matmulRElarge");
+        return wrap_all(outs);
+    }
+    vector<Ctxt> matmulCR(vector<Ctxt> rows, const Ptxt& weight, const Ptxt& bias) { return mm_pt(rows, weight, bias, 128, 1); }
+    vector<Ctxt> matmulCR(vector<Ctxt> rows, const Ctxt& matrix) { return mm_ct(rows, matrix, 64, 1); }
+    vector<Ctxt> matmulCR_128(vector<Ctxt> rows, const Ctxt& matrix) { return mm_ct(rows, matrix, 128, 1); }
+    Ctxt matmulCR_128(Ctxt row, const Ctxt& matrix) { return mm_ct({row}, matrix, 128, 1)[0]; }
+    vector<Ctxt> matmulCRlarge(vector<vector<Ctxt>> rows, vector<Ptxt> weights, const Ptxt& bias) {
+        vector<const fhelin_ct*> hs;
+        for (auto& r : rows)
+            for (int j = 0; j < 4; j++) hs.push_back(r.at(j)->h);
+        vector<const fhelin_pt*> ws;
+        for (auto& w : weights) ws.push_back(w->h);
+        if (ws.size() < 4) throw std::runtime_error("matmulCRlarge: need 4 weight blocks");
+        vector<fhelin_ct*> outs(rows.size());
+        fhelin_shim::check(fhelin_fc_matmulCRlarge(context, hs.data(), (int32_t)rows.size(), ws.data(), bias ? bias->h : nullptr, outs.data()),
+                           "matmulCRlarge");
+        return wrap_all(outs);
+    }
+    Ctxt matmulScores(vector<Ctxt> queries, const Ctxt& key) {
+        auto hs = handles(queries);
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_fc_matmulScores(context, hs.data(), (int32_t)hs.size(), key->h, &o), "matmulScores");
+        return wrap(o);
+    }
+    Ctxt matmulScores(Ctxt query, const Ctxt& key) { return matmulScores(vector<Ctxt>{query}, key); }
+
+    /* layout shuffles (reference :1060-1205) */
+    Ctxt wrapUpRepeated(vector<Ctxt> vectors) { return many(fhelin_fc_wrapUpRepeated, vectors, "wrapUpRepeated"); }
+    Ctxt wrapUpExpanded(vector<Ctxt> vectors) { return many(fhelin_fc_wrapUpExpanded, vectors, "wrapUpExpanded"); }
+    vector<Ctxt> unwrapExpanded(Ctxt c, int inputs_num) {
+        vector<fhelin_ct*> outs(inputs_num);
+        fhelin_shim::check(fhelin_fc_unwrapExpanded(context, c->h, inputs_num, outs.data()), "unwrapExpanded");
+        return wrap_all(outs);
+    }
+    vector<Ctxt> unwrapScoresExpanded(Ctxt c, int inputs_num) {
+        vector<fhelin_ct*> outs(inputs_num);
+        fhelin_shim::check(fhelin_fc_unwrapScoresExpanded(context, c->h, inputs_num, outs.data()), "unwrapScoresExpanded");
+        return wrap_all(outs);
+    }
+    vector<Ctxt> unwrap_512_in_4_128(const Ctxt& c, int index) {
+        vector<fhelin_ct*> outs(4);
+        fhelin_shim::check(fhelin_fc_unwrap_512_in_4_128(context, c->h, index, outs.data()), "unwrap_512_in_4_128");
+        return wrap_all(outs);
+    }
+    vector<vector<Ctxt>> unwrapRepeatedLarge(vector<Ctxt> c, int input_number) {
+        auto hs = handles(c);
+        vector<fhelin_ct*> outs((size_t)4 * input_number);
+        fhelin_shim::check(fhelin_fc_unwrapRepeatedLarge(context, hs.data(), (int32_t)hs.size(), input_number, outs.data()), "unwrapRepeatedLarge");
+        vector<vector<Ctxt>> res;
+        for (int i = 0; i < input_number; i++) {
+            vector<Ctxt> four;
+            for (int j = 0; j < 4; j++) four.push_back(wrap(outs[4 * i + j]));
+            res.push_back(four);
+        }
+        return res;
+    }
+    vector<Ctxt> generate_containers(vector<Ctxt> inputs, const Ptxt& bias) {
+        cout << "inputs.size(): " << inputs.size() << endl;
+        auto hs = handles(inputs);
+        vector<fhelin_ct*> outs((inputs.size() + 31) / 32);
+        int32_t n = 0;
+        fhelin_shim::check(fhelin_fc_generate_containers(context, hs.data(), (int32_t)hs.size(), bias ? bias->h : nullptr, outs.data(), &n),
+                           "generate_containers");
+        outs.resize(n);
+        return wrap_all(outs);
+    }
+    Ctxt wrap_containers(vector<Ctxt> inputs, int inputs_number) {
+        auto hs = handles(inputs);
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_fc_wrap_containers(context, hs.data(), (int32_t)hs.size(), inputs_number, &o), "wrap_containers");
+        return wrap(o);
+    }
+
+    /* masks (reference :1207-1286) */
+    Ctxt mask_block(const Ctxt& c, int from, int to, double mask_value = 1) { return mask(c, 0, from, to, mask_value); }
+    Ctxt mask_heads(const Ctxt& c, double mask_value = 1) { return mask(c, 1, 0, 0, mask_value); }
+    Ctxt mask_heads_128(const Ctxt& c, double mask_value = 1) { return mask(c, 2, 0, 0, mask_value); }
+    Ctxt mask_mod_n(const Ctxt& c, int n) { return mask(c, 3, n, 0, 1); }
+    Ctxt mask_mod_n(const Ctxt& c, int n, int padding, int max_slots) {
+        (void)max_slots;  // ignored by the reference too (:1262-1273, quirk Q7)
+        return mask(c, 3, n, padding, 1);
+    }
+    Ctxt mask_first_n(const Ctxt& c, int n, double mask_value = 1) { return mask(c, 4, n, 0, mask_value); }
+
+    /* polynomial / Chebyshev activations (reference :1289-1336) */
+    Ctxt eval_exp(const Ctxt& c, int inputs_number) {
+        const double coeffs[7] = {1, 1, 1 / 2.0, 1 / 6.0, 1 / 24.0, 1 / 120.0, 1 / 720.0};
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_eval_poly(context, c->h, coeffs, 7, &o), "EvalPoly");
+        Ctxt res = wrap(o);
+        if ((int)res->GetLevel() + 4 > circuit_depth) res = bootstrap(res);
+        vector<const fhelin_ct*> eight(8, res->h);
+        fhelin_shim::check(fhelin_mult_many(context, eight.data(), 8, &o), "EvalMultMany");
+        res = wrap(o);
+        vector<double> m;
+        for (int i = 0; i < num_slots; i++) m.push_back((i % 128 < inputs_number && i < (128 * inputs_number)) ? 0 : -1);
+        return add(res, encode(m, (int)res->GetLevel(), num_slots));
+    }
+    Ctxt eval_inverse(const Ctxt& c, double min, double max) {
+        double middle = (max - min) / 2;
+        Ctxt res = add(c, encode(-middle - min, (int)c->GetLevel(), num_slots));
+        res = mult(res, encode(1 / middle, (int)res->GetLevel(), num_slots));
+        return chebyshev([](double x) -> double { return 1 / ((x * 9895) + 9995); }, res, -1, 1, 200);
+    }
+    Ctxt eval_inverse_naive(const Ctxt& c, double min, double max) {
+        return chebyshev([](double x) -> double { return 1 / x; }, c, min, max, 119);
+    }
+    Ctxt eval_inverse_naive_2(const Ctxt& c, double min, double max, double mult) {
+        return chebyshev([mult](double x) -> double { return mult / x; }, c, min, max, 200);
+    }
+    Ctxt eval_gelu_function(const Ctxt& c, double min, double max, double mult, int degree) {
+        return chebyshev([mult](double x) -> double { return (0.5 * (x * (1 / mult)) * (1 + erf((x * (1 / mult)) / 1.41421356237))); }, c, min,
+                         max, degree);
+    }
+    Ctxt eval_tanh_function(const Ctxt& c, double min, double max, double mult, int degree) {
+        return chebyshev([mult](double x) -> double { return tanh(x * (1 / mult)); }, c, min, max, degree);
+    }
+
+    vector<Ctxt> slicing(vector<Ctxt>& arr, int X, int Y) {
+        if (Y - X >= (int)arr.size()) return arr;
+        if (Y > (int)arr.size()) Y = (int)arr.size();
+        return vector<Ctxt>(arr.begin() + X, arr.begin() + Y);
+    }
+
+    /* ciphertext checkpoint (reference :1360-1394) in the engine's own format */
+    void save(Ctxt v, string filename) { save(vector<Ctxt>{v}, filename); }
+    void save(vector<Ctxt> v, string filename) {
+        ofstream f(filename, ios::out | ios::binary);
+        if (!f.is_open()) return;
+        uint64_t magic = 0x46484C4E43543031ull, n = v.size();
+        f.write((const char*)&magic, 8);
+        f.write((const char*)&n, 8);
+        for (auto& c : v) {
+            int32_t npoly, ell, level, deg, slots;
+            double scale;
+            fhelin_ct_info(c->h, &npoly, &ell, &level, &deg, &scale, &slots);
+            fhelin_params p;
+            fhelin_ctx_info(context, &p, nullptr, nullptr);
+            vector<uint64_t> limbs((size_t)npoly * ell << p.log_n);
+            fhelin_shim::check(fhelin_ct_export(context, c->h, limbs.data(), limbs.size()), "Serialize");
+            int32_t hdr[5] = {npoly, ell, deg, slots, p.log_n};
+            f.write((const char*)hdr, sizeof hdr);
+            f.write((const char*)&scale, 8);
+            f.write((const char*)limbs.data(), (streamsize)(limbs.size() * 8));
+        }
+    }
+    vector<Ctxt> load_vector(string filename) {
+        vector<Ctxt> result;
+        ifstream f(filename, ios::in | ios::binary);
+        uint64_t magic = 0, n = 0;
+        if (f.is_open()) {
+            f.read((char*)&magic, 8);
+            f.read((char*)&n, 8);
+        }
+        if (!f || magic != 0x46484C4E43543031ull) {
+            cerr << "Could not find \"" << filename << "\"" << endl;
+            return result;
+        }
+        for (uint64_t i = 0; i < n; i++) {
+            int32_t hdr[5];
+            double scale;
+            f.read((char*)hdr, sizeof hdr);
+            f.read((char*)&scale, 8);
+            vector<uint64_t> limbs((size_t)hdr[0] * hdr[1] << hdr[4]);
+            f.read((char*)limbs.data(), (streamsize)(limbs.size() * 8));
+            if (!f) break;
+            fhelin_ct* o = nullptr;
+            fhelin_shim::check(fhelin_ct_import(context, limbs.data(), hdr[0], hdr[1], hdr[2], scale, hdr[3], &o), "Deserialize");
+            result.push_back(wrap(o));
+        }
+        return result;
+    }
+    Ctxt load_ciphertext(string filename) {
+        vector<Ctxt> v = load_vector(filename);
+        return v.empty() ? Ctxt() : v[0];
+    }
+
+    int relu_degree = 119;
+    string parameters_folder = "keys";
+
+    /* not part of the reference API: the engine handle, for tests and benchmarks */
+    fhelin_ctx* engine() { return context; }
+
+    /* EvalChebyshevCoefficients + EvalChebyshevSeries: coefficients fitted on the host (fp64), series on the GPU */
+    Ctxt chebyshev(std::function<double(double)> func, const Ctxt& c, double a, double b, int degree) {
+        const int n = degree + 1;
+        const double pi = 3.14159265358979323846, bma = 0.5 * (b - a), bpa = 0.5 * (b + a);
+        vector<double> fx(n), coeff(n);
+        for (int i = 0; i < n; i++) fx[i] = func(std::cos(pi * (i + 0.5) / n) * bma + bpa);
+        for (int k = 0; k < n; k++) {
+            double s = 0;
+            for (int j = 0; j < n; j++) s += fx[j] * std::cos(pi * k * (j + 0.5) / n);
+            coeff[k] = 2.0 * s / n;
+        }
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_eval_chebyshev(context, c->h, coeff.data(), n, a, b, &o), "EvalChebyshevFunction");
+        return wrap(o);
+    }
+
+private:
+    vector<uint32_t> level_budget = {4, 4};
+
+    static fhelin_params default_params() {
+        fhelin_params p;
+        const char* preset = std::getenv("FHELIN_PRESET");
+        const bool bench = preset && string(preset) == "bench";
+        p.log_n = bench ? 16 : 15;
+        p.n_q = bench ? 24 : 28;
+        p.first_bits = 55;
+        p.scale_bits = 52;
+        p.n_p = bench ? 6 : 7;
+        p.special_bits = 60;
+        p.dnum = 4;
+        p.log_slots = 14;
+        p.hamming = 192;
+        const char* dev = std::getenv("FHELIN_DEVICE");
+        p.device = dev ? std::atoi(dev) : 0;
+        const char* seed = std::getenv("FHELIN_SEED");
+        p.seed = seed ? std::strtoull(seed, nullptr, 10) : 20240112ull;
+        return p;
+    }
+    void create(const fhelin_params& p) {
+        fhelin_ctx_destroy(context);
+        context = nullptr;
+        fhelin_shim::check(fhelin_ctx_create(&p, &context), "GenCryptoContext");
+    }
+    Ctxt wrap(fhelin_ct* h) { return std::make_shared<fhelin_shim::CiphertextImpl>(context, h); }
+    vector<Ctxt> wrap_all(const vector<fhelin_ct*>& hs) {
+        vector<Ctxt> v;
+        for (auto* h : hs) v.push_back(wrap(h));
+        return v;
+    }
+    static vector<const fhelin_ct*> handles(const vector<Ctxt>& v) {
+        vector<const fhelin_ct*> hs;
+        for (auto& c : v) hs.push_back(c->h);
+        return hs;
+    }
+    template <class F> Ctxt bin(F f, const Ctxt& a, const Ctxt& b, const char* what) {
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(f(context, a->h, b->h, &o), what);
+        return wrap(o);
+    }
+    template <class F> Ctxt un2(F f, const Ctxt& a, int x, int y, const char* what) {
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(f(context, a->h, x, y, &o), what);
+        return wrap(o);
+    }
+    template <class F> Ctxt many(F f, const vector<Ctxt>& v, const char* what) {
+        auto hs = handles(v);
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(f(context, hs.data(), (int32_t)hs.size(), &o), what);
+        return wrap(o);
+    }
+    Ctxt mask(const Ctxt& c, int kind, int x, int y, double v) {
+        fhelin_ct* o = nullptr;
+        fhelin_shim::check(fhelin_fc_mask(context, c->h, kind, x, y, v, &o), "mask");
+        return wrap(o);
+    }
+    vector<Ctxt> mm_pt(const vector<Ctxt>& rows, const Ptxt& w, const Ptxt& bias, int slots, int padding) {
+        auto hs = handles(rows);
+        vector<fhelin_ct*> outs(rows.size());
+        fhelin_shim::check(fhelin_fc_matmul_pt(context, hs.data(), (int32_t)hs.size(), w->h, bias ? bias->h : nullptr, slots, padding, outs.data()),
+                           "matmul");
+        return wrap_all(outs);
+    }
+    vector<Ctxt> mm_ct(const vector<Ctxt>& rows, const Ctxt& w, int slots, int padding) {
+        auto hs = handles(rows);
+        vector<fhelin_ct*> outs(rows.size());
+        fhelin_shim::check(fhelin_fc_matmul_ct(context, hs.data(), (int32_t)hs.size(), w->h, slots, padding, outs.data()), "matmul");
+        return wrap_all(outs);
+    }
+    static void need(const vector<double>& v, size_t n, const string& filename) {
+        if (v.size() < n) {
+            cerr << "\"" << filename << "\" holds " << v.size() << " values, " << n << " expected" << endl;
+            exit(1);
+        }
+    }
+    vector<double> expanded(const string& filename, double scale, int num_inputs) {
+        vector<double> input = read_values_from_file(filename);
+        need(input, 128, filename);
+        vector<double> rep;
+        for (int j = 0; j < 128; j++) {
+            for (int i = 0; i < num_inputs; i++) rep.push_back(input[j] * scale);
+            for (int i = 0; i < 128 - num_inputs; i++) rep.push_back(0);
+        }
+        return rep;
+    }
+    static void print_slot(double v, bool last, const char* zero) {
+        string segno = v > 0 ? " " : "-";
+        double a = std::fabs(v);
+        if (last) cout << segno << a << " ]";
+        else if (a < 0.00000001) cout << zero << ", ";
+        else cout << segno << a << ", ";
+    }
+};
+
+#endif /* FHELIN_FHECONTROLLER_SHIM_H */
