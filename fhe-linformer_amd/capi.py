@@ -30,6 +30,7 @@ PRESETS = {
     "reference": dict(log_n=15, n_q=28, first_bits=55, scale_bits=52, n_p=7, special_bits=60, dnum=4, log_slots=14, hamming=192),
     "deep": dict(log_n=17, n_q=30, first_bits=55, scale_bits=52, n_p=8, special_bits=60, dnum=4, log_slots=14, hamming=192),
     "toy": dict(log_n=12, n_q=6, first_bits=55, scale_bits=52, n_p=2, special_bits=60, dnum=3, log_slots=11, hamming=64),
+    "boot12": dict(log_n=12, n_q=22, first_bits=55, scale_bits=52, n_p=6, special_bits=60, dnum=4, log_slots=10, hamming=64),
     "toy13": dict(log_n=13, n_q=7, first_bits=55, scale_bits=52, n_p=3, special_bits=60, dnum=3, log_slots=12, hamming=64),
 }
 
@@ -122,6 +123,8 @@ def load_library():
         "fhelin_eval_chebyshev": (i32, [vp, vp, C.POINTER(C.c_double), i32, C.c_double, C.c_double, C.POINTER(vp)]),
         "fhelin_bootstrap_setup": (i32, [vp, i32, i32, i32]),
         "fhelin_bootstrap": (i32, [vp, vp, C.POINTER(vp)]),
+        "fhelin_bootstrap_config": (i32, [vp, i32, i32, i32, i32]),
+        "fhelin_bootstrap_partial": (i32, [vp, vp, i32, C.POINTER(vp)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -371,6 +374,15 @@ class Engine:
 
     def bootstrap(self, a):
         return self._un(self.lib.fhelin_bootstrap, a)
+
+    def bootstrap_setup(self, budget_enc=3, budget_dec=3, slots=0):
+        self._ck(self.lib.fhelin_bootstrap_setup(self.h, budget_enc, budget_dec, slots))
+
+    def bootstrap_config(self, K=28, R=3, cheb_degree=47, correction=10):
+        self._ck(self.lib.fhelin_bootstrap_config(self.h, K, R, cheb_degree, correction))
+
+    def bootstrap_partial(self, a, stage):
+        return self._un(self.lib.fhelin_bootstrap_partial, a, stage)
 
     def mult_const(self, a, d):
         return self._un(self.lib.fhelin_fc_mult_const, a, float(d))

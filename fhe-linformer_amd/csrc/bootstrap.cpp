@@ -1,0 +1,298 @@
+#include "bootstrap.h"
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <set>
+
+namespace fhelin {
+
+namespace {
+
+const double PI = 3.14159265358979323846264338327950288;
+
+void add_diag(DiagMap& m, int r, int n, int pos, cplx v) {
+    r = ((r % n) + n) % n;
+    auto& d = m[r];
+    if (d.empty()) d.assign(n, cplx(0, 0));
+    d[pos] += v;
+}
+
+// one radix-2 stage of the special FFT as a 3-diagonal map (see ckks_fft_special in client.cpp)
+DiagMap stage_map(int n, int len, bool inverse, const std::vector<u32>& rot, const std::vector<std::pair<double, double>>& ksi) {
+    DiagMap m;
+    const int lenh = len >> 1, lenq = len << 2, gap = (4 * n) / lenq;
+    for (int p = 0; p < n; ++p) {
+        const int jj = p % len;
+        if (inverse) {
+            if (jj < lenh) {
+                add_diag(m, 0, n, p, 1.0);
+                add_diag(m, lenh, n, p, 1.0);
+            } else {
+                const int j = jj - lenh;
+                const auto& k = ksi[(lenq - (rot[j] % lenq)) * gap];
+                const cplx w(k.first, k.second);
+                add_diag(m, -lenh, n, p, w);
+                add_diag(m, 0, n, p, -w);
+            }
+        } else {
+            if (jj < lenh) {
+                const auto& k = ksi[(rot[jj] % lenq) * gap];
+                add_diag(m, 0, n, p, 1.0);
+                add_diag(m, lenh, n, p, cplx(k.first, k.second));
+            } else {
+                const int j = jj - lenh;
+                const auto& k = ksi[(rot[j] % lenq) * gap];
+                add_diag(m, -lenh, n, p, 1.0);
+                add_diag(m, 0, n, p, -cplx(k.first, k.second));
+            }
+        }
+    }
+    return m;
+}
+
+// (B after A): out = sum_s e_s * rot_s( sum_r d_r * rot_r(x) ) = sum_{r,s} e_s * rot_s(d_r) * rot_{r+s}(x)
+DiagMap compose(const DiagMap& B, const DiagMap& A, int n) {
+    DiagMap C;
+    for (const auto& be : B)
+        for (const auto& ae : A) {
+            const int s = be.first, r = ae.first;
+            auto& c = C[(r + s) % n];
+            if (c.empty()) c.assign(n, cplx(0, 0));
+            for (int j = 0; j < n; ++j) c[j] += be.second[j] * ae.second[(j + s) % n];
+        }
+    // drop numerically empty diagonals
+    for (auto it = C.begin(); it != C.end();) {
+        double mx = 0;
+        for (const auto& v : it->second) mx = std::max(mx, std::abs(v));
+        if (mx < 1e-300) it = C.erase(it);
+        else ++it;
+    }
+    return C;
+}
+
+void scale_map(DiagMap& m, double f) {
+    for (auto& e : m)
+        for (auto& v : e.second) v *= f;
+}
+
+}  // namespace
+
+Bootstrapper::~Bootstrapper() {
+    if (mono_i_) {
+        try { ev_.ctx().pool.free(mono_i_); } catch (...) {}
+    }
+}
+
+LinStage Bootstrapper::prepare(const DiagMap& m) {
+    const int n = slots_;
+    LinStage st;
+    int g = n;
+    for (const auto& e : m)
+        if (e.first) g = std::gcd(g, e.first);
+    st.g0 = g;
+    const int span = n / g;  // number of possible multiples
+    const int count = (int)m.size();
+    int bsz = 1;
+    while (bsz * bsz < count) bsz <<= 1;
+    st.bsz = std::min(bsz, span);
+    for (const auto& e : m) {
+        const int k = e.first / g;
+        const int G = k / st.bsz, B = k % st.bsz;
+        const int sG = G * st.bsz * g;
+        auto p = std::make_shared<Plaintext>();
+        p->ctx = &ev_.ctx();
+        p->slots = n;
+        p->level = 0;
+        p->values.resize(n);
+        p->imag.resize(n);
+        for (int j = 0; j < n; ++j) {
+            const cplx v = e.second[((j - sG) % n + n) % n];  // rot_{-sG}(d)
+            p->values[j] = v.real();
+            p->imag[j] = v.imag();
+        }
+        st.terms.push_back({sG, B * g, p});
+    }
+    return st;
+}
+
+void Bootstrapper::setup(int budget_enc, int budget_dec, int slots) {
+    Context& c = ev_.ctx();
+    c.require_device();
+    if (!cl_.has_keys()) throw Error(FHELIN_ERR_KEY, "bootstrap setup needs the secret key (keygen first)");
+    if (slots <= 0) slots = 1 << c.prm.log_slots;
+    if (slots & (slots - 1) || slots > c.N / 2 || slots < 4) throw Error(FHELIN_ERR_ARG, "bootstrap: slots must be a power of two in [4, N/2]");
+    if (budget_enc < 1 || budget_dec < 1) throw Error(FHELIN_ERR_ARG, "bootstrap: level budget must be >= 1");
+    slots_ = slots;
+    const int n = slots;
+    int logn = 0;
+    while ((1 << logn) < n) ++logn;
+    budget_enc = std::min(budget_enc, logn);
+    budget_dec = std::min(budget_dec, logn);
+    std::vector<u32> rot;
+    std::vector<std::pair<double, double>> ksi;
+    ckks_fft_tables(n, rot, ksi);
+
+    const int gapN = (c.N / 2) / n;
+    const double q0 = (double)c.chain.q[0];
+    // CoeffsToSlots: inverse-FFT stages (len = n .. 2), total constant Delta_r / (gapN q0 K 2n) spread over the levels
+    auto build = [&](bool inverse, int budget, double total_factor, std::vector<LinStage>& out) {
+        std::vector<int> lens;
+        if (inverse) for (int len = n; len >= 2; len >>= 1) lens.push_back(len);
+        else for (int len = 2; len <= n; len <<= 1) lens.push_back(len);
+        const double f = std::pow(total_factor, 1.0 / budget);
+        size_t pos = 0;
+        for (int g = 0; g < budget; ++g) {
+            int cnt = logn / budget + (g < logn % budget ? 1 : 0);
+            DiagMap m = stage_map(n, lens[pos], inverse, rot, ksi);
+            for (int i = 1; i < cnt; ++i) m = compose(stage_map(n, lens[pos + i], inverse, rot, ksi), m, n);
+            pos += cnt;
+            scale_map(m, f);
+            out.push_back(prepare(m));
+        }
+    };
+    c2s_.clear();
+    s2c_.clear();
+    const double delta_r = (double)c.sf_real[0];
+    build(true, budget_enc, delta_r / ((double)gapN * q0 * K * 2.0 * n), c2s_);
+    build(false, budget_dec, 1.0 / (2.0 * PI), s2c_);
+
+    // rotation keys: baby/giant shifts of every stage, SubSum shifts, conjugation
+    std::set<int> idx;
+    for (const auto* v : {&c2s_, &s2c_})
+        for (const auto& st : *v)
+            for (const auto& t : st.terms) {
+                if (t.giant) idx.insert(t.giant);
+                if (t.baby) idx.insert(t.baby);
+            }
+    for (int r : idx) cl_.gen_rotation_key(r);
+    for (int j = 1; j < gapN; j <<= 1) cl_.gen_rotation_key(n * j);
+    if (!ev_.conj_key) cl_.gen_conj_key();
+
+    // cosine fit: f(y) = cos((2 pi K y - pi/2) / 2^R) on [-1,1]; R double-angle steps give sin(2 pi K y)
+    const int d = cheb_degree, nn = d + 1;
+    cheb_.assign(nn, 0.0);
+    std::vector<double> fx(nn);
+    const double sc = 1.0 / (double)(1 << R);
+    for (int j = 0; j < nn; ++j) fx[j] = std::cos((2.0 * PI * K * std::cos(PI * (j + 0.5) / nn) - PI / 2) * sc);
+    for (int k = 0; k < nn; ++k) {
+        double s = 0;
+        for (int j = 0; j < nn; ++j) s += fx[j] * std::cos(PI * k * (j + 0.5) / nn);
+        cheb_[k] = 2.0 * s / nn;
+    }
+
+    // multiplication by i == multiplication by the monomial X^{N/2}
+    const int L1 = c.L + 1;
+    const size_t N = c.N;
+    if (!mono_i_) mono_i_ = c.dalloc<u64>((size_t)L1 * N);
+    std::vector<u64> h((size_t)L1 * N, 0);
+    for (int l = 0; l < L1; ++l) h[(size_t)l * N + N / 2] = 1;
+    hip_check(hipMemcpyAsync(mono_i_, h.data(), h.size() * 8, hipMemcpyHostToDevice, c.stream), "monomial upload");
+    hip_check(hipStreamSynchronize(c.stream), "monomial sync");
+    launch_ntt(c.dt, LimbBatch{mono_i_, L1, nullptr, 0, L1}, false, c.stream);
+    hip_check(hipGetLastError(), "monomial ntt");
+    depth_ = budget_enc + budget_dec + R + 6;
+}
+
+CtPtr Bootstrapper::mult_i(const CtPtr& x) {
+    Context& c = ev_.ctx();
+    CtPtr o = ev_.new_ct(x->npoly, x->ell, x->deg, x->scale, x->slots);
+    launch_ew_mul(c.dt, o->d, x->d, mono_i_, x->npoly * x->ell, x->ell, 0, x->ell, c.stream);
+    hip_check(hipGetLastError(), "mult_i");
+    return o;
+}
+
+CtPtr Bootstrapper::apply(const LinStage& st, const CtPtr& xin) {
+    CtPtr x = xin->deg >= 2 ? ev_.rescale(xin) : xin;
+    std::map<int, CtPtr> babies;
+    babies[0] = x;
+    std::map<int, CtPtr> inner;
+    for (const auto& t : st.terms) {
+        auto it = babies.find(t.baby);
+        if (it == babies.end()) it = babies.emplace(t.baby, ev_.rotate(x, t.baby)).first;
+        CtPtr term = ev_.mult_plain(it->second, t.diag);
+        auto g = inner.find(t.giant);
+        if (g == inner.end()) inner[t.giant] = term;
+        else g->second = ev_.add(g->second, term);
+    }
+    CtPtr out;
+    for (auto& g : inner) {
+        CtPtr v = g.first ? ev_.rotate(g.second, g.first) : g.second;
+        out = out ? ev_.add(out, v) : v;
+    }
+    return out;
+}
+
+CtPtr Bootstrapper::mod_raise(const CtPtr& ct, long double& rho) {
+    Context& c = ev_.ctx();
+    CtPtr x = ct->deg >= 2 ? ev_.rescale(ct) : ct;
+    if (x->npoly != 2) throw Error(FHELIN_ERR_STATE, "bootstrap: ciphertext must be relinearised");
+    if (x->ell < 2) throw Error(FHELIN_ERR_STATE, "bootstrap: need at least two limbs to set the message scale (bootstrap one level earlier)");
+    if (x->ell > 2) x = ev_.level_reduce(x, 2);
+    const long double q0 = (long double)c.chain.q[0], q1 = (long double)c.chain.q[1];
+    const long double target = q0 / (long double)(1ull << correction);
+    const u64 k0 = (u64)llroundl(target * q1 / x->scale);
+    if (k0 < 2) throw Error(FHELIN_ERR_STATE, "bootstrap: ciphertext scale too large for the correction factor");
+    x = ev_.mult_int(x, k0, true, x->scale * (long double)k0);
+    x = ev_.rescale(x);  // one limb (q0), scale ~ q0 / 2^correction
+    rho = x->scale * (long double)(1ull << correction) / q0;
+
+    const size_t N = c.N;
+    const int L1 = c.L + 1;
+    hipStream_t s = c.stream;
+    u64* coef = c.dalloc<u64>(2 * N);
+    hip_check(hipMemcpyAsync(coef, x->d, 2 * N * 8, hipMemcpyDeviceToDevice, s), "modraise copy");
+    launch_ntt(c.dt, LimbBatch{coef, 2, nullptr, 0, 1}, true, s);
+    CtPtr up = ev_.new_ct(2, L1, 1, c.sf_real[0], slots_);
+    launch_modraise(c.dt, up->d, coef, 2, 0, L1, s);
+    launch_ntt(c.dt, LimbBatch{up->d, 2 * L1, nullptr, 0, L1}, false, s);
+    hip_check(hipGetLastError(), "modraise");
+    c.pool.free(coef);
+    // SubSum: project onto the subring of X^{N/(2 slots)} (sparse packing)
+    const int gapN = (c.N / 2) / slots_;
+    for (int j = 1; j < gapN; j <<= 1) {
+        const u64 g = c.galois_element(slots_ * j);
+        auto it = ev_.rot_keys.find(g);
+        if (it == ev_.rot_keys.end()) throw Error(FHELIN_ERR_KEY, "bootstrap: SubSum rotation key missing");
+        up = ev_.add(up, ev_.raw_rotate(up, g, *it->second));
+    }
+    return up;
+}
+
+CtPtr Bootstrapper::eval_mod(const CtPtr& x) {
+    CtPtr u = ev_.eval_chebyshev(x, cheb_, -1.0, 1.0);
+    for (int i = 0; i < R; ++i) {
+        CtPtr t = ev_.mult(u, u);
+        t = ev_.add(t, t);
+        u = ev_.add_real(t, -1.0);
+    }
+    return u;
+}
+
+CtPtr Bootstrapper::run(const CtPtr& ct, int stop_after) {
+    if (!ready()) throw Error(FHELIN_ERR_STATE, "EvalBootstrapSetup has not been called");
+    long double rho = 1;
+    CtPtr w = mod_raise(ct, rho);
+    if (stop_after == 1) return w;
+    for (const auto& st : c2s_) w = apply(st, w);
+    CtPtr wc = ev_.conjugate(w);
+    CtPtr a = ev_.add(w, wc);                    // real parts  t_k       / (q0 K)   (1/2 folded into the DFT constants)
+    if (stop_after == 2) return a;
+    CtPtr b = mult_i(ev_.sub(wc, w));            // imaginary   t_{k+n}   / (q0 K)
+    CtPtr a2 = eval_mod(a);
+    if (stop_after == 3) return a2;
+    CtPtr b2 = eval_mod(b);
+    CtPtr v = ev_.add(a2, mult_i(b2));
+    for (const auto& st : s2c_) v = apply(st, v);
+    // slots now hold m * rho / 2^correction: undo the correction exactly and absorb rho in the scale
+    v = ev_.mult_int(v, 1ull << correction, false, v->scale);
+    v->scale = v->scale * rho;
+    if (v->deg >= 2) v = ev_.rescale(v);
+    v->slots = ct->slots > 0 ? ct->slots : slots_;
+    return v;
+}
+
+CtPtr Bootstrapper::bootstrap(const CtPtr& ct) { return run(ct, 0); }
+CtPtr Bootstrapper::partial(const CtPtr& ct, int stage) { return run(ct, stage); }
+
+}  // namespace fhelin

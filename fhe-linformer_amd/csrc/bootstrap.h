@@ -1,0 +1,63 @@
+// CKKS bootstrapping on the GPU evaluator: ModRaise -> (SubSum) -> CoeffsToSlots -> approximate modular
+// reduction (Chebyshev cosine + double-angle) -> SlotsToCoeffs.  Mirrors what the reference obtains from
+// OpenFHE's EvalBootstrapSetup / EvalBootstrapKeyGen / EvalBootstrap (reference src/FHEController.cpp
+// :237-240, :280, :438-469; level budget {3,3}, 16384 slots, sparse ternary secret).
+#pragma once
+#include <complex>
+#include <map>
+#include <vector>
+#include "client.h"
+#include "evaluator.h"
+
+namespace fhelin {
+
+typedef std::complex<double> cplx;
+typedef std::map<int, std::vector<cplx>> DiagMap;  // rotation (mod slots) -> diagonal: out = sum_r d_r * rot(in, r)
+
+// one level of the homomorphic DFT, prepared for baby-step / giant-step evaluation
+struct LinStage {
+    int g0 = 1;    // all rotation indices are multiples of g0
+    int bsz = 1;   // baby-step count
+    struct Term {
+        int giant;   // giant shift (slots), applied after the inner sum
+        int baby;    // baby shift (slots)
+        PtPtr diag;  // diagonal, pre-rotated by -giant
+    };
+    std::vector<Term> terms;
+};
+
+class Bootstrapper {
+public:
+    Bootstrapper(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {}
+    ~Bootstrapper();
+    void setup(int budget_enc, int budget_dec, int slots);
+    bool ready() const { return slots_ > 0; }
+    CtPtr bootstrap(const CtPtr& ct);
+    // debug / test hook: stop after stage 1 (ModRaise+SubSum), 2 (CoeffsToSlots, real part), 3 (EvalMod, real part)
+    CtPtr partial(const CtPtr& ct, int stage);
+    int depth() const { return depth_; }
+
+    // parameters (DESIGN.md "Bootstrapping")
+    int K = 28;            // bound on |I|: t = Delta m + q0 I
+    int R = 3;             // double-angle iterations
+    int cheb_degree = 47;  // degree of the cosine fit (depth 6)
+    int correction = 10;   // message is scaled to q0 / 2^correction before ModRaise
+
+private:
+    Evaluator& ev_;
+    Client& cl_;
+    int slots_ = 0;
+    int depth_ = 0;
+    std::vector<LinStage> c2s_, s2c_;
+    std::vector<double> cheb_;
+    u64* mono_i_ = nullptr;  // NTT of X^{N/2} over the Q limbs: multiplication by i
+
+    LinStage prepare(const DiagMap& m);
+    CtPtr apply(const LinStage& st, const CtPtr& x);
+    CtPtr mult_i(const CtPtr& x);
+    CtPtr mod_raise(const CtPtr& ct, long double& rho);
+    CtPtr eval_mod(const CtPtr& x);
+    CtPtr run(const CtPtr& ct, int stop_after);
+};
+
+}  // namespace fhelin

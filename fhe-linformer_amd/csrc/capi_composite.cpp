@@ -193,13 +193,34 @@ int fhelin_eval_chebyshev(fhelin_ctx* c, const fhelin_ct* x, const double* coeff
     *out = wrap(c->ev.eval_chebyshev(x->p, std::vector<double>(coeffs, coeffs + n), a, b));
     FHELIN_CATCH
 }
-int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t, int32_t, int32_t) {
+int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t budget_enc, int32_t budget_dec, int32_t slots) {
     NEED(c);
-    return capi_fail(FHELIN_ERR_STATE, "CKKS bootstrapping is not built yet (SURVEY.md §8 row a15; see DESIGN.md §9)");
+    FHELIN_TRY
+    c->boot.setup(budget_enc, budget_dec, slots);
+    FHELIN_CATCH
 }
 int fhelin_bootstrap(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
-    return capi_fail(FHELIN_ERR_STATE, "CKKS bootstrapping is not built yet (SURVEY.md §8 row a15; see DESIGN.md §9)");
+    FHELIN_TRY
+    *out = wrap(c->boot.bootstrap(a->p));
+    FHELIN_CATCH
+}
+int fhelin_bootstrap_partial(fhelin_ctx* c, const fhelin_ct* a, int32_t stage, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->boot.partial(a->p, stage));
+    FHELIN_CATCH
+}
+int fhelin_bootstrap_config(fhelin_ctx* c, int32_t K, int32_t R, int32_t cheb_degree, int32_t correction) {
+    NEED(c);
+    FHELIN_TRY
+    if (K < 1 || R < 0 || R > 8 || cheb_degree < 3 || cheb_degree > 255 || correction < 0 || correction > 20)
+        throw Error(FHELIN_ERR_ARG, "bootstrap_config: parameter out of range");
+    c->boot.K = K;
+    c->boot.R = R;
+    c->boot.cheb_degree = cheb_degree;
+    c->boot.correction = correction;
+    FHELIN_CATCH
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 #include "evaluator.h"
 #include "client.h"
 #include "composite.h"
+#include "bootstrap.h"
 
 // opaque handle behind include/fhelin.h's `fhelin_ctx`
 struct fhelin_ctx {
@@ -13,7 +14,8 @@ struct fhelin_ctx {
     fhelin::Evaluator ev;
     fhelin::Client cl;
     fhelin::Composite comp;
-    explicit fhelin_ctx(const fhelin::Params& p) : ctx(p), ev(ctx), cl(ev, p.seed), comp(ev, cl) {}
+    fhelin::Bootstrapper boot;
+    explicit fhelin_ctx(const fhelin::Params& p) : ctx(p), ev(ctx), cl(ev, p.seed), comp(ev, cl), boot(ev, cl) {}
 };
 struct fhelin_ct {
     fhelin::CtPtr p;

@@ -130,6 +130,13 @@ void ckks_fft_special(std::vector<std::pair<double, double>>& pv, bool inverse) 
     for (int i = 0; i < size; ++i) pv[i] = {v[i].real(), v[i].imag()};
 }
 
+void ckks_fft_tables(int slots, std::vector<u32>& rot, std::vector<std::pair<double, double>>& ksi) {
+    const FftTables& t = fft_tables(slots);
+    rot = t.rot;
+    ksi.resize(t.ksi.size());
+    for (size_t i = 0; i < t.ksi.size(); ++i) ksi[i] = {t.ksi[i].real(), t.ksi[i].imag()};
+}
+
 static void ld_to_i128(long double v, u64& lo, u64& hi) {
     const bool neg = v < 0;
     long double mag = roundl(fabsl(v));
@@ -144,12 +151,14 @@ static void ld_to_i128(long double v, u64& lo, u64& hi) {
     hi = h;
 }
 
-std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>& values, int slots, int ell, long double scale) {
+std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>& values, const std::vector<double>& imag, int slots,
+                                           int ell, long double scale) {
     c.require_device();
     if (slots < 1 || (slots & (slots - 1)) || slots > c.N / 2) throw Error(FHELIN_ERR_ARG, "encode: slots must be a power of two <= N/2");
     if (ell < 1 || ell > c.L + 1) throw Error(FHELIN_ERR_ARG, "encode: level out of range");
     std::vector<std::pair<double, double>> v(slots, {0.0, 0.0});
     for (int i = 0; i < slots && i < (int)values.size(); ++i) v[i].first = values[i];
+    for (int i = 0; i < slots && i < (int)imag.size(); ++i) v[i].second = imag[i];
     ckks_fft_special(v, true);
     const size_t N = c.N;
     const size_t gap = (N / 2) / slots;
@@ -176,7 +185,7 @@ std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>
 std::shared_ptr<Encoding> Plaintext::at(int ell, long double scale) {
     for (auto& e : cache)
         if (e->ell == ell && fabsl(e->scale / scale - 1.0L) < 1e-12L) return e;
-    auto e = encode_to_device(*ctx, values, slots, ell, scale);
+    auto e = encode_to_device(*ctx, values, imag, slots, ell, scale);
     cache.push_back(e);
     return e;
 }

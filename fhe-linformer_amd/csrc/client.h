@@ -49,6 +49,9 @@ private:
 
 // special FFT helpers (shared by encode/decode); slots must be a power of two
 void ckks_fft_special(std::vector<std::pair<double, double>>& v, bool inverse);
-std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>& values, int slots, int ell, long double scale);
+// tables of the special FFT for `slots` slots: rot[j] = 5^j mod 4*slots, ksi[k] = exp(2 pi i k / (4*slots))
+void ckks_fft_tables(int slots, std::vector<u32>& rot, std::vector<std::pair<double, double>>& ksi);
+std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>& values, const std::vector<double>& imag, int slots,
+                                           int ell, long double scale);
 
 }  // namespace fhelin

@@ -39,6 +39,7 @@ struct Encoding {
 struct Plaintext {
     Context* ctx = nullptr;
     std::vector<double> values;  // real slot values, size == slots
+    std::vector<double> imag;    // optional imaginary parts (bootstrapping's DFT diagonals); empty = real vector
     int slots = 0;
     int level = 0;               // level requested at encode time (reference encode(vec, level, slots))
     std::vector<std::shared_ptr<Encoding>> cache;

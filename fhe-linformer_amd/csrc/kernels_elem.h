@@ -23,6 +23,7 @@ void launch_automorph(const DeviceTables& t, u64* out, const u64* in, const u32*
 void launch_rescale_lift(const DeviceTables& t, u64* lifted, const u64* last, int npoly, int ell, const u64* qlmod_row, hipStream_t s);
 void launch_rescale_finish(const DeviceTables& t, u64* out, const u64* c, const u64* lifted, int npoly, int ell, const u64* qlinv_row,
                            hipStream_t s);
+void launch_modraise(const DeviceTables& t, u64* out, const u64* src, int npoly, int src_limb, int nl, hipStream_t s);
 void launch_reduce_i128(const DeviceTables& t, u64* out, const u64* coeffs, int limb_first, int nlimbs, hipStream_t s);
 
 // ---- hybrid key switching (K6-K8)

@@ -170,6 +170,26 @@ __global__ __launch_bounds__(256) void rescale_lift_kernel(DeviceTables t, u64* 
     reinterpret_cast<u64x2*>(lifted)[(size_t)v * row + n2] = r;
 }
 
+// K9 ModRaise: centred lift of a single-limb polynomial (coefficient form, modulus q_src) into nl limbs.
+// src [npoly][N] -> out [npoly][nl][N]
+__global__ __launch_bounds__(256) void modraise_kernel(DeviceTables t, u64* out, const u64* src, int src_limb, int nl) {
+    const int v = blockIdx.y;
+    const int p = v / nl, tq = v % nl;
+    const Barrett br = load_barrett(t, tq);
+    const u64 qs = t.moduli[src_limb];
+    const u64 half = qs >> 1;
+    const u64 qsm = barrett_reduce128(qs, 0, br);
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const u64x2 x = reinterpret_cast<const u64x2*>(src)[(size_t)p * row + n2];
+    u64x2 r;
+    r.x = barrett_reduce128(x.x, 0, br);
+    r.y = barrett_reduce128(x.y, 0, br);
+    if (x.x > half) r.x = sub_mod(r.x, qsm, br.q);
+    if (x.y > half) r.y = sub_mod(r.y, qsm, br.q);
+    reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
+}
+
 // K5 step 4: out[p][t] = (c[p][t] - lifted[p][t]) * q_l^{-1}   (c has ell limbs per poly, out ell-1)
 __global__ __launch_bounds__(256) void rescale_finish_kernel(DeviceTables t, u64* out, const u64* c, const u64* lifted, int ell1,
                                                              const u64* qlinv_row) {
@@ -252,6 +272,9 @@ void launch_rescale_lift(const DeviceTables& t, u64* lifted, const u64* last, in
 void launch_rescale_finish(const DeviceTables& t, u64* out, const u64* c, const u64* lifted, int npoly, int ell, const u64* qlinv_row,
                            hipStream_t s) {
     hipLaunchKernelGGL(rescale_finish_kernel, grid2(t.log_n, npoly * (ell - 1)), dim3(256), 0, s, t, out, c, lifted, ell - 1, qlinv_row);
+}
+void launch_modraise(const DeviceTables& t, u64* out, const u64* src, int npoly, int src_limb, int nl, hipStream_t s) {
+    hipLaunchKernelGGL(modraise_kernel, grid2(t.log_n, npoly * nl), dim3(256), 0, s, t, out, src, src_limb, nl);
 }
 void launch_reduce_i128(const DeviceTables& t, u64* out, const u64* coeffs, int limb_first, int nlimbs, hipStream_t s) {
     hipLaunchKernelGGL(reduce_i128_kernel, dim3((1u << t.log_n) / 256, (unsigned)nlimbs), dim3(256), 0, s, t, out, coeffs, limb_first);

@@ -175,6 +175,10 @@ int fhelin_eval_chebyshev(fhelin_ctx* c, const fhelin_ct* x, const double* coeff
 /* CKKS bootstrapping: EvalBootstrapSetup/KeyGen :238-239 and EvalBootstrap :445 */
 int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t level_budget_enc, int32_t level_budget_dec, int32_t slots);
 int fhelin_bootstrap(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);
+/* approximation parameters (before setup): |I| bound K, double-angle count R, cosine-fit degree, message correction 2^-c */
+int fhelin_bootstrap_config(fhelin_ctx* c, int32_t K, int32_t R, int32_t cheb_degree, int32_t correction);
+/* test hook: stop after 1 = ModRaise(+SubSum), 2 = CoeffsToSlots (real part), 3 = approximate mod (real part) */
+int fhelin_bootstrap_partial(fhelin_ctx* c, const fhelin_ct* a, int32_t stage, fhelin_ct** out);
 
 #ifdef __cplusplus
 }

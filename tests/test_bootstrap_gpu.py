@@ -1,0 +1,61 @@
+"""CKKS bootstrapping on the GPU, checked by decryption.
+Stated tolerance: 2e-4 absolute for |m| <= 1 — the sine approximation of the modular reduction contributes
+(2 pi 2^-c |mu|)^2 / 6 relative (c = 10: 6e-6), the degree-47 cosine fit ~1e-10 * 4^R * 2^c = 7e-6, CKKS noise
+of ~25 multiplicative levels the rest."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(fa, log_slots):
+    e = fa.Engine("boot12", seed=77, log_slots=log_slots)
+    e.keygen()
+    e.gen_relin_key()
+    e.bootstrap_setup(3, 3, 1 << log_slots)
+    return e
+
+
+def _coeffs(m):
+    """unscaled plaintext coefficients (mu_lo + i mu_hi) of the slot vector m: w = U^H m / n, U_jk = zeta_j^k"""
+    n = len(m)
+    j = np.arange(n)
+    e5 = np.array([pow(5, int(t), 4 * n) for t in j])
+    U = np.exp(2j * np.pi * np.outer(e5, np.arange(n)) / (4 * n))
+    return U.conj().T @ m / n
+
+
+@pytest.mark.parametrize("log_slots", [10, 11])     # 10: sparse packing (N/4 slots, SubSum path); 11: full packing
+def test_bootstrap_refreshes_levels_and_keeps_message(fa, log_slots):
+    eng = _engine(fa, log_slots)
+    try:
+        n = 1 << log_slots
+        m = np.random.default_rng(3).uniform(-1, 1, n)
+        ct = eng.encrypt(m, level=eng.n_q - 3)               # 3 limbs left: nearly exhausted
+        assert ct.info()["ell"] == 3
+        # stage 2: slots hold t_k / (q0 K) (bit-reversed order) with t = Delta' mu + q0 I
+        a = eng.decrypt(eng.bootstrap_partial(ct, 2))
+        frac = a * 28 - np.round(a * 28)
+        mu = _coeffs(m).real
+        got = np.sort(frac * 2 ** 10)
+        assert np.max(np.abs(got - np.sort(mu))) < 1e-3
+        out = eng.bootstrap(ct)
+        info = out.info()
+        assert info["ell"] >= 4, info                         # strictly more limbs than before
+        err = np.max(np.abs(eng.decrypt(out) - m))
+        assert err < 2e-4, err
+        # the refreshed ciphertext is usable: one more multiplication
+        sq = eng.mult(out, out)
+        assert np.max(np.abs(eng.decrypt(sq) - m * m)) < 1e-3
+    finally:
+        eng.close()
+
+
+def test_bootstrap_requires_setup_and_two_limbs(fa):
+    e = fa.Engine("boot12", seed=1)
+    e.keygen()
+    ct = e.encrypt(np.zeros(4), level=e.n_q - 2)
+    with pytest.raises(fa.FhelinError) as ei:
+        e.bootstrap(ct)
+    assert ei.value.code == 4                                 # EvalBootstrapSetup has not been called
+    e.close()
