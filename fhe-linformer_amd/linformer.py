@@ -1,0 +1,279 @@
+"""Host-side mirror of the reference's encrypted Linformer driver (reference src/main.cpp / src/main_2.cpp):
+`encoder1()`, `pooler()`, `classifier()` with the SAME call sequence against a controller object that exposes
+the reference's FHEController method names.  Two controllers exist: `GpuController` (this file; every operation
+is a C-ABI call into libfhelin_amd.so) and `oracle.circuit_sim.SlotSimController` (plaintext slot vectors, test
+infrastructure).  Text-file I/O of the reference (`read_*`, src/FHEController.cpp:501-698) is replaced by
+in-memory arrays with the same three packing layouts (plain / repeated / expanded).
+
+Nothing here computes on residues: this module only sequences operations (like main.cpp does)."""
+import math
+
+import numpy as np
+
+SLOTS = 16384
+
+
+# ---- offline weight helpers (reference src/python/split_ffn_w1.py:24-37, split_ffn_w2_cols.py:22-29) -------
+def split_transposed_blocks(W0, cols_per_block=128):
+    WT = np.asarray(W0).T                                    # [128, 512]
+    return [WT[:, i:i + cols_per_block] for i in range(0, WT.shape[1], cols_per_block)]
+
+
+def split_col_blocks(W2, cols_per_block=128):
+    W2 = np.asarray(W2)                                       # [128, 512]
+    return [W2[:, i:i + cols_per_block] for i in range(0, W2.shape[1], cols_per_block)]
+
+
+def expanded(v, num_inputs=128):                             # read_expanded_input / read_plain_expanded_input :623-698
+    out = np.zeros(SLOTS)
+    v = np.asarray(v, dtype=np.float64)
+    for j in range(128):
+        out[j * 128: j * 128 + num_inputs] = v[j]
+    return out
+
+
+def repeated(v):                                             # read_plain_repeated_input :582-603
+    return np.tile(np.asarray(v, dtype=np.float64)[:128], 128)
+
+
+def cheb_coeffs(f, a, b, degree):
+    """EvalChebyshevCoefficients (what include/FHEController.h::chebyshev does in C++)"""
+    n = degree + 1
+    j = np.arange(n)
+    nodes = np.cos(np.pi * (j + 0.5) / n)
+    fx = np.array([f(0.5 * (b - a) * t + 0.5 * (b + a)) for t in nodes])
+    return np.array([2.0 / n * np.sum(fx * np.cos(np.pi * k * (j + 0.5) / n)) for k in range(n)])
+
+
+class GpuController:
+    """The reference's FHEController surface on top of fhe_linformer_amd.Engine."""
+
+    def __init__(self, eng, verbose=False):
+        self.e, self.verbose = eng, verbose
+        self.num_slots = SLOTS
+        self.n_boot = 0
+
+    # handles
+    def level(self, c):
+        return c.level
+
+    def clone(self, c):
+        return c.clone()
+
+    # encode / encrypt
+    def encode(self, v, level=0):
+        if np.isscalar(v):
+            v = np.full(SLOTS, float(v))
+        return self.e.encode(np.asarray(v, dtype=np.float64), level, SLOTS)
+
+    def encrypt(self, v, level=0):
+        return self.e.encrypt(np.asarray(v, dtype=np.float64), level, SLOTS)
+
+    def decrypt(self, c):
+        return self.e.decrypt(c, SLOTS)
+
+    def read_expanded_input(self, v, scale=1.0):
+        return self.encrypt(expanded(np.asarray(v) * scale), 0)
+
+    def read_plain_input(self, m, level=0, scale=1.0):
+        return self.encode(np.asarray(m, dtype=np.float64).reshape(-1) * scale, level)
+
+    def read_plain_repeated_input(self, v, level=0, scale=1.0):
+        return self.encode(repeated(v) * scale, level)
+
+    def read_plain_expanded_input(self, v, level=0, scale=1.0):
+        return self.encode(expanded(np.asarray(v) * scale), level)
+
+    # leaf ops
+    def add(self, a, b):
+        return self.e.add(a, b)
+
+    def mult(self, a, b):
+        return self.e.mult_const(a, b) if np.isscalar(b) else self.e.mult(a, b)
+
+    def rotate(self, a, i):
+        return self.e.rotate(a, i)
+
+    def bootstrap(self, a):
+        self.n_boot += 1
+        return self.e.bootstrap(a)
+
+    # composites: same names as the reference
+    def rotsum(self, a, slots, padding):
+        return self.e.rotsum(a, slots, padding)
+
+    def matmulRE(self, rows, w, bias=None, row_size=128, padding=128):
+        return self.e.matmulRE(rows, w, bias, row_size, padding)
+
+    def matmulCR(self, rows, w, bias=None):
+        return self.e.matmulCR(rows, w, bias)
+
+    def matmulRElarge(self, rows, weights, bias, mask_val=1.0):
+        return self.e.matmulRElarge(rows, weights, bias, mask_val)
+
+    def matmulCRlarge(self, rows, weights, bias):
+        return self.e.matmulCRlarge(rows, weights, bias)
+
+    def matmulScores(self, queries, key):
+        return self.e.matmulScores(queries if isinstance(queries, list) else [queries], key)
+
+    def wrapUpRepeated(self, v):
+        return self.e.wrapUpRepeated(v)
+
+    def wrapUpExpanded(self, v):
+        return self.e.wrapUpExpanded(v)
+
+    def unwrapExpanded(self, c, n):
+        return self.e.unwrapExpanded(c, n)
+
+    def unwrapRepeatedLarge(self, cs, n):
+        return self.e.unwrapRepeatedLarge(cs, n)
+
+    def generate_containers(self, inputs, bias=None):
+        return self.e.generate_containers(inputs, bias)
+
+    # activations (reference src/FHEController.cpp:1289-1336)
+    def eval_exp(self, c, inputs_number):
+        res = self.e.eval_poly(c, [1, 1, 1 / 2.0, 1 / 6.0, 1 / 24.0, 1 / 120.0, 1 / 720.0])
+        res = self.e.mult_many([res] * 8)
+        i = np.arange(SLOTS)
+        mask = np.where((i % 128 < inputs_number) & (i < 128 * inputs_number), 0.0, -1.0)
+        return self.e.add(res, self.encode(mask, res.level))
+
+    def _cheb(self, f, c, a, b, degree):
+        return self.e.eval_chebyshev(c, cheb_coeffs(f, a, b, degree), a, b)
+
+    def eval_inverse_naive(self, c, lo, hi):
+        return self._cheb(lambda x: 1.0 / x, c, lo, hi, 119)
+
+    def eval_gelu_function(self, c, lo, hi, mult, degree):
+        return self._cheb(lambda x: 0.5 * (x / mult) * (1 + math.erf((x / mult) / 1.41421356237)), c, lo, hi, degree)
+
+    def eval_tanh_function(self, c, lo, hi, mult, degree):
+        return self._cheb(lambda x: math.tanh(x / mult), c, lo, hi, degree)
+
+
+# ---- the circuit: reference src/main.cpp:145-475 (CLS-query variant, as built) -----------------------------
+def encoder1(ctl, w, x_in, X_E, X_F, trace=None):
+    """x_in [S_total,128] (row 0 = CLS token), X_E / X_F [32,128] (client-side Linformer projections)."""
+    t = trace if trace is not None else {}
+    S = x_in.shape[0]
+    inputs_E = [ctl.read_expanded_input(X_E[i]) for i in range(32)]                         # main.cpp:159-162
+    inputs_F = [ctl.read_expanded_input(X_F[i]) for i in range(32)]                         # :164-167
+    inputs = [ctl.read_expanded_input(x_in[i]) for i in range(S)]                           # :169-173
+
+    query_w = ctl.read_plain_input(w["WQ"].T)                                               # ..._WQ_weight_T.txt :177
+    query_b = ctl.read_plain_repeated_input(w["BQ"])
+    key_w = ctl.read_plain_input(w["WK"].T)
+    key_b = ctl.read_plain_repeated_input(w["BK"])
+    Q = ctl.matmulRE(inputs, query_w, query_b)                                              # :183
+    K = ctl.matmulRE(inputs_E, key_w, key_b)                                                # :184
+    K_wrapped = ctl.wrapUpRepeated(K)                                                       # :186
+    scores = ctl.matmulScores(Q[0], K_wrapped)                                              # :196
+    t["scores"] = scores
+    scores = ctl.eval_exp(scores, 32)                                                       # :197
+    t["exp"] = scores
+    scores_sum = ctl.rotsum(scores, 32, 128)                                                # :201
+    scores_denominator = ctl.eval_inverse_naive(scores_sum, -1, 128)                        # :203
+    scores = ctl.mult(scores, scores_denominator)                                           # :205
+    unwrapped_scores = ctl.unwrapExpanded(scores, 1)                                        # :207
+    value_w = ctl.read_plain_input(w["WV"].T)
+    value_b = ctl.read_plain_repeated_input(w["BV"])
+    V = ctl.matmulRE(inputs_F, value_w, value_b)                                            # :212
+    V_wrapped = ctl.wrapUpRepeated(V)
+    cls_output = ctl.matmulRE(unwrapped_scores, V_wrapped, None, 128, 128)[0]               # :215
+    t["self_attention"] = cls_output
+    output = [cls_output]
+    zero_c = ctl.encrypt(np.zeros(SLOTS), ctl.level(cls_output))                            # :220-221
+    for _ in range(1, S):
+        output.append(ctl.clone(zero_c))
+
+    dense_w = ctl.read_plain_input(w["WO"], ctl.level(output[0]))                           # ..._WO_weight.txt :231
+    dense_b = ctl.read_plain_expanded_input(w["BO"], ctl.level(output[0]) + 1)
+    output = ctl.matmulCR(output, dense_w, None)                                            # :235
+    output[0] = ctl.add(output[0], dense_b)
+    output = [ctl.add(output[i], inputs[i]) for i in range(S)]                              # :237-239
+
+    fL1 = w["c10"] + w["c11"] / math.sqrt(S) + w["c12"] / S                                 # :290-291
+    output_0, output_1 = output[:128], output[128:]                                         # :293-300
+    wrapped_0 = ctl.wrapUpExpanded(output_0)
+    wrapped_1 = ctl.wrapUpExpanded(output_1)
+    a1 = ctl.read_plain_repeated_input(w["a1"], ctl.level(wrapped_0), fL1)
+    b1 = ctl.read_plain_repeated_input(w["b1"], ctl.level(wrapped_0) + 1, fL1)
+    wrapped_0 = ctl.add(ctl.mult(wrapped_0, a1), b1)                                        # :308-311
+    wrapped_1 = ctl.add(ctl.mult(wrapped_1, a1), b1)
+    t["affine1_0"] = wrapped_0
+    wrapped_0 = ctl.bootstrap(wrapped_0)                                                    # :313-314
+    wrapped_1 = ctl.bootstrap(wrapped_1)
+    copy_0, copy_1 = ctl.clone(wrapped_0), ctl.clone(wrapped_1)
+    output_0 = ctl.unwrapExpanded(wrapped_0, 128)                                           # :319-320
+    output_1 = ctl.unwrapExpanded(wrapped_1, S - 128)
+
+    gelu_scale = 1.0 / 8.0                                                                  # :329
+    blocks = split_transposed_blocks(w["Wffn0"])                                            # ffn_W0_transposed_block_k.txt
+    dense_weights = [ctl.read_plain_input(b, ctl.level(wrapped_0), gelu_scale) for b in blocks]
+    inter_bias = ctl.read_plain_input(w["Bffn0"], ctl.level(wrapped_0) + 1, gelu_scale)
+    output_0 = ctl.matmulRElarge(output_0, dense_weights, inter_bias)                       # :341-342
+    output_1 = ctl.matmulRElarge(output_1, dense_weights, inter_bias)
+    outputs_raw = output_0 + output_1
+    outputs = ctl.generate_containers(outputs_raw, None)                                    # :352
+    for i in range(len(outputs)):                                                           # :354-358
+        outputs[i] = ctl.eval_gelu_function(outputs[i], -1, 1, gelu_scale, 119)
+        outputs[i] = ctl.bootstrap(outputs[i])
+    unwrapped_large = ctl.unwrapRepeatedLarge(outputs, S)                                   # :360
+
+    lvl = ctl.level(unwrapped_large[0][0])
+    out_w = [ctl.read_plain_input(b, lvl) for b in split_col_blocks(w["Wffn2"])]            # ffn_W2_block_k.txt :367-370
+    out_bias = ctl.read_plain_expanded_input(w["Bffn2"], lvl + 1)
+    output = ctl.matmulCRlarge(unwrapped_large, out_w, out_bias)                            # :374
+    output_2, output_3 = output[:128], output[128:]
+    wrapped_2 = ctl.add(ctl.wrapUpExpanded(output_2), copy_0)                               # :386-390
+    wrapped_3 = ctl.add(ctl.wrapUpExpanded(output_3), copy_1)
+    S1 = len(output)
+    fL2 = w["c20"] + w["c21"] / math.sqrt(S1) + w["c22"] / S1
+    a2 = ctl.read_plain_repeated_input(w["a2"], ctl.level(wrapped_2), fL2)
+    b2 = ctl.read_plain_repeated_input(w["b2"], ctl.level(wrapped_3) + 1, fL2)
+    wrapped_2 = ctl.add(ctl.mult(wrapped_2, a2), b2)                                        # :404-408
+    wrapped_3 = ctl.add(ctl.mult(wrapped_3, a2), b2)
+    output_2 = ctl.unwrapExpanded(wrapped_2, 128)                                           # :410-411
+    output_3 = ctl.unwrapExpanded(wrapped_3, S - 128)
+    t["encoder_out"] = output_2[0]
+    return output_2[0]
+
+
+def pooler(ctl, w, x, trace=None):                                                          # main.cpp:427-451
+    tanh_scale = 1.0 / 50
+    weight = ctl.read_plain_input(w["Wp"].T, ctl.level(x), tanh_scale)                      # pooler_dense_weight_T.txt
+    bias = ctl.read_plain_repeated_input(w["bp"], ctl.level(x) + 1, tanh_scale)
+    out = ctl.mult(x, weight)
+    out = ctl.rotsum(out, 128, 128)
+    out = ctl.add(out, bias)
+    out = ctl.bootstrap(out)
+    out = ctl.eval_tanh_function(out, -1, 1, tanh_scale, 300)
+    if trace is not None:
+        trace["pooled"] = out
+    return out
+
+
+def classifier(ctl, w, x):                                                                  # main.cpp:453-475
+    fc = np.zeros((128, 128))
+    fc[:20] = w["fc_w"]                                                                     # fcLinear_0_weight.txt: 20 rows
+    weight = ctl.read_plain_input(fc, ctl.level(x))
+    bias = ctl.read_plain_expanded_input(np.concatenate([w["fc_b"], np.zeros(108)]), ctl.level(x))
+    out = ctl.mult(x, weight)
+    out = ctl.rotsum(out, 128, 1)
+    out = ctl.add(out, bias)
+    mask = np.zeros(SLOTS)
+    mask[np.arange(20) * 128] = 1
+    return ctl.mult(out, ctl.encrypt(mask, ctl.level(out)))                                 # encrypted mask (quirk Q8)
+
+
+def forward(ctl, w, x_in, X_E, X_F, trace=None):
+    """one sample: encoder1 -> pooler -> classifier -> logits at slots {0,128,...,19*128} (main.cpp:105-123)"""
+    enc = encoder1(ctl, w, x_in, X_E, X_F, trace)
+    cls = classifier(ctl, w, pooler(ctl, w, enc, trace))
+    return cls
+
+
+def logits_from_slots(v):
+    return np.asarray(v)[np.arange(20) * 128]

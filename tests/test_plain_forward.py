@@ -1,0 +1,59 @@
+"""The float-level application oracle (oracle/plain_forward.py) is pinned by golden vectors produced by the
+reference's own compute_simple.main() (tests/golden/make_golden.py).  The reference computes in float32, hence
+the 2e-4 relative tolerance; the prediction must match exactly."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _golden():
+    return json.load(open(os.path.join(HERE, "golden", "plain_forward_s129.json")))
+
+
+def test_plain_forward_matches_reference_golden():
+    from oracle import plain_forward as pf
+    g = _golden()
+    w = pf.synthetic_model(g["weights_seed"])
+    x = pf.synthetic_tokens(g["S"], g["tokens_seed"])
+    for dtype, tol in ((np.float32, 2e-5), (np.float64, 2e-4)):
+        r = pf.plain_forward(w, x, dtype=dtype)
+        for key, mine in (("Q[0]", r["Q0"]), ("logits", r["logits"]), ("x", r["x"]), ("exp_approx", r["exp_approx"]),
+                          ("self-attention", r["self_attention"])):
+            ref = np.array(g[key])
+            assert np.allclose(np.asarray(mine, dtype=np.float64).reshape(-1), ref, rtol=tol, atol=tol), key
+        assert np.allclose(np.asarray(r["K"], dtype=np.float64).reshape(-1)[:256], np.array(g["K"]), rtol=tol, atol=tol)
+        yp = np.array(g["y_prob"])
+        assert np.allclose(np.asarray(r["y_prob"], dtype=np.float64), yp, rtol=10 * tol, atol=tol)
+        assert r["pred"] == g["Pred"]
+
+
+def test_circuit_model_agrees_with_plain_model_on_prediction():
+    """the polynomial stand-ins of the encrypted circuit (Taylor^8 exp, Chebyshev 1/x, erf-GELU, tanh) change the
+    logits only slightly on the synthetic model: same argmax, logits within 0.05."""
+    from oracle import plain_forward as pf
+    g = _golden()
+    w = pf.synthetic_model(g["weights_seed"])
+    x = pf.synthetic_tokens(g["S"], g["tokens_seed"])
+    p = pf.plain_forward(w, x)
+    c = pf.fhe_circuit_model(w, x)
+    assert c["pred"] == p["pred"] == g["Pred"]
+    assert np.max(np.abs(c["y_logit_cls"] - p["y_logit_cls"])) < 0.05
+    assert c["gelu_in_max"] < 1.0                      # GELU Chebyshev domain [-1,1] is respected
+    assert np.all(np.abs(c["scores"]) < 1.0) and 1.0 < c["exp"].sum() < 128.0
+    assert np.max(np.abs(c["x_norm0_cls"])) < 2.0      # bootstrapping input range (|m| well inside q0/2^correction K)
+
+
+def test_helper_scripts_layouts():
+    """output layouts of the reference's offline weight splitters (split_ffn_w1.py:24-37, split_ffn_w2_cols.py:22-29)
+    as the driver consumes them: W0^T [128,512] -> 4 blocks [128,128]; W2 [128,512] -> 4 column blocks."""
+    from fhe_linformer_amd import linformer as lf
+    rng = np.random.default_rng(0)
+    W0, W2 = rng.normal(size=(512, 128)), rng.normal(size=(128, 512))
+    b0 = lf.split_transposed_blocks(W0)
+    assert len(b0) == 4 and all(b.shape == (128, 128) for b in b0)
+    assert np.array_equal(np.hstack(b0), W0.T)
+    b2 = lf.split_col_blocks(W2)
+    assert len(b2) == 4 and np.array_equal(np.hstack(b2), W2)

@@ -1,0 +1,22 @@
+"""Probe: bootstrapping at a given preset — precision, levels, wall time (not a test; used to fill DESIGN.md)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import fhe_linformer_amd as fa
+
+preset = sys.argv[1] if len(sys.argv) > 1 else "bench"
+kw = {}
+if len(sys.argv) > 2:
+    kw["n_q"] = int(sys.argv[2])
+e = fa.Engine(preset, seed=5, **kw)
+t0 = time.time(); e.keygen(); e.gen_relin_key(); print("keygen s", round(time.time() - t0, 2))
+t0 = time.time(); e.bootstrap_setup(3, 3, 1 << e.params.log_slots); print("setup s", round(time.time() - t0, 2))
+n = 1 << e.params.log_slots
+m = np.random.default_rng(1).uniform(-1, 1, n)
+ct = e.encrypt(m, level=e.n_q - 3)
+for it in range(3):
+    e.sync(); t0 = time.time()
+    out = e.bootstrap(ct)
+    e.sync(); dt = time.time() - t0
+    err = np.max(np.abs(e.decrypt(out) - m))
+    print(f"bootstrap {it}: {dt*1e3:.1f} ms, out {out.info()}, max err {err:.3e}")
