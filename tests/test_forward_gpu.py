@@ -1,0 +1,42 @@
+"""End-to-end: one encrypted Linformer-d128 forward pass (driver fhe-linformer_amd/linformer.py, the call
+sequence of reference src/main.cpp:145-475 incl. 8 bootstraps) on the GPU at the reference's parameters
+(N=2^15, 16384 slots, dnum 4, 29+8 limbs: depth 27 + 1 because this engine's bootstrap uses 15 levels instead
+of OpenFHE's 14), compared by decryption with the SAME operation sequence executed in the clear
+(oracle/circuit_sim.py).  Tolerances (stated): intermediates before the first bootstrap 1e-8; after
+bootstrapping 1e-4 (bootstrap precision ~2e-5); the degree-300 tanh amplifies that to <= 5e-3 on the logits.
+The arg-max class must be identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_encrypted_forward_matches_plaintext_circuit(fa):
+    from fhe_linformer_amd import linformer as lf
+    from oracle import plain_forward as pf, circuit_sim as cs
+    S = 129
+    w = pf.synthetic_model(1234)
+    x = pf.synthetic_tokens(S, 4321)
+    x_in, X_E, X_F = pf.client_inputs(w, x)
+    sim, st = cs.SlotSimController(), {}
+    ref = lf.forward(sim, w, x_in, X_E, X_F, st)
+
+    eng = fa.Engine("reference", seed=11, n_q=29, n_p=8)
+    try:
+        eng.keygen()
+        eng.gen_relin_key()
+        eng.gen_rotation_keys(sorted(set([2 ** i for i in range(14)] + [-(2 ** i) for i in range(14)])))
+        eng.bootstrap_setup(3, 3, 16384)
+        ctl, tr = lf.GpuController(eng), {}
+        out = lf.forward(ctl, w, x_in, X_E, X_F, tr)
+        assert ctl.n_boot == sim.n_boot == 8                   # 2 (affine-1) + 5 (GELU containers) + 1 (pooler)
+        tol = {"scores": 1e-8, "exp": 1e-8, "self_attention": 1e-8, "affine1_0": 1e-8, "encoder_out": 1e-4, "pooled": 5e-3}
+        for k, t in tol.items():
+            err = np.max(np.abs(eng.decrypt(tr[k]) - st[k]))
+            assert err < t, (k, err)
+        lg, lr = lf.logits_from_slots(eng.decrypt(out)), lf.logits_from_slots(ref)
+        assert np.max(np.abs(lg - lr)) < 2e-2
+        assert int(np.argmax(lg)) == int(np.argmax(lr))
+        assert out.info()["ell"] >= 2
+    finally:
+        eng.close()
