@@ -69,6 +69,7 @@ def load_library():
         "fhelin_dev_download": (i32, [vp, vp, vp, C.c_size_t]),
         "fhelin_ntt": (i32, [vp, vp, i32, i32, i32, i32]),
         "fhelin_microbench": (i32, [vp, i32, i32, i32, f32p]),
+        "fhelin_stats": (i32, [vp, u64p, i32, i32]),
         "fhelin_keygen": (i32, [vp]),
         "fhelin_gen_relin_key": (i32, [vp]),
         "fhelin_gen_rotation_keys": (i32, [vp, C.POINTER(i32), i32]),
@@ -234,6 +235,12 @@ class Engine:
         if limb_count is None:
             limb_count = self.n_q
         self._ck(self.lib.fhelin_ntt(self.h, buf.ptr, nvec, limb_first, limb_count, 1 if inverse else 0))
+
+    def stats(self, reset=False):
+        out = np.zeros(7, dtype=np.uint64)
+        self._ck(self.lib.fhelin_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), 7, 1 if reset else 0))
+        keys = ["limb_ntt", "keyswitch", "keyswitch_limbs", "rescale", "ct_pt_mult", "bootstrap", "encode"]
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def microbench(self, variant, iters=4096, blocks=2048):
         ms = C.c_float()

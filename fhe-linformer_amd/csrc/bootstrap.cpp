@@ -242,10 +242,11 @@ CtPtr Bootstrapper::mod_raise(const CtPtr& ct, long double& rho) {
     hipStream_t s = c.stream;
     u64* coef = c.dalloc<u64>(2 * N);
     hip_check(hipMemcpyAsync(coef, x->d, 2 * N * 8, hipMemcpyDeviceToDevice, s), "modraise copy");
-    launch_ntt(c.dt, LimbBatch{coef, 2, nullptr, 0, 1}, true, s);
+    c.stats.bootstrap += 1;
+    c.ntt(LimbBatch{coef, 2, nullptr, 0, 1}, true);
     CtPtr up = ev_.new_ct(2, L1, 1, c.sf_real[0], slots_);
     launch_modraise(c.dt, up->d, coef, 2, 0, L1, s);
-    launch_ntt(c.dt, LimbBatch{up->d, 2 * L1, nullptr, 0, L1}, false, s);
+    c.ntt(LimbBatch{up->d, 2 * L1, nullptr, 0, L1}, false);
     hip_check(hipGetLastError(), "modraise");
     c.pool.free(coef);
     // SubSum: project onto the subring of X^{N/(2 slots)} (sparse packing)

@@ -164,9 +164,24 @@ int fhelin_ntt(fhelin_ctx* c, uint64_t* d_data, int32_t nvec, int32_t limb_first
     if (nvec < 0 || limb_count < 1 || limb_first < 0 || limb_first + limb_count > (int)x.moduli.size())
         throw Error(FHELIN_ERR_ARG, "fhelin_ntt: limb range outside the context's moduli");
     LimbBatch b{d_data, nvec, nullptr, limb_first, limb_count};
-    launch_ntt(x.dt, b, inverse != 0, x.stream);
+    x.ntt(b, inverse != 0);
     hip_check(hipGetLastError(), "launch_ntt");
     FHELIN_CATCH
+}
+
+int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset) {
+    if (!c || !out) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    if (cap < 7) return capi_fail(FHELIN_ERR_ARG, "need room for 7 counters");
+    OpStats& s = c->ctx.stats;
+    out[0] = s.limb_ntt;
+    out[1] = s.keyswitch;
+    out[2] = s.keyswitch_limbs;
+    out[3] = s.rescale;
+    out[4] = s.ct_pt_mult;
+    out[5] = s.bootstrap;
+    out[6] = s.encode;
+    if (reset) s = OpStats();
+    return FHELIN_OK;
 }
 
 int fhelin_microbench(fhelin_ctx* c, int32_t variant, int32_t iters, int32_t blocks, float* ms) {

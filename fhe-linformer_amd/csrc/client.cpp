@@ -176,7 +176,8 @@ std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>
     e->scale = scale;
     e->d = c.dalloc<u64>((size_t)ell * N);
     launch_reduce_i128(c.dt, e->d, dco, 0, ell, c.stream);
-    launch_ntt(c.dt, LimbBatch{e->d, ell, nullptr, 0, ell}, false, c.stream);
+    c.stats.encode += 1;
+    c.ntt(LimbBatch{e->d, ell, nullptr, 0, ell}, false);
     hip_check(hipGetLastError(), "encode kernels");
     c.pool.free(dco);
     return e;
@@ -391,7 +392,7 @@ std::vector<double> Client::decrypt(const CtPtr& cin, int slots) {
         launch_ew_muladd(c_.dt, m, m, ct->d + 2 * pn, s2, nl, nl, 0, nl, c_.stream);
         c_.pool.free(s2);
     }
-    launch_ntt(c_.dt, LimbBatch{m, nl, nullptr, 0, nl}, true, c_.stream);
+    c_.ntt(LimbBatch{m, nl, nullptr, 0, nl}, true);
     std::vector<u64> h((size_t)nl * N);
     hip_check(hipMemcpyAsync(h.data(), m, h.size() * 8, hipMemcpyDeviceToHost, c_.stream), "decrypt download");
     hip_check(hipStreamSynchronize(c_.stream), "decrypt sync");

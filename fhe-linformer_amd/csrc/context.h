@@ -63,8 +63,20 @@ struct LevelTables {
     const int* ext_limb_tab = nullptr;  // [beta*(ell+k)] limb id for the NTT after ModUp, -1 on own-digit slots
 };
 
+// host-side operation counters (bench.py scales the CPU baseline sample with these)
+struct OpStats {
+    u64 limb_ntt = 0;      // limb vectors transformed (forward + inverse)
+    u64 keyswitch = 0;     // hybrid key switches (rotations + relinearisations)
+    u64 keyswitch_limbs = 0;  // sum of live Q limbs over those key switches
+    u64 rescale = 0;
+    u64 ct_pt_mult = 0;
+    u64 bootstrap = 0;
+    u64 encode = 0;
+};
+
 struct Context {
     Params prm;
+    OpStats stats;
     int N = 0;
     int L = 0;       // n_q - 1
     int K = 0;       // n_p
@@ -106,6 +118,11 @@ struct Context {
     u64 galois_element(int rot_index) const;       // 5^r mod 2N (r may be negative)
     const u32* automorph_map(u64 galois);          // device map for the NTT-domain permutation
     void sync();
+    // K1 launch + accounting (active = vectors actually transformed, for tables with skipped entries)
+    void ntt(const LimbBatch& b, bool inverse, int active = -1) {
+        stats.limb_ntt += (u64)(active >= 0 ? active : b.nvec);
+        launch_ntt(dt, b, inverse, stream);
+    }
 };
 
 }  // namespace fhelin

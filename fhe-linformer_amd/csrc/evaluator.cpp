@@ -63,17 +63,19 @@ void Evaluator::keyswitch(const u64* c_ntt, int ell, const EvalKey& key, u64* ou
     hipStream_t s = c_.stream;
     u64* cc = c_.dalloc<u64>((size_t)ell * N);
     hip_check(hipMemcpyAsync(cc, c_ntt, (size_t)ell * N * 8, hipMemcpyDeviceToDevice, s), "ks copy");
-    launch_ntt(c_.dt, LimbBatch{cc, ell, nullptr, 0, ell}, true, s);
+    c_.stats.keyswitch += 1;
+    c_.stats.keyswitch_limbs += (u64)ell;
+    c_.ntt(LimbBatch{cc, ell, nullptr, 0, ell}, true);
     u64* ext = c_.dalloc<u64>((size_t)lt.beta * (ell + K) * N);
     launch_modup_conv(c_.dt, sh, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod, s);
-    launch_ntt(c_.dt, LimbBatch{ext, lt.beta * (ell + K), lt.ext_limb_tab, 0, 1}, false, s);
+    c_.ntt(LimbBatch{ext, lt.beta * (ell + K), lt.ext_limb_tab, 0, 1}, false, lt.beta * (ell + K) - ell);
     u64* accQ = c_.dalloc<u64>((size_t)2 * ell * N);
     u64* accP = c_.dalloc<u64>((size_t)2 * K * N);
     launch_ks_inner(c_.dt, sh, accQ, accP, ext, key.d, s);
-    launch_ntt(c_.dt, LimbBatch{accP, 2 * K, nullptr, L1, K}, true, s);
+    c_.ntt(LimbBatch{accP, 2 * K, nullptr, L1, K}, true);
     u64* conv = c_.dalloc<u64>((size_t)2 * ell * N);
     launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
-    launch_ntt(c_.dt, LimbBatch{conv, 2 * ell, nullptr, 0, ell}, false, s);
+    c_.ntt(LimbBatch{conv, 2 * ell, nullptr, 0, ell}, false);
     launch_moddown_finish(c_.dt, sh, out, accQ, conv, c_.d_pinv, add0, add1, map, s);
     launch_ok("keyswitch");
     c_.pool.free(cc);
@@ -92,10 +94,11 @@ CtPtr Evaluator::raw_rescale(const CtPtr& a) {
     u64* last = c_.dalloc<u64>((size_t)P * N);
     for (int p = 0; p < P; ++p)
         hip_check(hipMemcpyAsync(last + p * N, a->d + ((size_t)p * ell + ell - 1) * N, N * 8, hipMemcpyDeviceToDevice, s), "rescale copy");
-    launch_ntt(c_.dt, LimbBatch{last, P, nullptr, ell - 1, 1}, true, s);
+    c_.stats.rescale += 1;
+    c_.ntt(LimbBatch{last, P, nullptr, ell - 1, 1}, true);
     u64* lifted = c_.dalloc<u64>((size_t)P * (ell - 1) * N);
     launch_rescale_lift(c_.dt, lifted, last, P, ell, c_.d_qlmod + (size_t)(ell - 1) * (c_.L + 1), s);
-    launch_ntt(c_.dt, LimbBatch{lifted, P * (ell - 1), nullptr, 0, ell - 1}, false, s);
+    c_.ntt(LimbBatch{lifted, P * (ell - 1), nullptr, 0, ell - 1}, false);
     CtPtr o = new_ct(P, ell - 1, a->deg, a->scale, a->slots);
     launch_rescale_finish(c_.dt, o->d, a->d, lifted, P, ell, c_.d_qlinv + (size_t)(ell - 1) * (c_.L + 1) * 2, s);
     launch_ok("rescale");
@@ -241,6 +244,7 @@ CtPtr Evaluator::mult_plain(const CtPtr& a, const PtPtr& p) {
     auto enc = p->at(x->ell, c_.sf_real[x->level()]);
     CtPtr o = new_ct(x->npoly, x->ell, x->deg + 1, x->scale * enc->scale, x->slots);
     launch_ew_mul(c_.dt, o->d, x->d, enc->d, x->npoly * x->ell, x->ell, 0, x->ell, c_.stream);
+    c_.stats.ct_pt_mult += 1;
     launch_ok("mult_plain");
     return o;
 }

@@ -154,13 +154,17 @@ class GpuController:
 
 
 # ---- the circuit: reference src/main.cpp:145-475 (CLS-query variant, as built) -----------------------------
-def encoder1(ctl, w, x_in, X_E, X_F, trace=None):
-    """x_in [S_total,128] (row 0 = CLS token), X_E / X_F [32,128] (client-side Linformer projections)."""
+def encrypt_inputs(ctl, x_in, X_E, X_F):
+    """client side (main.cpp:159-173): x_in [S_total,128] (row 0 = CLS token), X_E / X_F [32,128] (Linformer projections)"""
+    return {"inputs_E": [ctl.read_expanded_input(X_E[i]) for i in range(32)],               # main.cpp:159-162
+            "inputs_F": [ctl.read_expanded_input(X_F[i]) for i in range(32)],               # :164-167
+            "inputs": [ctl.read_expanded_input(x_in[i]) for i in range(x_in.shape[0])]}     # :169-173
+
+
+def encoder1(ctl, w, enc, trace=None):
     t = trace if trace is not None else {}
-    S = x_in.shape[0]
-    inputs_E = [ctl.read_expanded_input(X_E[i]) for i in range(32)]                         # main.cpp:159-162
-    inputs_F = [ctl.read_expanded_input(X_F[i]) for i in range(32)]                         # :164-167
-    inputs = [ctl.read_expanded_input(x_in[i]) for i in range(S)]                           # :169-173
+    inputs_E, inputs_F, inputs = enc["inputs_E"], enc["inputs_F"], enc["inputs"]
+    S = len(inputs)
 
     query_w = ctl.read_plain_input(w["WQ"].T)                                               # ..._WQ_weight_T.txt :177
     query_b = ctl.read_plain_repeated_input(w["BQ"])
@@ -268,11 +272,14 @@ def classifier(ctl, w, x):                                                      
     return ctl.mult(out, ctl.encrypt(mask, ctl.level(out)))                                 # encrypted mask (quirk Q8)
 
 
+def forward_encrypted(ctl, w, enc, trace=None):
+    """server side of one sample: encoder1 -> pooler -> classifier -> logits at slots {0,128,...,19*128} (main.cpp:105-123)"""
+    out = encoder1(ctl, w, enc, trace)
+    return classifier(ctl, w, pooler(ctl, w, out, trace))
+
+
 def forward(ctl, w, x_in, X_E, X_F, trace=None):
-    """one sample: encoder1 -> pooler -> classifier -> logits at slots {0,128,...,19*128} (main.cpp:105-123)"""
-    enc = encoder1(ctl, w, x_in, X_E, X_F, trace)
-    cls = classifier(ctl, w, pooler(ctl, w, enc, trace))
-    return cls
+    return forward_encrypted(ctl, w, encrypt_inputs(ctl, x_in, X_E, X_F), trace)
 
 
 def logits_from_slots(v):

@@ -81,6 +81,10 @@ int fhelin_dev_download(fhelin_ctx* c, void* dst, const void* src, size_t bytes)
  * limb_first + (v % limb_count).  Stands in for DCRTPoly::SetFormat inside OpenFHE. */
 int fhelin_ntt(fhelin_ctx* c, uint64_t* d_data, int32_t nvec, int32_t limb_first, int32_t limb_count, int32_t inverse);
 
+/* host-side operation counters since the last reset: [0] limb-NTTs, [1] key switches, [2] sum of live limbs over
+ * key switches, [3] rescales, [4] ct x pt products, [5] bootstraps, [6] plaintext encodes */
+int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset);
+
 /* instruction-rate probe (bench.py --micro): variant 0..7, see csrc/kernels_micro.hip */
 int fhelin_microbench(fhelin_ctx* c, int32_t variant, int32_t iters, int32_t blocks, float* ms);
 
