@@ -100,19 +100,19 @@ static int log_steps(int slots) {
 }
 
 CtPtr Composite::rotsum(const CtPtr& in, int slots, int padding) {
-    CtPtr r = ev_.clone(in);
+    CtPtr r = in;  // handles are immutable: no Clone() needed before the first step
     const int n = log_steps(slots);
-    for (int i = 0; i < n; ++i) r = ev_.add(r, ev_.rotate(r, padding * (1 << i)));
-    return r;
+    for (int i = 0; i < n; ++i) r = ev_.rotate_add(r, padding * (1 << i));
+    return n ? r : ev_.clone(in);
 }
 
 CtPtr Composite::rotsum_padded(const CtPtr& in, int slots) { return rotsum(in, slots, slots); }
 
 CtPtr Composite::repeat(const CtPtr& in, int slots, int padding) {
-    CtPtr r = ev_.clone(in);
+    CtPtr r = in;
     const int n = log_steps(slots);
-    for (int i = 0; i < n; ++i) r = ev_.add(r, ev_.rotate(r, padding * -(1 << i)));
-    return r;
+    for (int i = 0; i < n; ++i) r = ev_.rotate_add(r, padding * -(1 << i));
+    return n ? r : ev_.clone(in);
 }
 
 CtPtr Composite::add_many(const CtVec& v) {

@@ -53,7 +53,7 @@ KeyPtr Evaluator::new_key() {
 
 // ------------------------------------------------------------------------------------------------
 void Evaluator::keyswitch(const u64* c_ntt, int ell, const EvalKey& key, u64* out, const u64* add0, const u64* add1,
-                          const u32* map) {
+                          const u32* map, const u64* post) {
     c_.require_device();
     if (c_.K < 1) throw Error(FHELIN_ERR_STATE, "hybrid key switching needs at least one special prime");
     const size_t N = c_.N;
@@ -62,10 +62,9 @@ void Evaluator::keyswitch(const u64* c_ntt, int ell, const EvalKey& key, u64* ou
     KsShape sh{ell, K, c_.alpha, lt.beta, L1};
     hipStream_t s = c_.stream;
     u64* cc = c_.dalloc<u64>((size_t)ell * N);
-    hip_check(hipMemcpyAsync(cc, c_ntt, (size_t)ell * N * 8, hipMemcpyDeviceToDevice, s), "ks copy");
     c_.stats.keyswitch += 1;
     c_.stats.keyswitch_limbs += (u64)ell;
-    c_.ntt(LimbBatch{cc, ell, nullptr, 0, ell}, true);
+    c_.ntt(LimbBatch{cc, ell, nullptr, 0, ell, c_ntt}, true);  // out of place: cc = INTT(c)
     u64* ext = c_.dalloc<u64>((size_t)lt.beta * (ell + K) * N);
     launch_modup_conv(c_.dt, sh, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod, s);
     c_.ntt(LimbBatch{ext, lt.beta * (ell + K), lt.ext_limb_tab, 0, 1}, false, lt.beta * (ell + K) - ell);
@@ -76,7 +75,7 @@ void Evaluator::keyswitch(const u64* c_ntt, int ell, const EvalKey& key, u64* ou
     u64* conv = c_.dalloc<u64>((size_t)2 * ell * N);
     launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
     c_.ntt(LimbBatch{conv, 2 * ell, nullptr, 0, ell}, false);
-    launch_moddown_finish(c_.dt, sh, out, accQ, conv, c_.d_pinv, add0, add1, map, s);
+    launch_moddown_finish(c_.dt, sh, out, accQ, conv, c_.d_pinv, add0, add1, map, post, s);
     launch_ok("keyswitch");
     c_.pool.free(cc);
     c_.pool.free(ext);
@@ -107,12 +106,23 @@ CtPtr Evaluator::raw_rescale(const CtPtr& a) {
     return o;
 }
 
-CtPtr Evaluator::raw_rotate(const CtPtr& a, u64 g, const EvalKey& key) {
+CtPtr Evaluator::raw_rotate(const CtPtr& a, u64 g, const EvalKey& key, bool accumulate) {
     if (a->npoly != 2) throw Error(FHELIN_ERR_STATE, "rotate: ciphertext must have 2 components");
     const size_t pn = (size_t)a->ell * c_.N;
     CtPtr o = new_ct(2, a->ell, a->deg, a->scale, a->slots);
-    keyswitch(a->d + pn, a->ell, key, o->d, a->d, nullptr, c_.automorph_map(g));
+    // accumulate: out = a + rot(a) — the addition of the rotate-and-sum step rides in the ModDown epilogue
+    keyswitch(a->d + pn, a->ell, key, o->d, a->d, nullptr, c_.automorph_map(g), accumulate ? a->d : nullptr);
     return o;
+}
+
+CtPtr Evaluator::rotate_add(const CtPtr& a, int index) {
+    const int ns = a->slots > 0 ? a->slots : (1 << c_.prm.log_slots);
+    if (index % ns == 0) return add(a, a);
+    const u64 g = c_.galois_element(index);
+    auto it = rot_keys.find(g);
+    if (it == rot_keys.end())
+        throw Error(FHELIN_ERR_KEY, "no rotation key for index " + std::to_string(index) + " (EvalRotateKeyGen list)");
+    return raw_rotate(a, g, *it->second, true);
 }
 
 CtPtr Evaluator::raw_mult_relin(const CtPtr& a, const CtPtr& b, const EvalKey& key) {

@@ -72,7 +72,8 @@ public:
     KeyPtr conj_key;
 
     // ---- K6-K8 composite: out[2][ell][N] = KeySwitch(c) (+ add0/add1, gathered through map if given)
-    void keyswitch(const u64* c_ntt, int ell, const EvalKey& key, u64* out, const u64* add0, const u64* add1, const u32* map);
+    void keyswitch(const u64* c_ntt, int ell, const EvalKey& key, u64* out, const u64* add0, const u64* add1, const u32* map,
+                   const u64* post = nullptr);
 
     // ---- leveled ops (functional: inputs are never modified)
     CtPtr add(const CtPtr& a, const CtPtr& b);
@@ -99,7 +100,8 @@ public:
 
     // raw, no bookkeeping (parity tests): exactly the residue functions of the oracle
     CtPtr raw_rescale(const CtPtr& a);
-    CtPtr raw_rotate(const CtPtr& a, u64 galois, const EvalKey& key);
+    CtPtr raw_rotate(const CtPtr& a, u64 galois, const EvalKey& key, bool accumulate = false);
+    CtPtr rotate_add(const CtPtr& a, int index);            // a + rot(a, index), one fused key switch (rotsum step :833)
     CtPtr raw_mult_relin(const CtPtr& a, const CtPtr& b, const EvalKey& key);
 
 private:

@@ -18,6 +18,7 @@ struct LimbBatch {
     const int* limb_tab;  // device pointer or nullptr
     int limb_first;
     int limb_count;
+    const u64* src = nullptr;  // optional: read the input from src[v][N] (out of place), results land in data
 };
 
 // Device-resident per-context tables.

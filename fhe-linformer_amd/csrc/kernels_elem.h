@@ -43,8 +43,8 @@ void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* a
 // K8a: accP coefficient form [2][k][N] -> conv [2][ell][N] (coefficient form)
 void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
                          hipStream_t s);
-// K8b: out[c][t][j] = (accQ[c][t][m] - conv[c][t][m]) * P^{-1} + add_c[t][m],  m = map ? map[j] : j
+// K8b: out[c][t][j] = (accQ[c][t][m] - conv[c][t][m]) * P^{-1} + add_c[t][m] (+ post[c][t][j]),  m = map ? map[j] : j
 void launch_moddown_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* pinv,
-                           const u64* add0, const u64* add1, const u32* map, hipStream_t s);
+                           const u64* add0, const u64* add1, const u32* map, const u64* post, hipStream_t s);
 
 }  // namespace fhelin

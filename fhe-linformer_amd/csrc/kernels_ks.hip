@@ -27,7 +27,9 @@ __device__ __forceinline__ Barrett load_barrett(const DeviceTables& t, int limb)
     return b;
 }
 
-// grid (N/256, beta)
+constexpr int TCH = 4;  // targets per block: (ell+k)/TCH blocks in z keep >2000 workgroups in flight at every level
+
+// grid (N/256, beta, ceil((ell+k)/TCH))
 template <int MAXA>
 __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape sh, u64* ext, const u64* cc, const u64* c_ntt,
                                                          const u64* hatinv, const u64* hatmod) {
@@ -48,7 +50,8 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
         }
     }
     u64* dst = ext + (size_t)j * nt * N + n;
-    for (int tt = 0; tt < nt; ++tt) {
+    const int t0 = blockIdx.z * TCH, t1 = min(nt, t0 + TCH);
+    for (int tt = t0; tt < t1; ++tt) {
         if (tt >= lo && tt < lo + cnt) {
             dst[(size_t)tt * N] = c_ntt[(size_t)tt * N + n];
             continue;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
     }
 }
 
-// grid (N/256, 2)
+// grid (N/256, 2, ceil(ell/TCH))
 template <int MAXK>
 __global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsShape sh, u64* conv, const u64* accP, const u64* phatinv,
                                                            const u64* phatmod) {
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsSha
         }
     }
     u64* dst = conv + (size_t)c * sh.ell * N + n;
-    for (int tt = 0; tt < sh.ell; ++tt) {
+    const int t0 = blockIdx.z * TCH, t1 = min(sh.ell, t0 + TCH);
+    for (int tt = t0; tt < t1; ++tt) {
         const Barrett br = load_barrett(t, tt);
         Acc128 acc = {0, 0};
 #pragma unroll
@@ -131,7 +135,8 @@ __global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsSha
 
 // grid (N/512, 2*ell)
 __global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsShape sh, u64* out, const u64* accQ, const u64* conv,
-                                                             const u64* pinv, const u64* add0, const u64* add1, const u32* map) {
+                                                             const u64* pinv, const u64* add0, const u64* add1, const u32* map,
+                                                             const u64* post) {
     const int v = blockIdx.y;
     const int c = v / sh.ell, tt = v % sh.ell;
     const u64 q = t.moduli[tt];
@@ -159,6 +164,11 @@ __global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsS
             r.y = add_mod(r.y, d.y, q);
         }
     }
+    if (post) {
+        const u64x2 p = reinterpret_cast<const u64x2*>(post)[((size_t)v * N + j) >> 1];
+        r.x = add_mod(r.x, p.x, q);
+        r.y = add_mod(r.y, p.y, q);
+    }
     reinterpret_cast<u64x2*>(out)[((size_t)v * N + j) >> 1] = r;
 }
 
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsS
 
 void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const u64* cc, const u64* c_ntt, const u64* hatinv,
                        const u64* hatmod, hipStream_t s) {
-    dim3 g((1u << t.log_n) / 256, (unsigned)sh.beta);
+    dim3 g((1u << t.log_n) / 256, (unsigned)sh.beta, (unsigned)((sh.ell + sh.k + TCH - 1) / TCH));
     if (sh.alpha <= 4)
         hipLaunchKernelGGL((modup_conv_kernel<4>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod);
     else if (sh.alpha <= 8)
@@ -180,16 +190,16 @@ void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* a
 }
 void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
                          hipStream_t s) {
-    dim3 g((1u << t.log_n) / 256, 2);
+    dim3 g((1u << t.log_n) / 256, 2, (unsigned)((sh.ell + TCH - 1) / TCH));
     if (sh.k <= 8)
         hipLaunchKernelGGL((moddown_conv_kernel<8>), g, dim3(256), 0, s, t, sh, conv, accP, phatinv, phatmod);
     else
         hipLaunchKernelGGL((moddown_conv_kernel<16>), g, dim3(256), 0, s, t, sh, conv, accP, phatinv, phatmod);
 }
 void launch_moddown_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* pinv,
-                           const u64* add0, const u64* add1, const u32* map, hipStream_t s) {
+                           const u64* add0, const u64* add1, const u32* map, const u64* post, hipStream_t s) {
     dim3 g((1u << t.log_n) / 512, (unsigned)(2 * sh.ell));
-    hipLaunchKernelGGL(moddown_finish_kernel, g, dim3(256), 0, s, t, sh, out, accQ, conv, pinv, add0, add1, map);
+    hipLaunchKernelGGL(moddown_finish_kernel, g, dim3(256), 0, s, t, sh, out, accQ, conv, pinv, add0, add1, map, post);
 }
 
 }  // namespace fhelin

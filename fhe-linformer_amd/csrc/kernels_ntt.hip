@@ -26,6 +26,7 @@ namespace {
 
 struct NttArgs {
     u64* data;
+    const u64* src;     // input of this pass (== data when in place)
     const u64* tw;      // [n_limbs][2N]
     const u64* moduli;  // [n_limbs]
     const u64* ninv;    // [n_limbs][4]
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256) void ntt_cols_kernel(NttArgs a) {
     const u64 q2 = q << 1;
     const u64x2* tw = reinterpret_cast<const u64x2*>(a.tw) + ((size_t)limb << LOGN);
     u64* base = a.data + ((size_t)vec << LOGN) + tile * CW;
+    const u64* sbase = a.src + ((size_t)vec << LOGN) + tile * CW;
     const int tau = threadIdx.x;
     u64 x[16];
 
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void ntt_cols_kernel(NttArgs a) {
         // windows (in tile-index bits), top down: LOGCW+A-4, LOGCW+A-8, ..., then the remainder at LOGCW
         constexpr int P0 = LOGCW + A - 4;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = base[goff(tile_index(tau, k, P0))];
+        for (int k = 0; k < 16; ++k) x[k] = sbase[goff(tile_index(tau, k, P0))];
         fwd_round<0, 4>(x, tw, q, q2, LOGN, 8 + P0 - LOGCW, tau >> P0);
         int p_prev = P0;
         if constexpr (NFULL >= 2) {
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void ntt_cols_kernel(NttArgs a) {
         const u64* ninv = a.ninv + 4 * limb;
         constexpr int P0 = LOGCW;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = base[goff(tile_index(tau, k, P0))];
+        for (int k = 0; k < 16; ++k) x[k] = sbase[goff(tile_index(tau, k, P0))];
         inv_round<0, 4, (NFULL == 1 && REM == 0)>(x, tw, q, q2, LOGN, 8, tau >> P0, ninv);
         int p_prev = P0;
         if constexpr (NFULL >= 2) {
@@ -212,12 +214,13 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
     const u64 q2 = q << 1;
     const u64x2* tw = reinterpret_cast<const u64x2*>(a.tw) + ((size_t)limb << log_n);
     u64* base = a.data + ((size_t)vec << log_n) + ((size_t)tile << 12);
+    const u64* sbase = a.src + ((size_t)vec << log_n) + ((size_t)tile << 12);
     const int tau = threadIdx.x;
     u64 x[16];
 
     if (!INVERSE) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = base[tile_index(tau, k, 4)];
+        for (int k = 0; k < 16; ++k) x[k] = sbase[tile_index(tau, k, 4)];
         fwd_round<0, 4>(x, tw, q, q2, log_n, 4, (tile << 4) | (tau >> 4));
         exchange(x, lds, tau, 4, 0, false);
         fwd_round<0, 4>(x, tw, q, q2, log_n, 0, (tile << 8) | tau);
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
             out[k >> 1] = v;
         }
     } else {
-        const u64x2* in = reinterpret_cast<const u64x2*>(base + (tau << 4));
+        const u64x2* in = reinterpret_cast<const u64x2*>(sbase + (tau << 4));
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
             u64x2 v = in[k >> 1];
@@ -262,6 +265,7 @@ void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStre
     if (b.nvec <= 0) return;
     NttArgs a;
     a.data = b.data;
+    a.src = b.src ? b.src : b.data;
     a.tw = inverse ? t.tw_inv : t.tw_fwd;
     a.moduli = t.moduli;
     a.ninv = t.ninv;
@@ -282,11 +286,14 @@ void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStre
             default: break;
         }
     };
+    // the first pass may read out of place; the second always works in place on `data`
     if (!inverse) {
         cols();
+        a.src = a.data;
         hipLaunchKernelGGL((ntt_rows_kernel<false>), dim3(blocks), dim3(256), 0, s, a);
     } else {
         hipLaunchKernelGGL((ntt_rows_kernel<true>), dim3(blocks), dim3(256), 0, s, a);
+        a.src = a.data;
         cols();
     }
 }

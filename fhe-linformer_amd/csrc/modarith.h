@@ -44,7 +44,11 @@ FHE_HD u64 mul_shoup(u64 x, u64 w, u64 ws, u64 q) {
     return r >= q ? r - q : r;
 }
 
-FHE_HD u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }
+FHE_HD u64 csub(u64 x, u64 q) {
+    u64 t;
+    const bool borrow = __builtin_sub_overflow(x, q, &t);  // the subtraction's borrow IS the comparison x < q
+    return borrow ? x : t;
+}
 FHE_HD u64 add_mod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
 FHE_HD u64 sub_mod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
 FHE_HD u64 neg_mod(u64 a, u64 q) { return a ? q - a : 0; }
