@@ -167,7 +167,7 @@ def main():
 
     import oracle as orc                                    # checker + cpu_baseline leg only
     from oracle import plain_forward as pf, circuit_sim as cs
-    from fhe_linformer_amd import linformer as lf
+    from fhe_linformer_amd import linformer as lf, shard
 
     n_q = args.n_q if args.workload == "forward" else 24
     n_p = -(-n_q // 4)
@@ -205,16 +205,14 @@ def main():
         eng.sync()
         torch.cuda.synchronize()
         if dist:
-            t = torch.tensor(np.array(logits), dtype=torch.float64, device="cuda")
-            gathered = [torch.zeros_like(t) for _ in range(world)]
-            dist.all_gather(gathered, t)      # the path's only collective: gather of the logits over RCCL/xGMI
+            # the path's only collective: gather of the per-sample logits over RCCL/xGMI (a few hundred bytes)
+            gathered = shard.gather_results(dist, np.array(logits), max_rows=args.steps)
+            assert sum(len(g) for g in gathered) == args.steps * world
             torch.cuda.synchronize()
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if dist:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+            elapsed = shard.max_over_ranks(dist, elapsed)
         stats = eng.stats()
         for k in stats:
             stats[k] = stats[k] // max(1, args.steps)       # per sample
@@ -236,9 +234,7 @@ def main():
     torch.cuda.synchronize()
     ntt_elapsed = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([ntt_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        ntt_ms = float(tt.item())
+        ntt_ms = shard.max_over_ranks(dist, ntt_ms)
     ntt_rate = n_ntt * world / (ntt_ms * 1e-3)
 
     if rank == 0:
