@@ -145,7 +145,7 @@ Context::Context(const Params& p) : prm(p) {
             u64 inv = h_invmod(hat, pj);
             phatinv[2 * j] = inv;
             phatinv[2 * j + 1] = h_shoup(inv, pj);
-            for (int t = 0; t <= L; ++t) phatmod[(size_t)j * (L + 1) + t] = prod_mod(chain.p, j, chain.q[t]);
+            for (int t = 0; t <= L; ++t) phatmod[(size_t)j * (L + 1) + t] = pack30(prod_mod(chain.p, j, chain.q[t]));  // 30-bit halves
         }
         for (int t = 0; t <= L; ++t) {
             u64 qt = chain.q[t];
@@ -189,7 +189,7 @@ Context::Context(const Params& p) : prm(p) {
                 hatinv[2 * i + 1] = h_shoup(inv, qi);
                 for (int t = 0; t < nt; ++t) {
                     u64 mt = t < ell ? chain.q[t] : chain.p[t - ell];
-                    hatmod[(size_t)i * nt + t] = prod_mod(dig, i - lo, mt);
+                    hatmod[(size_t)i * nt + t] = pack30(prod_mod(dig, i - lo, mt));  // 30-bit halves for mac30
                 }
             }
             for (int t = 0; t < nt; ++t) {

@@ -39,14 +39,14 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
     const int lo = j * sh.alpha;
     const int cnt = min(sh.alpha, sh.ell - lo);
     const int nt = sh.ell + sh.k;
-    u64 y[MAXA];
+    u32 y0[MAXA], y1[MAXA];  // y_i = [c_i * (Q_j/q_i)^{-1}]_{q_i}, split in 30-bit halves
 #pragma unroll
     for (int i = 0; i < MAXA; ++i) {
         if (i < cnt) {
             const int li = lo + i;
-            y[i] = mul_shoup(cc[(size_t)li * N + n], hatinv[2 * li], hatinv[2 * li + 1], t.moduli[li]);
+            split30(mul_shoup(cc[(size_t)li * N + n], hatinv[2 * li], hatinv[2 * li + 1], t.moduli[li]), y0[i], y1[i]);
         } else {
-            y[i] = 0;
+            y0[i] = y1[i] = 0;
         }
     }
     u64* dst = ext + (size_t)j * nt * N + n;
@@ -58,11 +58,19 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
         }
         const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
         const Barrett br = load_barrett(t, limb);
-        Acc128 acc = {0, 0};
+        u64 slo = 0, shi = 0;
 #pragma unroll
-        for (int i = 0; i < MAXA; ++i)
-            if (i < cnt) acc_mac(acc, y[i], hatmod[(size_t)(lo + i) * nt + tt]);
-        dst[(size_t)tt * N] = barrett_reduce128(acc.lo, acc.hi, br);
+        for (int i0 = 0; i0 < MAXA; i0 += 8) {
+            Acc30 acc = {0, 0, 0};
+#pragma unroll
+            for (int i = i0; i < i0 + 8 && i < MAXA; ++i)
+                if (i < cnt) {
+                    const u64 h = hatmod[(size_t)(lo + i) * nt + tt];  // pre-split on the host (pack30)
+                    mac30(acc, y0[i], y1[i], (u32)h, (u32)(h >> 32));
+                }
+            acc30_flush(acc, slo, shi);
+        }
+        dst[(size_t)tt * N] = barrett_reduce128(slo, shi, br);
     }
 }
 
@@ -78,21 +86,36 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
     const size_t kstride = (size_t)(sh.L1 + sh.k) * row;  // one evk component, in u64x2 units
     const u64x2* E = reinterpret_cast<const u64x2*>(ext);
     const u64x2* K = reinterpret_cast<const u64x2*>(evk);
-    Acc128 b0 = {0, 0}, b1 = {0, 0}, a0 = {0, 0}, a1 = {0, 0};
-    for (int j = 0; j < sh.beta; ++j) {
-        const u64x2 d = E[((size_t)j * nt + tt) * row + n2];
-        const u64x2 kb = K[(size_t)(2 * j) * kstride + (size_t)limb * row + n2];
-        const u64x2 ka = K[(size_t)(2 * j + 1) * kstride + (size_t)limb * row + n2];
-        acc_mac(b0, d.x, kb.x);
-        acc_mac(b1, d.y, kb.y);
-        acc_mac(a0, d.x, ka.x);
-        acc_mac(a1, d.y, ka.y);
+    u64 lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};  // b.x, b.y, a.x, a.y
+    for (int j0 = 0; j0 < sh.beta; j0 += 8) {
+        Acc30 b0 = {0, 0, 0}, b1 = {0, 0, 0}, a0 = {0, 0, 0}, a1 = {0, 0, 0};
+        const int j1 = min(sh.beta, j0 + 8);
+        for (int j = j0; j < j1; ++j) {
+            const u64x2 d = E[((size_t)j * nt + tt) * row + n2];
+            const u64x2 kb = K[(size_t)(2 * j) * kstride + (size_t)limb * row + n2];
+            const u64x2 ka = K[(size_t)(2 * j + 1) * kstride + (size_t)limb * row + n2];
+            u32 dx0, dx1, dy0, dy1, k0, k1;
+            split30(d.x, dx0, dx1);
+            split30(d.y, dy0, dy1);
+            split30(kb.x, k0, k1);
+            mac30(b0, dx0, dx1, k0, k1);
+            split30(kb.y, k0, k1);
+            mac30(b1, dy0, dy1, k0, k1);
+            split30(ka.x, k0, k1);
+            mac30(a0, dx0, dx1, k0, k1);
+            split30(ka.y, k0, k1);
+            mac30(a1, dy0, dy1, k0, k1);
+        }
+        acc30_flush(b0, lo[0], hi[0]);
+        acc30_flush(b1, lo[1], hi[1]);
+        acc30_flush(a0, lo[2], hi[2]);
+        acc30_flush(a1, lo[3], hi[3]);
     }
     u64x2 rb, ra;
-    rb.x = barrett_reduce128(b0.lo, b0.hi, br);
-    rb.y = barrett_reduce128(b1.lo, b1.hi, br);
-    ra.x = barrett_reduce128(a0.lo, a0.hi, br);
-    ra.y = barrett_reduce128(a1.lo, a1.hi, br);
+    rb.x = barrett_reduce128(lo[0], hi[0], br);
+    rb.y = barrett_reduce128(lo[1], hi[1], br);
+    ra.x = barrett_reduce128(lo[2], hi[2], br);
+    ra.y = barrett_reduce128(lo[3], hi[3], br);
     if (tt < sh.ell) {
         u64x2* O = reinterpret_cast<u64x2*>(accQ);
         O[(size_t)tt * row + n2] = rb;
@@ -112,24 +135,32 @@ __global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsSha
     const int c = blockIdx.y;
     const size_t N = (size_t)1 << t.log_n;
     const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
-    u64 z[MAXK];
+    u32 z0[MAXK], z1[MAXK];
 #pragma unroll
     for (int p = 0; p < MAXK; ++p) {
         if (p < sh.k) {
-            z[p] = mul_shoup(accP[((size_t)c * sh.k + p) * N + n], phatinv[2 * p], phatinv[2 * p + 1], t.moduli[sh.L1 + p]);
+            split30(mul_shoup(accP[((size_t)c * sh.k + p) * N + n], phatinv[2 * p], phatinv[2 * p + 1], t.moduli[sh.L1 + p]), z0[p], z1[p]);
         } else {
-            z[p] = 0;
+            z0[p] = z1[p] = 0;
         }
     }
     u64* dst = conv + (size_t)c * sh.ell * N + n;
     const int t0 = blockIdx.z * TCH, t1 = min(sh.ell, t0 + TCH);
     for (int tt = t0; tt < t1; ++tt) {
         const Barrett br = load_barrett(t, tt);
-        Acc128 acc = {0, 0};
+        u64 slo = 0, shi = 0;
 #pragma unroll
-        for (int p = 0; p < MAXK; ++p)
-            if (p < sh.k) acc_mac(acc, z[p], phatmod[(size_t)p * sh.L1 + tt]);
-        dst[(size_t)tt * N] = barrett_reduce128(acc.lo, acc.hi, br);
+        for (int p0 = 0; p0 < MAXK; p0 += 8) {
+            Acc30 acc = {0, 0, 0};
+#pragma unroll
+            for (int p = p0; p < p0 + 8 && p < MAXK; ++p)
+                if (p < sh.k) {
+                    const u64 h = phatmod[(size_t)p * sh.L1 + tt];  // pre-split on the host (pack30)
+                    mac30(acc, z0[p], z1[p], (u32)h, (u32)(h >> 32));
+                }
+            acc30_flush(acc, slo, shi);
+        }
+        dst[(size_t)tt * N] = barrett_reduce128(slo, shi, br);
     }
 }
 

@@ -97,6 +97,37 @@ FHE_HD void acc_mac(Acc128& a, u64 x, u64 y) {
     a.hi += ph + (a.lo < pl);
 }
 
+// ---- 30-bit split accumulation -------------------------------------------------------------
+// Residues are < 2^60, so x = x1*2^30 + x0 with x0, x1 < 2^30 and every partial product is < 2^60: up to 8
+// products can be summed per column in plain 64-bit registers with NO carry handling.  One multiply-accumulate
+// is then exactly four v_mad_u64_u32 (vs ~16 VALU ops for a carried 64x64->128 MAC).
+struct Acc30 {
+    u64 s0, s1, s2;  // value = s0 + s1*2^30 + s2*2^60
+};
+FHE_HD void split30(u64 x, u32& lo, u32& hi) {
+    lo = (u32)x & 0x3FFFFFFFu;
+    hi = (u32)(x >> 30);
+}
+FHE_HD u64 pack30(u64 x) { return (x & 0x3FFFFFFFull) | ((x >> 30) << 32); }  // host: constants stored pre-split
+FHE_HD void mac30(Acc30& a, u32 x0, u32 x1, u32 y0, u32 y1) {
+    a.s0 += (u64)x0 * y0;
+    a.s1 += (u64)x0 * y1;
+    a.s1 += (u64)x1 * y0;
+    a.s2 += (u64)x1 * y1;
+}
+// fold an Acc30 (<= 8 accumulated products) into a running 128-bit sum
+FHE_HD void acc30_flush(const Acc30& a, u64& lo, u64& hi) {
+    u64 t = lo + a.s0;
+    hi += (t < lo);
+    lo = t;
+    t = lo + (a.s1 << 30);
+    hi += (a.s1 >> 34) + (t < lo);
+    lo = t;
+    t = lo + (a.s2 << 60);
+    hi += (a.s2 >> 4) + (t < lo);
+    lo = t;
+}
+
 #if !defined(__HIP_DEVICE_COMPILE__)
 // ---- host-only helpers ------------------------------------------------------------------
 inline u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
