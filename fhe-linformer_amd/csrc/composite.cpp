@@ -1,9 +1,17 @@
 #include "composite.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace fhelin {
+
+Composite::Composite(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {
+    if (const char* b = std::getenv("FHELIN_BATCH")) {
+        int v = std::atoi(b);
+        if (v >= 1 && v <= 256) ev_.batch_limit = v;
+    }
+}
 
 PtPtr Composite::encode_vec(const std::vector<double>& v, int level) {
     return cl_.encode(v.data(), (int)v.size(), level, num_slots());
@@ -115,6 +123,22 @@ CtPtr Composite::repeat(const CtPtr& in, int slots, int padding) {
     return n ? r : ev_.clone(in);
 }
 
+CtVec Composite::rotsum_batch(const CtVec& in, int slots, int padding) {
+    CtVec r = in;
+    const int n = log_steps(slots);
+    for (int i = 0; i < n; ++i) r = ev_.rotate_add_batch(r, padding * (1 << i));
+    if (!n) for (auto& c : r) c = ev_.clone(c);
+    return r;
+}
+
+CtVec Composite::repeat_batch(const CtVec& in, int slots, int padding) {
+    CtVec r = in;
+    const int n = log_steps(slots);
+    for (int i = 0; i < n; ++i) r = ev_.rotate_add_batch(r, padding * -(1 << i));
+    if (!n) for (auto& c : r) c = ev_.clone(c);
+    return r;
+}
+
 CtPtr Composite::add_many(const CtVec& v) {
     if (v.empty()) throw Error(FHELIN_ERR_ARG, "add_many: empty vector");
     CtVec cur = v;
@@ -128,54 +152,53 @@ CtPtr Composite::add_many(const CtVec& v) {
 }
 
 CtVec Composite::matmul_pt(const CtVec& rows, const PtPtr& w, const PtPtr& bias, int slots, int padding) {
-    CtVec out;
-    for (const CtPtr& row : rows) {
-        CtPtr m = ev_.mult_plain(row, w);
-        m = rotsum(m, slots, padding);
-        if (bias) m = ev_.add_plain(m, bias);
-        out.push_back(m);
-    }
+    // rows are independent (reference loop :872,:888,:985): the same operation sequence, interchanged so that
+    // every rotate-and-sum step runs over all rows at once
+    CtVec out = rotsum_batch(ev_.mult_plain_batch(rows, w), slots, padding);
+    if (bias)
+        for (auto& m : out) m = ev_.add_plain(m, bias);
     return out;
 }
 
 CtVec Composite::matmul_ct(const CtVec& rows, const CtPtr& w, int slots, int padding) {
-    CtVec out;
-    for (const CtPtr& row : rows) out.push_back(rotsum(ev_.mult(row, w), slots, padding));
-    return out;
+    CtVec prod;
+    for (const CtPtr& row : rows) prod.push_back(ev_.mult(row, w));
+    return rotsum_batch(prod, slots, padding);
 }
 
 CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias, double mask_val) {
-    CtVec densed;
-    for (const CtPtr& in : inputs) {
-        CtPtr res;
-        for (int j = (int)weights.size() - 1; j >= 0; --j) {
-            CtPtr out = ev_.mult_plain(in, weights[j]);
-            out = rotsum(out, 128, 128);
-            out = mask_first_n(out, 128, mask_val);
+    // per input the reference computes (:915-944) res = sum_j rot(mask(rotsum(x * W_j)), -128 (3-j)) + bias; inputs are
+    // independent, so each block j is evaluated for all inputs together
+    CtVec res(inputs.size());
+    for (int j = (int)weights.size() - 1; j >= 0; --j) {
+        CtVec outs = rotsum_batch(ev_.mult_plain_batch(inputs, weights[j]), 128, 128);
+        for (size_t i = 0; i < inputs.size(); ++i) {
+            CtPtr out = mask_first_n(outs[i], 128, mask_val);
             if (j == (int)weights.size() - 1) {
-                res = out;
+                res[i] = out;
             } else {
-                res = ev_.rotate(res, -64);
-                res = ev_.rotate(res, -64);
-                res = ev_.add(res, out);
+                res[i] = ev_.rotate(res[i], -64);
+                res[i] = ev_.rotate(res[i], -64);
+                res[i] = ev_.add(res[i], out);
             }
         }
-        if (bias) res = ev_.add_plain(res, bias);
-        densed.push_back(res);
     }
-    return densed;
+    if (bias)
+        for (auto& r : res) r = ev_.add_plain(r, bias);
+    return res;
 }
 
 CtVec Composite::matmulCRlarge(const std::vector<CtVec>& rows, const std::vector<PtPtr>& weights, const PtPtr& bias) {
-    CtVec out;
+    CtVec sums;
     for (const CtVec& r : rows) {
         if (r.size() < 4 || weights.size() < 4) throw Error(FHELIN_ERR_ARG, "matmulCRlarge: need 4 blocks");
         CtVec parts;
         for (int j = 0; j < 4; ++j) parts.push_back(ev_.mult_plain(r[j], weights[j]));
-        CtPtr res = rotsum(add_many(parts), 128, 1);
-        if (bias) res = ev_.add_plain(res, bias);
-        out.push_back(res);
+        sums.push_back(add_many(parts));
     }
+    CtVec out = rotsum_batch(sums, 128, 1);
+    if (bias)
+        for (auto& m : out) m = ev_.add_plain(m, bias);
     return out;
 }
 
@@ -211,14 +234,13 @@ CtPtr Composite::wrapUpExpanded(const CtVec& v) {
 }
 
 CtVec Composite::unwrapExpanded(CtPtr c, int n) {
-    CtVec result;
+    // the mask/rotate chain is sequential (:1089-1097); the `repeat` of every extracted token is independent
+    CtVec masked;
     for (int i = 0; i < n; ++i) {
-        CtPtr out = mask_mod_n(c, 128, 0);
-        out = repeat(out, 128, 1);
+        masked.push_back(mask_mod_n(c, 128, 0));
         if (i < n - 1) c = ev_.rotate(c, 1);
-        result.push_back(out);
     }
-    return result;
+    return repeat_batch(masked, 128, 1);
 }
 
 CtVec Composite::unwrapScoresExpanded(CtPtr c, int n) {
@@ -243,15 +265,21 @@ CtVec Composite::unwrap_512_in_4_128(const CtPtr& c, int index) {
 }
 
 std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int input_number) {
-    std::vector<CtVec> out;
     std::vector<int> quantities;
     for (int i = 0; i < input_number / 32.0; ++i) {
         int q = 32;
         if ((i + 1) * 32 > input_number) q = input_number - i * 32;
         quantities.push_back(q);
     }
+    // unwrap_512_in_4_128 (:1142-1162) for every (container, token): mask the four 128-slot blocks, then one batched
+    // repeat(128, -128) over all of them
+    CtVec masked;
     for (size_t i = 0; i < containers.size() && i < quantities.size(); ++i)
-        for (int j = 0; j < quantities[i]; ++j) out.push_back(unwrap_512_in_4_128(containers[i], j));
+        for (int j = 0; j < quantities[i]; ++j)
+            for (int k = 0; k < 4; ++k) masked.push_back(mask_block(containers[i], j * 512 + 128 * k, j * 512 + 128 * (k + 1), 1));
+    CtVec rep = repeat_batch(masked, 128, -128);
+    std::vector<CtVec> out;
+    for (size_t i = 0; i + 3 < rep.size(); i += 4) out.push_back(CtVec(rep.begin() + i, rep.begin() + i + 4));
     return out;
 }
 

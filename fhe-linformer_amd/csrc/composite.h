@@ -15,7 +15,7 @@ typedef std::vector<CtPtr> CtVec;
 
 class Composite {
 public:
-    Composite(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {}
+    Composite(Evaluator& ev, Client& cl);
     int num_slots() const { return 1 << ev_.ctx().prm.log_slots; }
 
     // leaf helpers
@@ -35,6 +35,10 @@ public:
     CtPtr rotsum_padded(const CtPtr& in, int slots);
     CtPtr repeat(const CtPtr& in, int slots, int padding);              // repeat(in,slots) == padding 1
     CtPtr add_many(const CtVec& v);                                     // EvalAddMany               :417-419
+    // the same reductions over independent rows, step i for ALL rows before step i+1 (one batched key switch per
+    // step: the evaluation key is read once per batch and every launch fills the GPU) — results are bit-identical
+    CtVec rotsum_batch(const CtVec& in, int slots, int padding);
+    CtVec repeat_batch(const CtVec& in, int slots, int padding);
 
     // matmuls                                                                                 :869-1058
     CtVec matmul_pt(const CtVec& rows, const PtPtr& w, const PtPtr& bias, int slots, int padding);   // RE / CR with plaintext weight

@@ -4,8 +4,13 @@
 
 namespace fhelin {
 
-Ciphertext::~Ciphertext() {
+DevBlock::~DevBlock() {
     if (d && ctx) {
+        try { ctx->pool.free(d); } catch (...) {}
+    }
+}
+Ciphertext::~Ciphertext() {
+    if (d && ctx && !block) {
         try { ctx->pool.free(d); } catch (...) {}
     }
 }
@@ -42,6 +47,45 @@ CtPtr Evaluator::clone(const CtPtr& a) {
     return o;
 }
 
+std::vector<CtPtr> Evaluator::new_ct_batch(int count, int npoly, int ell, int deg, long double scale, int slots) {
+    c_.require_device();
+    if (count < 1 || ell < 1 || ell > c_.L + 1 || npoly < 1 || npoly > 3) throw Error(FHELIN_ERR_ARG, "new_ct_batch: bad shape");
+    auto blk = std::make_shared<DevBlock>();
+    blk->ctx = &c_;
+    const size_t words = (size_t)npoly * ell * c_.N;
+    blk->d = c_.dalloc<u64>(words * count);
+    std::vector<CtPtr> v;
+    for (int i = 0; i < count; ++i) {
+        auto ct = std::make_shared<Ciphertext>();
+        ct->ctx = &c_;
+        ct->npoly = npoly;
+        ct->ell = ell;
+        ct->deg = deg;
+        ct->scale = scale;
+        ct->slots = slots;
+        ct->block = blk;
+        ct->d = blk->d + words * i;
+        v.push_back(ct);
+    }
+    return v;
+}
+
+u64* Evaluator::contiguous_base(const std::vector<CtPtr>& v) {
+    if (v.empty() || !v[0]->block) return nullptr;
+    const size_t words = v[0]->words();
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i]->block != v[0]->block || v[i]->d != v[0]->d + words * i || v[i]->words() != words) return nullptr;
+    return v[0]->d;
+}
+
+std::vector<CtPtr> Evaluator::make_contiguous(const std::vector<CtPtr>& v) {
+    if (v.size() <= 1 || contiguous_base(v)) return v;
+    std::vector<CtPtr> o = new_ct_batch((int)v.size(), v[0]->npoly, v[0]->ell, v[0]->deg, v[0]->scale, v[0]->slots);
+    for (size_t i = 0; i < v.size(); ++i)
+        hip_check(hipMemcpyAsync(o[i]->d, v[i]->d, v[i]->words() * 8, hipMemcpyDeviceToDevice, c_.stream), "batch gather");
+    return o;
+}
+
 KeyPtr Evaluator::new_key() {
     c_.require_device();
     auto k = std::make_shared<EvalKey>();
@@ -54,27 +98,43 @@ KeyPtr Evaluator::new_key() {
 // ------------------------------------------------------------------------------------------------
 void Evaluator::keyswitch(const u64* c_ntt, int ell, const EvalKey& key, u64* out, const u64* add0, const u64* add1,
                           const u32* map, const u64* post) {
+    keyswitch_batch(1, c_ntt, 0, ell, key, out, 0, add0, add1, 0, map, post, 0);
+}
+
+void Evaluator::keyswitch_batch(int B, const u64* c_ntt, size_t c_stride, int ell, const EvalKey& key, u64* out, size_t out_stride,
+                                const u64* add0, const u64* add1, size_t add_stride, const u32* map, const u64* post,
+                                size_t post_stride) {
     c_.require_device();
     if (c_.K < 1) throw Error(FHELIN_ERR_STATE, "hybrid key switching needs at least one special prime");
+    if (B < 1) return;
     const size_t N = c_.N;
     const int K = c_.K, L1 = c_.L + 1;
     const LevelTables& lt = c_.lvl[ell];
-    KsShape sh{ell, K, c_.alpha, lt.beta, L1};
+    const int nt = ell + K;
+    KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, c_stride, out_stride, add_stride, post_stride};
     hipStream_t s = c_.stream;
-    u64* cc = c_.dalloc<u64>((size_t)ell * N);
-    c_.stats.keyswitch += 1;
-    c_.stats.keyswitch_limbs += (u64)ell;
-    c_.ntt(LimbBatch{cc, ell, nullptr, 0, ell, c_ntt}, true);  // out of place: cc = INTT(c)
-    u64* ext = c_.dalloc<u64>((size_t)lt.beta * (ell + K) * N);
+    u64* cc = c_.dalloc<u64>((size_t)B * ell * N);
+    c_.stats.keyswitch += (u64)B;
+    c_.stats.keyswitch_limbs += (u64)B * ell;
+    if (B == 1 || c_stride == (size_t)ell * N) {
+        c_.ntt(LimbBatch{cc, B * ell, nullptr, 0, ell, c_ntt}, true);  // out of place: cc = INTT(c)
+    } else {
+        // inputs are strided (c1 of consecutive ciphertexts): gather, then transform in place
+        hip_check(hipMemcpy2DAsync(cc, (size_t)ell * N * 8, c_ntt, c_stride * 8, (size_t)ell * N * 8, B, hipMemcpyDeviceToDevice, s), "ks gather");
+        c_.ntt(LimbBatch{cc, B * ell, nullptr, 0, ell}, true);
+    }
+    u64* ext = c_.dalloc<u64>((size_t)B * lt.beta * nt * N);
     launch_modup_conv(c_.dt, sh, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod, s);
-    c_.ntt(LimbBatch{ext, lt.beta * (ell + K), lt.ext_limb_tab, 0, 1}, false, lt.beta * (ell + K) - ell);
-    u64* accQ = c_.dalloc<u64>((size_t)2 * ell * N);
-    u64* accP = c_.dalloc<u64>((size_t)2 * K * N);
+    LimbBatch eb{ext, B * lt.beta * nt, lt.ext_limb_tab, 0, 1};
+    eb.tab_len = lt.beta * nt;
+    c_.ntt(eb, false, B * (lt.beta * nt - ell));
+    u64* accQ = c_.dalloc<u64>((size_t)B * 2 * ell * N);
+    u64* accP = c_.dalloc<u64>((size_t)B * 2 * K * N);
     launch_ks_inner(c_.dt, sh, accQ, accP, ext, key.d, s);
-    c_.ntt(LimbBatch{accP, 2 * K, nullptr, L1, K}, true);
-    u64* conv = c_.dalloc<u64>((size_t)2 * ell * N);
+    c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
+    u64* conv = c_.dalloc<u64>((size_t)B * 2 * ell * N);
     launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
-    c_.ntt(LimbBatch{conv, 2 * ell, nullptr, 0, ell}, false);
+    c_.ntt(LimbBatch{conv, B * 2 * ell, nullptr, 0, ell}, false);
     launch_moddown_finish(c_.dt, sh, out, accQ, conv, c_.d_pinv, add0, add1, map, post, s);
     launch_ok("keyswitch");
     c_.pool.free(cc);
@@ -112,6 +172,69 @@ CtPtr Evaluator::raw_rotate(const CtPtr& a, u64 g, const EvalKey& key, bool accu
     CtPtr o = new_ct(2, a->ell, a->deg, a->scale, a->slots);
     // accumulate: out = a + rot(a) — the addition of the rotate-and-sum step rides in the ModDown epilogue
     keyswitch(a->d + pn, a->ell, key, o->d, a->d, nullptr, c_.automorph_map(g), accumulate ? a->d : nullptr);
+    return o;
+}
+
+static void check_uniform(const std::vector<CtPtr>& v) {
+    for (const CtPtr& c : v)
+        if (c->npoly != 2 || c->ell != v[0]->ell || c->deg != v[0]->deg || fabsl(c->scale / v[0]->scale - 1.0L) > 1e-9L)
+            throw Error(FHELIN_ERR_STATE, "batched op: ciphertexts must share level, degree and scale");
+}
+
+std::vector<CtPtr> Evaluator::rotate_batch(const std::vector<CtPtr>& vin, int index) {
+    std::vector<CtPtr> out;
+    for (const CtPtr& c : vin) out.push_back(rotate(c, index));
+    return out;
+}
+
+std::vector<CtPtr> Evaluator::rotate_add_batch(const std::vector<CtPtr>& vin, int index) {
+    if (vin.empty()) return {};
+    check_uniform(vin);
+    const int ns = vin[0]->slots > 0 ? vin[0]->slots : (1 << c_.prm.log_slots);
+    if (vin.size() == 1 || index % ns == 0) {
+        std::vector<CtPtr> out;
+        for (const CtPtr& c : vin) out.push_back(rotate_add(c, index));
+        return out;
+    }
+    const u64 g = c_.galois_element(index);
+    auto it = rot_keys.find(g);
+    if (it == rot_keys.end())
+        throw Error(FHELIN_ERR_KEY, "no rotation key for index " + std::to_string(index) + " (EvalRotateKeyGen list)");
+    const u32* map = c_.automorph_map(g);
+    std::vector<CtPtr> out;
+    for (size_t lo = 0; lo < vin.size(); lo += (size_t)batch_limit) {
+        const size_t hi = std::min(vin.size(), lo + (size_t)batch_limit);
+        std::vector<CtPtr> chunk = make_contiguous(std::vector<CtPtr>(vin.begin() + lo, vin.begin() + hi));
+        const int B = (int)chunk.size();
+        const int ell = chunk[0]->ell;
+        const size_t pn = (size_t)ell * c_.N, ctw = 2 * pn;
+        std::vector<CtPtr> o = new_ct_batch(B, 2, ell, chunk[0]->deg, chunk[0]->scale, chunk[0]->slots);
+        const u64* base = B > 1 ? contiguous_base(chunk) : chunk[0]->d;
+        keyswitch_batch(B, base + pn, ctw, ell, *it->second, o[0]->d, ctw, base, nullptr, ctw, map, base, ctw);
+        out.insert(out.end(), o.begin(), o.end());
+    }
+    return out;
+}
+
+std::vector<CtPtr> Evaluator::mult_plain_batch(const std::vector<CtPtr>& vin, const PtPtr& p) {
+    if (vin.empty()) return {};
+    std::vector<CtPtr> x;
+    for (const CtPtr& c : vin) x.push_back(c->deg >= 2 ? rescale(c) : c);
+    bool uniform = true;
+    for (const CtPtr& c : x) uniform = uniform && c->npoly == 2 && c->ell == x[0]->ell && c->deg == x[0]->deg;
+    if (!uniform) {
+        std::vector<CtPtr> out;
+        for (const CtPtr& c : vin) out.push_back(mult_plain(c, p));
+        return out;
+    }
+    auto enc = p->at(x[0]->ell, c_.sf_real[x[0]->level()]);
+    std::vector<CtPtr> o = new_ct_batch((int)x.size(), 2, x[0]->ell, x[0]->deg + 1, x[0]->scale * enc->scale, x[0]->slots);
+    for (size_t i = 0; i < x.size(); ++i) {
+        o[i]->scale = x[i]->scale * enc->scale;
+        launch_ew_mul(c_.dt, o[i]->d, x[i]->d, enc->d, 2 * x[i]->ell, x[i]->ell, 0, x[i]->ell, c_.stream);
+    }
+    c_.stats.ct_pt_mult += x.size();
+    launch_ok("mult_plain_batch");
     return o;
 }
 

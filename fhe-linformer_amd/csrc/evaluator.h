@@ -10,10 +10,18 @@
 
 namespace fhelin {
 
+// One device allocation shared by the ciphertexts of a batch (rows of a matmul processed together).
+struct DevBlock {
+    Context* ctx = nullptr;
+    u64* d = nullptr;
+    ~DevBlock();
+};
+
 // Device-resident ciphertext: d[npoly][ell][N], NTT (evaluation) form.
 struct Ciphertext {
     Context* ctx = nullptr;
     u64* d = nullptr;
+    std::shared_ptr<DevBlock> block;  // set when d is a view into a batch allocation (then d is not owned)
     int npoly = 2;
     int ell = 0;          // live Q limbs; level (OpenFHE GetLevel) = L+1-ell
     int deg = 1;          // noiseScaleDeg: 1 after rescale / fresh, 2 after a multiplication
@@ -63,6 +71,11 @@ public:
 
     // ---- allocation / import / export
     CtPtr new_ct(int npoly, int ell, int deg, long double scale, int slots);
+    std::vector<CtPtr> new_ct_batch(int count, int npoly, int ell, int deg, long double scale, int slots);
+    // base pointer of `v` if its members are consecutive views of one block (else nullptr)
+    static u64* contiguous_base(const std::vector<CtPtr>& v);
+    std::vector<CtPtr> make_contiguous(const std::vector<CtPtr>& v);
+    int batch_limit = 16;   // rows processed per batched key switch (FHELIN_BATCH overrides)
     CtPtr clone(const CtPtr& a);
     KeyPtr new_key();
 
@@ -74,6 +87,13 @@ public:
     // ---- K6-K8 composite: out[2][ell][N] = KeySwitch(c) (+ add0/add1, gathered through map if given)
     void keyswitch(const u64* c_ntt, int ell, const EvalKey& key, u64* out, const u64* add0, const u64* add1, const u32* map,
                    const u64* post = nullptr);
+    // the same for `batch` independent polynomials laid out with the given element strides
+    void keyswitch_batch(int batch, const u64* c_ntt, size_t c_stride, int ell, const EvalKey& key, u64* out, size_t out_stride,
+                         const u64* add0, const u64* add1, size_t add_stride, const u32* map, const u64* post, size_t post_stride);
+    // batched leveled ops over independent ciphertexts of identical (level, degree, scale): one launch set per op
+    std::vector<CtPtr> rotate_add_batch(const std::vector<CtPtr>& v, int index);   // v_i + rot(v_i, index)
+    std::vector<CtPtr> rotate_batch(const std::vector<CtPtr>& v, int index);
+    std::vector<CtPtr> mult_plain_batch(const std::vector<CtPtr>& v, const PtPtr& p);
 
     // ---- leveled ops (functional: inputs are never modified)
     CtPtr add(const CtPtr& a, const CtPtr& b);

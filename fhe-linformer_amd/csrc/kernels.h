@@ -19,6 +19,7 @@ struct LimbBatch {
     int limb_first;
     int limb_count;
     const u64* src = nullptr;  // optional: read the input from src[v][N] (out of place), results land in data
+    int tab_len = 0;           // > 0: the table describes one batch element and repeats: limb_tab[v % tab_len]
 };
 
 // Device-resident per-context tables.

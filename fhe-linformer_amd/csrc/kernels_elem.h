@@ -33,6 +33,12 @@ struct KsShape {
     int alpha;   // limbs per digit
     int beta;    // digits at this level
     int L1;      // total Q limbs (evk limb stride is L1 + k)
+    // batching over independent ciphertexts (rows of a matmul): element b of the batch lives at base + b*stride
+    int batch = 1;
+    size_t c_stride = 0;     // input polynomial c (NTT form)
+    size_t out_stride = 0;   // output [2][ell][N]
+    size_t add_stride = 0;   // add0 / add1
+    size_t post_stride = 0;  // post-add operand
 };
 // K6: cc [ell][N] coefficient form, c_ntt [ell][N] NTT form -> ext [beta][ell+k][N]
 //     (own-digit slots receive c_ntt, the others the fast-basis-extended values in coefficient form)

@@ -33,12 +33,15 @@ constexpr int TCH = 4;  // targets per block: (ell+k)/TCH blocks in z keep >2000
 template <int MAXA>
 __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape sh, u64* ext, const u64* cc, const u64* c_ntt,
                                                          const u64* hatinv, const u64* hatmod) {
-    const int j = blockIdx.y;
+    const int bi = blockIdx.y / sh.beta, j = blockIdx.y % sh.beta;
     const size_t N = (size_t)1 << t.log_n;
     const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int lo = j * sh.alpha;
     const int cnt = min(sh.alpha, sh.ell - lo);
     const int nt = sh.ell + sh.k;
+    cc += (size_t)bi * sh.ell * N;
+    c_ntt += (size_t)bi * sh.c_stride;
+    ext += (size_t)bi * sh.beta * nt * N;
     u32 y0[MAXA], y1[MAXA];  // y_i = [c_i * (Q_j/q_i)^{-1}]_{q_i}, split in 30-bit halves
 #pragma unroll
     for (int i = 0; i < MAXA; ++i) {
@@ -77,9 +80,12 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
 // grid (N/512, ell + k)
 __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape sh, u64* accQ, u64* accP, const u64* ext,
                                                        const u64* evk) {
-    const int tt = blockIdx.y;
     const int nt = sh.ell + sh.k;
+    const int bi = blockIdx.y / nt, tt = blockIdx.y % nt;
     const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
+    ext += (size_t)bi * sh.beta * nt * ((size_t)1 << t.log_n);
+    accQ += (size_t)bi * 2 * sh.ell * ((size_t)1 << t.log_n);
+    accP += (size_t)bi * 2 * sh.k * ((size_t)1 << t.log_n);
     const Barrett br = load_barrett(t, limb);
     const size_t row = ((size_t)1 << t.log_n) >> 1;
     const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -132,9 +138,11 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
 template <int MAXK>
 __global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsShape sh, u64* conv, const u64* accP, const u64* phatinv,
                                                            const u64* phatmod) {
-    const int c = blockIdx.y;
+    const int bi = blockIdx.y >> 1, c = blockIdx.y & 1;
     const size_t N = (size_t)1 << t.log_n;
     const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    accP += (size_t)bi * 2 * sh.k * N;
+    conv += (size_t)bi * 2 * sh.ell * N;
     u32 z0[MAXK], z1[MAXK];
 #pragma unroll
     for (int p = 0; p < MAXK; ++p) {
@@ -168,13 +176,18 @@ __global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsSha
 __global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsShape sh, u64* out, const u64* accQ, const u64* conv,
                                                              const u64* pinv, const u64* add0, const u64* add1, const u32* map,
                                                              const u64* post) {
-    const int v = blockIdx.y;
+    const int bi = blockIdx.y / (2 * sh.ell), v = blockIdx.y % (2 * sh.ell);
     const int c = v / sh.ell, tt = v % sh.ell;
     const u64 q = t.moduli[tt];
     const u64 w = pinv[2 * tt], ws = pinv[2 * tt + 1];
     const size_t N = (size_t)1 << t.log_n;
     const size_t j = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    accQ += (size_t)bi * 2 * sh.ell * N;
+    conv += (size_t)bi * 2 * sh.ell * N;
+    out += (size_t)bi * sh.out_stride;
     const u64* add = c == 0 ? add0 : add1;
+    if (add) add += (size_t)bi * sh.add_stride;
+    if (post) post += (size_t)bi * sh.post_stride;
     u64x2 r;
     if (map) {
         const u32 m0 = map[j], m1 = map[j + 1];
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsS
 
 void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const u64* cc, const u64* c_ntt, const u64* hatinv,
                        const u64* hatmod, hipStream_t s) {
-    dim3 g((1u << t.log_n) / 256, (unsigned)sh.beta, (unsigned)((sh.ell + sh.k + TCH - 1) / TCH));
+    dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * sh.beta), (unsigned)((sh.ell + sh.k + TCH - 1) / TCH));
     if (sh.alpha <= 4)
         hipLaunchKernelGGL((modup_conv_kernel<4>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod);
     else if (sh.alpha <= 8)
@@ -216,12 +229,12 @@ void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const
         hipLaunchKernelGGL((modup_conv_kernel<16>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod);
 }
 void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* evk, hipStream_t s) {
-    dim3 g((1u << t.log_n) / 512, (unsigned)(sh.ell + sh.k));
+    dim3 g((1u << t.log_n) / 512, (unsigned)(sh.batch * (sh.ell + sh.k)));
     hipLaunchKernelGGL(ks_inner_kernel, g, dim3(256), 0, s, t, sh, accQ, accP, ext, evk);
 }
 void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
                          hipStream_t s) {
-    dim3 g((1u << t.log_n) / 256, 2, (unsigned)((sh.ell + TCH - 1) / TCH));
+    dim3 g((1u << t.log_n) / 256, (unsigned)(2 * sh.batch), (unsigned)((sh.ell + TCH - 1) / TCH));
     if (sh.k <= 8)
         hipLaunchKernelGGL((moddown_conv_kernel<8>), g, dim3(256), 0, s, t, sh, conv, accP, phatinv, phatmod);
     else
@@ -229,7 +242,7 @@ void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, co
 }
 void launch_moddown_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* pinv,
                            const u64* add0, const u64* add1, const u32* map, const u64* post, hipStream_t s) {
-    dim3 g((1u << t.log_n) / 512, (unsigned)(2 * sh.ell));
+    dim3 g((1u << t.log_n) / 512, (unsigned)(sh.batch * 2 * sh.ell));
     hipLaunchKernelGGL(moddown_finish_kernel, g, dim3(256), 0, s, t, sh, out, accQ, conv, pinv, add0, add1, map, post);
 }
 

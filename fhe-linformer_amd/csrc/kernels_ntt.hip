@@ -31,6 +31,7 @@ struct NttArgs {
     const u64* moduli;  // [n_limbs]
     const u64* ninv;    // [n_limbs][4]
     const int* limb_tab;
+    int tab_len;
     int limb_first;
     int limb_count;
     int log_n;
@@ -48,7 +49,7 @@ __device__ __forceinline__ int tile_index(int tau, int k, int p) {
 __device__ __forceinline__ int lds_slot(int e) { return e + (e >> 4); }
 
 __device__ __forceinline__ int limb_of(const NttArgs& a, int vec) {
-    return a.limb_tab ? a.limb_tab[vec] : a.limb_first + (vec % a.limb_count);
+    return a.limb_tab ? a.limb_tab[a.tab_len ? vec % a.tab_len : vec] : a.limb_first + (vec % a.limb_count);
 }
 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
@@ -270,6 +271,7 @@ void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStre
     a.moduli = t.moduli;
     a.ninv = t.ninv;
     a.limb_tab = b.limb_tab;
+    a.tab_len = b.tab_len;
     a.limb_first = b.limb_first;
     a.limb_count = b.limb_count > 0 ? b.limb_count : 1;
     a.log_n = t.log_n;
