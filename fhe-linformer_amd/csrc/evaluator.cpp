@@ -175,12 +175,6 @@ CtPtr Evaluator::raw_rotate(const CtPtr& a, u64 g, const EvalKey& key, bool accu
     return o;
 }
 
-static void check_uniform(const std::vector<CtPtr>& v) {
-    for (const CtPtr& c : v)
-        if (c->npoly != 2 || c->ell != v[0]->ell || c->deg != v[0]->deg || fabsl(c->scale / v[0]->scale - 1.0L) > 1e-9L)
-            throw Error(FHELIN_ERR_STATE, "batched op: ciphertexts must share level, degree and scale");
-}
-
 std::vector<CtPtr> Evaluator::rotate_batch(const std::vector<CtPtr>& vin, int index) {
     std::vector<CtPtr> out;
     for (const CtPtr& c : vin) out.push_back(rotate(c, index));
@@ -189,11 +183,10 @@ std::vector<CtPtr> Evaluator::rotate_batch(const std::vector<CtPtr>& vin, int in
 
 std::vector<CtPtr> Evaluator::rotate_add_batch(const std::vector<CtPtr>& vin, int index) {
     if (vin.empty()) return {};
-    check_uniform(vin);
     const int ns = vin[0]->slots > 0 ? vin[0]->slots : (1 << c_.prm.log_slots);
+    std::vector<CtPtr> out(vin.size());
     if (vin.size() == 1 || index % ns == 0) {
-        std::vector<CtPtr> out;
-        for (const CtPtr& c : vin) out.push_back(rotate_add(c, index));
+        for (size_t i = 0; i < vin.size(); ++i) out[i] = rotate_add(vin[i], index);
         return out;
     }
     const u64 g = c_.galois_element(index);
@@ -201,17 +194,32 @@ std::vector<CtPtr> Evaluator::rotate_add_batch(const std::vector<CtPtr>& vin, in
     if (it == rot_keys.end())
         throw Error(FHELIN_ERR_KEY, "no rotation key for index " + std::to_string(index) + " (EvalRotateKeyGen list)");
     const u32* map = c_.automorph_map(g);
-    std::vector<CtPtr> out;
-    for (size_t lo = 0; lo < vin.size(); lo += (size_t)batch_limit) {
-        const size_t hi = std::min(vin.size(), lo + (size_t)batch_limit);
-        std::vector<CtPtr> chunk = make_contiguous(std::vector<CtPtr>(vin.begin() + lo, vin.begin() + hi));
+    // rows that share (level, degree, scale) go through one batched key switch; others form their own groups
+    std::vector<char> done(vin.size(), 0);
+    for (size_t first = 0; first < vin.size(); ++first) {
+        if (done[first]) continue;
+        std::vector<size_t> idx;
+        for (size_t i = first; i < vin.size() && (int)idx.size() < batch_limit; ++i) {
+            const CtPtr &a = vin[first], &b = vin[i];
+            if (!done[i] && b->npoly == 2 && a->npoly == 2 && b->ell == a->ell && b->deg == a->deg &&
+                fabsl(b->scale / a->scale - 1.0L) < 1e-9L)
+                idx.push_back(i);
+        }
+        if (vin[first]->npoly != 2) throw Error(FHELIN_ERR_STATE, "rotate: ciphertext must have 2 components");
+        std::vector<CtPtr> chunk;
+        for (size_t i : idx) chunk.push_back(vin[i]);
+        chunk = make_contiguous(chunk);
         const int B = (int)chunk.size();
         const int ell = chunk[0]->ell;
         const size_t pn = (size_t)ell * c_.N, ctw = 2 * pn;
         std::vector<CtPtr> o = new_ct_batch(B, 2, ell, chunk[0]->deg, chunk[0]->scale, chunk[0]->slots);
-        const u64* base = B > 1 ? contiguous_base(chunk) : chunk[0]->d;
+        const u64* base = chunk[0]->d;  // contiguous by construction (or a single ciphertext)
         keyswitch_batch(B, base + pn, ctw, ell, *it->second, o[0]->d, ctw, base, nullptr, ctw, map, base, ctw);
-        out.insert(out.end(), o.begin(), o.end());
+        for (int b = 0; b < B; ++b) {
+            o[b]->scale = vin[idx[b]]->scale;
+            out[idx[b]] = o[b];
+            done[idx[b]] = 1;
+        }
     }
     return out;
 }
