@@ -227,25 +227,18 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
         fwd_round<0, 4>(x, tw, q, q2, log_n, 0, (tile << 8) | tau);
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = csub(csub(x[k], q2), q);
-        // window at bit 0: the thread owns 16 consecutive residues -> 8 x 16-byte stores
-        u64x2* out = reinterpret_cast<u64x2*>(base + (tau << 4));
+        // window at bit 0 leaves 16 consecutive residues per thread (128-byte lane stride); one more LDS exchange
+        // to the bit-8 window makes every store instruction a contiguous 512-byte wave access
+        exchange(x, lds, tau, 0, 8, true);
 #pragma unroll
-        for (int k = 0; k < 16; k += 2) {
-            u64x2 v;
-            v.x = x[k];
-            v.y = x[k + 1];
-            out[k >> 1] = v;
-        }
+        for (int k = 0; k < 16; ++k) base[tile_index(tau, k, 8)] = x[k];
     } else {
-        const u64x2* in = reinterpret_cast<const u64x2*>(sbase + (tau << 4));
+        // coalesced load through the bit-8 window, then an LDS exchange to the bit-0 window of the first GS round
 #pragma unroll
-        for (int k = 0; k < 16; k += 2) {
-            u64x2 v = in[k >> 1];
-            x[k] = v.x;
-            x[k + 1] = v.y;
-        }
+        for (int k = 0; k < 16; ++k) x[k] = sbase[tile_index(tau, k, 8)];
+        exchange(x, lds, tau, 8, 0, false);
         inv_round<0, 4, false>(x, tw, q, q2, log_n, 0, (tile << 8) | tau, nullptr);
-        exchange(x, lds, tau, 0, 4, false);
+        exchange(x, lds, tau, 0, 4, true);
         inv_round<0, 4, false>(x, tw, q, q2, log_n, 4, (tile << 4) | (tau >> 4), nullptr);
 #pragma unroll
         for (int k = 0; k < 16; ++k) base[tile_index(tau, k, 4)] = x[k];
