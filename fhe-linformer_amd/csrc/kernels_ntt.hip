@@ -35,6 +35,8 @@ struct NttArgs {
     int limb_first;
     int limb_count;
     int log_n;
+    int nvec;
+    int period;  // > 0: vectors v and v + period use the same limb (twiddles); used to co-schedule them
 };
 
 constexpr int TILE = 4096;
@@ -207,8 +209,23 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
     __shared__ u64 lds[LDS_WORDS];
     const int log_n = a.log_n;
     const int logtiles = log_n - 12;
-    const int vec = blockIdx.x >> logtiles;
-    const int tile = blockIdx.x & ((1 << logtiles) - 1);
+    // Block -> (vector, tile) map.  A row tile needs its own 4 KiB twiddle slice per (limb, tile); vectors of the same
+    // limb (the two polys of a ciphertext, the rows of a batch) reuse it.  Blocks b and b+8 share an XCD (L2), so
+    // each XCD gets a contiguous range of logical ids, ordered (limb, tile, repetition): the slice is fetched once
+    // per XCD instead of once per block.  Placement affects speed only.
+    int lid = blockIdx.x;
+    const int nblk = gridDim.x;
+    if ((nblk & 7) == 0) lid = (lid & 7) * (nblk >> 3) + (lid >> 3);
+    int vec, tile;
+    if (a.period > 0) {
+        const int nper = a.nvec / a.period;
+        const int rep = lid % nper, r = lid / nper;
+        tile = r & ((1 << logtiles) - 1);
+        vec = rep * a.period + (r >> logtiles);
+    } else {
+        vec = lid >> logtiles;
+        tile = lid & ((1 << logtiles) - 1);
+    }
     const int limb = limb_of(a, vec);
     if (limb < 0) return;
     const u64 q = a.moduli[limb];
@@ -268,6 +285,9 @@ void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStre
     a.limb_first = b.limb_first;
     a.limb_count = b.limb_count > 0 ? b.limb_count : 1;
     a.log_n = t.log_n;
+    a.nvec = b.nvec;
+    const int per = b.limb_tab ? b.tab_len : a.limb_count;
+    a.period = (per > 0 && per < b.nvec && b.nvec % per == 0) ? per : 0;
     const int A = t.log_n - 8;
     const int blocks = b.nvec << (t.log_n - 12);
     auto cols = [&]() {
