@@ -161,7 +161,7 @@ def encrypt_inputs(ctl, x_in, X_E, X_F):
             "inputs": [ctl.read_expanded_input(x_in[i]) for i in range(x_in.shape[0])]}     # :169-173
 
 
-def encoder1(ctl, w, enc, trace=None):
+def encoder1(ctl, w, enc, trace=None, full_attention=False):
     t = trace if trace is not None else {}
     inputs_E, inputs_F, inputs = enc["inputs_E"], enc["inputs_F"], enc["inputs"]
     S = len(inputs)
@@ -173,29 +173,51 @@ def encoder1(ctl, w, enc, trace=None):
     Q = ctl.matmulRE(inputs, query_w, query_b)                                              # :183
     K = ctl.matmulRE(inputs_E, key_w, key_b)                                                # :184
     K_wrapped = ctl.wrapUpRepeated(K)                                                       # :186
-    scores = ctl.matmulScores(Q[0], K_wrapped)                                              # :196
-    t["scores"] = scores
-    scores = ctl.eval_exp(scores, 32)                                                       # :197
-    t["exp"] = scores
-    scores_sum = ctl.rotsum(scores, 32, 128)                                                # :201
-    scores_denominator = ctl.eval_inverse_naive(scores_sum, -1, 128)                        # :203
-    scores = ctl.mult(scores, scores_denominator)                                           # :205
-    unwrapped_scores = ctl.unwrapExpanded(scores, 1)                                        # :207
     value_w = ctl.read_plain_input(w["WV"].T)
     value_b = ctl.read_plain_repeated_input(w["BV"])
-    V = ctl.matmulRE(inputs_F, value_w, value_b)                                            # :212
-    V_wrapped = ctl.wrapUpRepeated(V)
-    cls_output = ctl.matmulRE(unwrapped_scores, V_wrapped, None, 128, 128)[0]               # :215
-    t["self_attention"] = cls_output
-    output = [cls_output]
-    zero_c = ctl.encrypt(np.zeros(SLOTS), ctl.level(cls_output))                            # :220-221
-    for _ in range(1, S):
-        output.append(ctl.clone(zero_c))
+    if not full_attention:
+        # src/main.cpp:196-224 — attention for the CLS query only; the other tokens' attention output is an encrypted zero
+        scores = ctl.matmulScores(Q[0], K_wrapped)                                          # :196
+        t["scores"] = scores
+        scores = ctl.eval_exp(scores, 32)                                                   # :197
+        t["exp"] = scores
+        scores_sum = ctl.rotsum(scores, 32, 128)                                            # :201
+        scores_denominator = ctl.eval_inverse_naive(scores_sum, -1, 128)                    # :203
+        scores = ctl.mult(scores, scores_denominator)                                       # :205
+        unwrapped_scores = ctl.unwrapExpanded(scores, 1)                                    # :207
+        V = ctl.matmulRE(inputs_F, value_w, value_b)                                        # :212
+        V_wrapped = ctl.wrapUpRepeated(V)
+        cls_output = ctl.matmulRE(unwrapped_scores, V_wrapped, None, 128, 128)[0]           # :215
+        t["self_attention"] = cls_output
+        output = [cls_output]
+        zero_c = ctl.encrypt(np.zeros(SLOTS), ctl.level(cls_output))                        # :220-221
+        for _ in range(1, S):
+            output.append(ctl.clone(zero_c))
+        dense_bias_in_matmul = False
+    else:
+        # src/main_2.cpp:187-229 — attention for every token, queries wrapped 128 at a time
+        Q_1, Q_2 = Q[:128], Q[128:]
+        scores_1 = ctl.eval_exp(ctl.matmulScores(Q_1, K_wrapped), len(Q_1))                 # main_2.cpp:196-197
+        scores_2 = ctl.eval_exp(ctl.matmulScores(Q_2, K_wrapped), len(Q_2))                 # :199-200
+        t["scores"], t["exp"] = scores_1, scores_2
+        den_1 = ctl.eval_inverse_naive(ctl.rotsum(scores_1, 32, 128), -1, 190000)           # :202-212
+        den_2 = ctl.eval_inverse_naive(ctl.rotsum(scores_2, 32, 128), -1, 190000)
+        scores_1 = ctl.mult(scores_1, den_1)
+        scores_2 = ctl.mult(scores_2, den_2)
+        unwrapped_scores = ctl.unwrapExpanded(scores_1, 128) + ctl.unwrapExpanded(scores_2, S - 128)   # :216-221
+        V = ctl.matmulRE(inputs_F, value_w, value_b)                                        # :226
+        V_wrapped = ctl.wrapUpRepeated(V)
+        output = ctl.matmulRE(unwrapped_scores, V_wrapped, None, 128, 128)                  # :229
+        t["self_attention"] = output[0]
+        dense_bias_in_matmul = True
 
     dense_w = ctl.read_plain_input(w["WO"], ctl.level(output[0]))                           # ..._WO_weight.txt :231
     dense_b = ctl.read_plain_expanded_input(w["BO"], ctl.level(output[0]) + 1)
-    output = ctl.matmulCR(output, dense_w, None)                                            # :235
-    output[0] = ctl.add(output[0], dense_b)
+    if dense_bias_in_matmul:
+        output = ctl.matmulCR(output, dense_w, dense_b)                                     # main_2.cpp:241
+    else:
+        output = ctl.matmulCR(output, dense_w, None)                                        # main.cpp:235
+        output[0] = ctl.add(output[0], dense_b)
     output = [ctl.add(output[i], inputs[i]) for i in range(S)]                              # :237-239
 
     fL1 = w["c10"] + w["c11"] / math.sqrt(S) + w["c12"] / S                                 # :290-291
@@ -245,8 +267,7 @@ def encoder1(ctl, w, enc, trace=None):
     return output_2[0]
 
 
-def pooler(ctl, w, x, trace=None):                                                          # main.cpp:427-451
-    tanh_scale = 1.0 / 50
+def pooler(ctl, w, x, trace=None, tanh_scale=1.0 / 50):                                     # main.cpp:427-451 (main_2.cpp:385: 1/18)
     weight = ctl.read_plain_input(w["Wp"].T, ctl.level(x), tanh_scale)                      # pooler_dense_weight_T.txt
     bias = ctl.read_plain_repeated_input(w["bp"], ctl.level(x) + 1, tanh_scale)
     out = ctl.mult(x, weight)
@@ -259,7 +280,7 @@ def pooler(ctl, w, x, trace=None):                                              
     return out
 
 
-def classifier(ctl, w, x):                                                                  # main.cpp:453-475
+def classifier(ctl, w, x, encrypted_mask=True):                                             # main.cpp:453-475
     fc = np.zeros((128, 128))
     fc[:20] = w["fc_w"]                                                                     # fcLinear_0_weight.txt: 20 rows
     weight = ctl.read_plain_input(fc, ctl.level(x))
@@ -269,17 +290,23 @@ def classifier(ctl, w, x):                                                      
     out = ctl.add(out, bias)
     mask = np.zeros(SLOTS)
     mask[np.arange(20) * 128] = 1
-    return ctl.mult(out, ctl.encrypt(mask, ctl.level(out)))                                 # encrypted mask (quirk Q8)
+    if encrypted_mask:
+        return ctl.mult(out, ctl.encrypt(mask, ctl.level(out)))                             # encrypted mask (quirk Q8)
+    return ctl.mult(out, ctl.encode(mask, ctl.level(out)))                                  # main_2.cpp:427: plaintext mask
 
 
-def forward_encrypted(ctl, w, enc, trace=None):
-    """server side of one sample: encoder1 -> pooler -> classifier -> logits at slots {0,128,...,19*128} (main.cpp:105-123)"""
-    out = encoder1(ctl, w, enc, trace)
-    return classifier(ctl, w, pooler(ctl, w, out, trace))
+def forward_encrypted(ctl, w, enc, trace=None, variant="main"):
+    """server side of one sample: encoder1 -> pooler -> classifier -> logits at slots {0,128,...,19*128} (main.cpp:105-123).
+    variant "main" = src/main.cpp as built (CLS-query attention); "main_2" = src/main_2.cpp (full attention,
+    tanh scale 1/18, plaintext output mask)."""
+    full = variant == "main_2"
+    out = encoder1(ctl, w, enc, trace, full_attention=full)
+    pooled = pooler(ctl, w, out, trace, tanh_scale=1.0 / 18 if full else 1.0 / 50)
+    return classifier(ctl, w, pooled, encrypted_mask=not full)
 
 
-def forward(ctl, w, x_in, X_E, X_F, trace=None):
-    return forward_encrypted(ctl, w, encrypt_inputs(ctl, x_in, X_E, X_F), trace)
+def forward(ctl, w, x_in, X_E, X_F, trace=None, variant="main"):
+    return forward_encrypted(ctl, w, encrypt_inputs(ctl, x_in, X_E, X_F), trace, variant)
 
 
 def logits_from_slots(v):

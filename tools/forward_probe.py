@@ -9,10 +9,11 @@ from oracle import plain_forward as pf, circuit_sim as cs
 preset = sys.argv[1] if len(sys.argv) > 1 else "reference"
 n_q = int(sys.argv[2]) if len(sys.argv) > 2 else 29
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 129
+variant = sys.argv[4] if len(sys.argv) > 4 else "main"
 w = pf.synthetic_model(1234); x = pf.synthetic_tokens(S, 4321)
 x_in, X_E, X_F = pf.client_inputs(w, x)
 sim = cs.SlotSimController(); st = {}
-ref = lf.forward(sim, w, x_in, X_E, X_F, st)
+ref = lf.forward(sim, w, x_in, X_E, X_F, st, variant)
 n_p = -(-n_q // 4)
 e = fa.Engine(preset, seed=11, n_q=n_q, n_p=n_p)
 t0 = time.time(); e.keygen(); e.gen_relin_key()
@@ -29,7 +30,7 @@ class Tracing(lf.GpuController):
 ctl = Tracing(e); tr = {}
 e.sync(); t0 = time.time()
 try:
-    out = lf.forward(ctl, w, x_in, X_E, X_F, tr)
+    out = lf.forward(ctl, w, x_in, X_E, X_F, tr, variant)
     e.sync(); print("forward s", round(time.time() - t0, 2), "bootstraps", ctl.n_boot)
 except Exception as ex:
     print("FAILED:", ex)
