@@ -43,6 +43,7 @@ def test_rescale_three_components_and_last_limb(engine_factory, orc):
     ("toy13", [7, 3], [128, -64]),
     ("bench", [24, 8], [1, 128]),                  # BASELINE size: N=2^16, 24 limbs, k=6, alpha=6
     ("reference", [28], [-1]),                     # reference parameters: N=2^15, 28+7 limbs, alpha=7
+    ("deep", [30, 9], [128]),                      # BASELINE config 5: N=2^17, 30+8 limbs, alpha=8
 ])
 def test_rotate_bit_exact(engine_factory, orc, preset, ells, rots):
     eng = engine_factory(preset)

@@ -11,7 +11,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_encrypted_forward_matches_plaintext_circuit(fa):
+@pytest.mark.parametrize("variant,preset,n_q", [
+    ("main", "reference", 29),       # src/main.cpp as built: CLS-query attention (BASELINE configs 2-3)
+    ("main_2", "reference", 29),     # src/main_2.cpp: full attention over all S tokens
+    ("main_2", "deep", 30),          # BASELINE config 5: N=2^17, 30+8 limbs, sparse (N/8) bootstrapping
+])
+def test_encrypted_forward_matches_plaintext_circuit(fa, variant, preset, n_q):
     from fhe_linformer_amd import linformer as lf
     from oracle import plain_forward as pf, circuit_sim as cs
     S = 129
@@ -19,16 +24,16 @@ def test_encrypted_forward_matches_plaintext_circuit(fa):
     x = pf.synthetic_tokens(S, 4321)
     x_in, X_E, X_F = pf.client_inputs(w, x)
     sim, st = cs.SlotSimController(), {}
-    ref = lf.forward(sim, w, x_in, X_E, X_F, st)
+    ref = lf.forward(sim, w, x_in, X_E, X_F, st, variant)
 
-    eng = fa.Engine("reference", seed=11, n_q=29, n_p=8)
+    eng = fa.Engine(preset, seed=11, n_q=n_q, n_p=8)
     try:
         eng.keygen()
         eng.gen_relin_key()
         eng.gen_rotation_keys(sorted(set([2 ** i for i in range(14)] + [-(2 ** i) for i in range(14)])))
         eng.bootstrap_setup(3, 3, 16384)
         ctl, tr = lf.GpuController(eng), {}
-        out = lf.forward(ctl, w, x_in, X_E, X_F, tr)
+        out = lf.forward(ctl, w, x_in, X_E, X_F, tr, variant)
         assert ctl.n_boot == sim.n_boot == 8                   # 2 (affine-1) + 5 (GELU containers) + 1 (pooler)
         tol = {"scores": 1e-8, "exp": 1e-8, "self_attention": 1e-8, "affine1_0": 1e-8, "encoder_out": 1e-4, "pooled": 5e-3}
         for k, t in tol.items():
