@@ -82,8 +82,6 @@ Context::Context(const Params& p) : prm(p) {
     K = p.n_p;
     alpha = (p.n_q + p.dnum - 1) / p.dnum;
     if (alpha > 16) throw Error(FHELIN_ERR_ARG, "digit size > 16 limbs not supported");
-    if (K > 0 && (long)K * p.special_bits < (long)alpha * std::max(p.scale_bits, p.first_bits) - 8)
-        ;  // P smaller than a digit is allowed (noise grows); no hard error
     try {
         chain = make_prime_chain(p.log_n, p.n_q, p.first_bits, p.scale_bits, p.n_p, p.special_bits);
     } catch (const std::exception& e) {

@@ -60,8 +60,8 @@ struct Barrett {
     u64 r1;  // high word
 };
 
-// reduce a 128-bit value (hi:lo) modulo q; requires q < 2^62 (quotient estimate off by <= 2... we
-// correct with two conditional subtractions).  Any 128-bit input is accepted.
+// reduce a 128-bit value (hi:lo) modulo q.  Requirements: q < 2^62 and hi < q (value < q * 2^64, so that the
+// quotient fits 64 bits); the quotient estimate is short by at most 2, hence two conditional subtractions.
 FHE_HD u64 barrett_reduce128(u64 lo, u64 hi, const Barrett& b) {
     // qhat = floor( (hi:lo) * (r1:r0) / 2^128 ), computed without the lowest partial product's low word
     u64 carry = mulhi64(lo, b.r0);

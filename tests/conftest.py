@@ -12,6 +12,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The .so files are build artefacts (git-ignored): build them when a fresh checkout runs the tests first."""
+    lib = os.path.join(ROOT, "fhe-linformer_amd", "libfhelin_amd.so")
+    drv = os.path.join(ROOT, "tests", "shim", "shim_driver")
+    if not (os.path.exists(lib) and os.path.exists(drv)):
+        import __graft_entry__
+        __graft_entry__.build()
+    yield
+
+
 @pytest.fixture(scope="session")
 def orc():
     import oracle
