@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--micro", action="store_true", help="instruction-rate probes instead of the benchmark")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: ranks may share GPU 0)")
     return ap.parse_args()
 
 
@@ -158,8 +159,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:  # rehearsal on a box with fewer GPUs than ranks: every rank computes on GPU 0, collectives over gloo
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     if args.micro:
