@@ -60,5 +60,26 @@ def main():
     real_print("wrote", path, {k: (len(v) if isinstance(v, list) else v) for k, v in out.items()})
 
 
+def helpers():
+    """pin the reference's offline weight splitters (split_ffn_w1.py:24-37, split_ffn_w2_cols.py:22-29) on seeded matrices"""
+    import hashlib
+    import split_ffn_w1
+    import split_ffn_w2_cols
+    rng = np.random.default_rng(77)
+    W0 = rng.normal(size=(512, 128))
+    W2 = rng.normal(size=(128, 512))
+    b0 = split_ffn_w1.split_transposed_blocks(W0, 128)
+    b2 = split_ffn_w2_cols.split_col_blocks(W2, 128)
+    dig = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+    out = {"seed": 77, "source": "reference split_ffn_w1.split_transposed_blocks / split_ffn_w2_cols.split_col_blocks",
+           "w1_blocks_sha256": [dig(b) for b in b0], "w2_blocks_sha256": [dig(b) for b in b2],
+           "w1_block0_row0_head": np.asarray(b0[0], dtype=np.float64)[0, :4].tolist(),
+           "w2_block3_row5_head": np.asarray(b2[3], dtype=np.float64)[5, :4].tolist()}
+    path = os.path.join(ROOT, "tests", "golden", "weight_split_helpers.json")
+    json.dump(out, open(path, "w"))
+    print("wrote", path)
+
+
 if __name__ == "__main__":
     main()
+    helpers()

@@ -47,6 +47,21 @@ def test_circuit_model_agrees_with_plain_model_on_prediction():
     assert np.max(np.abs(c["x_norm0_cls"])) < 2.0      # bootstrapping input range (|m| well inside q0/2^correction K)
 
 
+def test_weight_split_helpers_match_reference_golden():
+    """tests/golden/weight_split_helpers.json was produced by the reference's own splitter functions"""
+    import hashlib
+    from fhe_linformer_amd import linformer as lf
+    g = json.load(open(os.path.join(HERE, "golden", "weight_split_helpers.json")))
+    rng = np.random.default_rng(g["seed"])
+    W0 = rng.normal(size=(512, 128))
+    W2 = rng.normal(size=(128, 512))
+    dig = lambda a: hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+    b0, b2 = lf.split_transposed_blocks(W0), lf.split_col_blocks(W2)
+    assert [dig(b) for b in b0] == g["w1_blocks_sha256"]
+    assert [dig(b) for b in b2] == g["w2_blocks_sha256"]
+    assert np.allclose(b0[0][0, :4], g["w1_block0_row0_head"]) and np.allclose(b2[3][5, :4], g["w2_block3_row5_head"])
+
+
 def test_helper_scripts_layouts():
     """output layouts of the reference's offline weight splitters (split_ffn_w1.py:24-37, split_ffn_w2_cols.py:22-29)
     as the driver consumes them: W0^T [128,512] -> 4 blocks [128,128]; W2 [128,512] -> 4 column blocks."""
