@@ -116,12 +116,14 @@ void Evaluator::keyswitch_batch(int B, const u64* c_ntt, size_t c_stride, int el
     u64* cc = c_.dalloc<u64>((size_t)B * ell * N);
     c_.stats.keyswitch += (u64)B;
     c_.stats.keyswitch_limbs += (u64)B * ell;
-    if (B == 1 || c_stride == (size_t)ell * N) {
-        c_.ntt(LimbBatch{cc, B * ell, nullptr, 0, ell, c_ntt}, true);  // out of place: cc = INTT(c)
-    } else {
-        // inputs are strided (c1 of consecutive ciphertexts): gather, then transform in place
-        hip_check(hipMemcpy2DAsync(cc, (size_t)ell * N * 8, c_ntt, c_stride * 8, (size_t)ell * N * 8, B, hipMemcpyDeviceToDevice, s), "ks gather");
-        c_.ntt(LimbBatch{cc, B * ell, nullptr, 0, ell}, true);
+    {
+        // out of place: cc = INTT(c); the inputs of a batch are strided (c1 of consecutive ciphertexts)
+        LimbBatch ib{cc, B * ell, nullptr, 0, ell, c_ntt};
+        if (B > 1 && c_stride != (size_t)ell * N) {
+            ib.src_group = ell;
+            ib.src_group_stride = c_stride;
+        }
+        c_.ntt(ib, true);
     }
     u64* ext = c_.dalloc<u64>((size_t)B * lt.beta * nt * N);
     launch_modup_conv(c_.dt, sh, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod, s);

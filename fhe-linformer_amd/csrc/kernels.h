@@ -20,6 +20,9 @@ struct LimbBatch {
     int limb_count;
     const u64* src = nullptr;  // optional: read the input from src[v][N] (out of place), results land in data
     int tab_len = 0;           // > 0: the table describes one batch element and repeats: limb_tab[v % tab_len]
+    // strided out-of-place input: vector v is read from src + (v / src_group) * src_group_stride + (v % src_group) * N
+    int src_group = 0;         // 0 = src is dense like data
+    size_t src_group_stride = 0;
 };
 
 // Device-resident per-context tables.

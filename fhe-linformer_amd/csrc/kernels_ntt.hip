@@ -37,7 +37,14 @@ struct NttArgs {
     int log_n;
     int nvec;
     int period;  // > 0: vectors v and v + period use the same limb (twiddles); used to co-schedule them
+    int src_group;            // > 0: strided first-pass input (see LimbBatch)
+    size_t src_group_stride;
 };
+
+__device__ __forceinline__ size_t src_offset(const NttArgs& a, int vec, int log_n) {
+    if (a.src_group > 0) return (size_t)(vec / a.src_group) * a.src_group_stride + ((size_t)(vec % a.src_group) << log_n);
+    return (size_t)vec << log_n;
+}
 
 constexpr int TILE = 4096;
 constexpr int LDS_WORDS = TILE + TILE / 16;
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void ntt_cols_kernel(NttArgs a) {
     const u64 q2 = q << 1;
     const u64x2* tw = reinterpret_cast<const u64x2*>(a.tw) + ((size_t)limb << LOGN);
     u64* base = a.data + ((size_t)vec << LOGN) + tile * CW;
-    const u64* sbase = a.src + ((size_t)vec << LOGN) + tile * CW;
+    const u64* sbase = a.src + src_offset(a, vec, LOGN) + tile * CW;
     const int tau = threadIdx.x;
     u64 x[16];
 
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
     const u64 q2 = q << 1;
     const u64x2* tw = reinterpret_cast<const u64x2*>(a.tw) + ((size_t)limb << log_n);
     u64* base = a.data + ((size_t)vec << log_n) + ((size_t)tile << 12);
-    const u64* sbase = a.src + ((size_t)vec << log_n) + ((size_t)tile << 12);
+    const u64* sbase = a.src + src_offset(a, vec, log_n) + ((size_t)tile << 12);
     const int tau = threadIdx.x;
     u64 x[16];
 
@@ -277,6 +284,8 @@ void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStre
     NttArgs a;
     a.data = b.data;
     a.src = b.src ? b.src : b.data;
+    a.src_group = b.src ? b.src_group : 0;
+    a.src_group_stride = b.src_group_stride;
     a.tw = inverse ? t.tw_inv : t.tw_fwd;
     a.moduli = t.moduli;
     a.ninv = t.ninv;
@@ -305,10 +314,12 @@ void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStre
     if (!inverse) {
         cols();
         a.src = a.data;
+        a.src_group = 0;
         hipLaunchKernelGGL((ntt_rows_kernel<false>), dim3(blocks), dim3(256), 0, s, a);
     } else {
         hipLaunchKernelGGL((ntt_rows_kernel<true>), dim3(blocks), dim3(256), 0, s, a);
         a.src = a.data;
+        a.src_group = 0;
         cols();
     }
 }
