@@ -30,6 +30,7 @@
 #include <functional>
 #include <iomanip>
 #include <iostream>
+#include <iterator>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -47,38 +48,44 @@ using namespace std::chrono;
 
 /* ---- the subset of reference src/Utils.h that FHEController and main.cpp use (:21-42, :61-87) ---------- */
 namespace utils {
-static inline chrono::time_point<steady_clock, nanoseconds> start_time() { return steady_clock::now(); }
+typedef chrono::time_point<steady_clock, nanoseconds> tick_t;
+static inline tick_t start_time() { return steady_clock::now(); }
 static duration<long long, ratio<1, 1000>> total_time;
-static inline void print_duration(chrono::time_point<steady_clock, nanoseconds> start, const string& title) {
-    auto ms = duration_cast<milliseconds>(steady_clock::now() - start);
-    total_time += ms;
-    auto secs = duration_cast<seconds>(ms);
-    ms -= duration_cast<milliseconds>(secs);
-    auto mins = duration_cast<minutes>(secs);
-    secs -= duration_cast<seconds>(mins);
-    if (mins.count() < 1)
-        cout << "(" << title << "): " << secs.count() << ":" << ms.count() << "s" << " (Total: " << duration_cast<seconds>(total_time).count() << "s)" << endl;
-    else
-        cout << "(" << title << "): " << mins.count() << "." << secs.count() << ":" << ms.count() << endl;
+// "(title): s:ms (Total: Ns)" like the reference's stopwatch, minutes shown once a step exceeds 60 s
+static inline void print_duration(tick_t start, const string& title) {
+    const long long ms_all = duration_cast<milliseconds>(steady_clock::now() - start).count();
+    total_time += milliseconds(ms_all);
+    const long long mins = ms_all / 60000, secs = (ms_all / 1000) % 60, ms = ms_all % 1000;
+    cout << "(" << title << "): ";
+    if (mins > 0) cout << mins << "." << secs << ":" << ms << endl;
+    else cout << secs << ":" << ms << "s (Total: " << duration_cast<seconds>(total_time).count() << "s)" << endl;
 }
+// comma- and newline-separated decimal numbers (the format written by extract_parameters_numeric.py): one strtod
+// sweep over the whole file; unparsable tokens are reported and skipped; a missing file yields an empty vector
 static inline vector<double> read_values_from_file(const string& filename, double scale = 1) {
     vector<double> values;
-    ifstream file(filename);
+    ifstream file(filename, ios::in | ios::binary);
     if (!file.is_open()) {
         std::cerr << "Can not open " << filename << std::endl;
         return values;
     }
-    string row;
-    while (std::getline(file, row)) {
-        istringstream stream(row);
-        string value;
-        while (std::getline(stream, value, ',')) {
-            try {
-                values.push_back(stod(value) * scale);
-            } catch (const invalid_argument&) {
-                cerr << "Can not convert: " << value << endl;
-            }
+    const string text((istreambuf_iterator<char>(file)), istreambuf_iterator<char>());
+    const char* p = text.c_str();
+    const char* const last = p + text.size();
+    while (p < last) {
+        while (p < last && (*p == ',' || *p == '\n' || *p == '\r' || *p == ' ' || *p == '\t')) ++p;
+        if (p >= last) break;
+        char* stop = nullptr;
+        const double v = std::strtod(p, &stop);
+        if (stop == p) {
+            const char* q = p;
+            while (q < last && *q != ',' && *q != '\n') ++q;
+            cerr << "Can not convert: " << string(p, q) << endl;
+            p = q;
+            continue;
         }
+        values.push_back(v * scale);
+        p = stop;
     }
     return values;
 }
@@ -160,14 +167,16 @@ public:
     FHEController(const FHEController&) = delete;
     FHEController& operator=(const FHEController&) = delete;
 
-    /* Context generating/loading (reference :3-235).  The literal reference parameters are N=2^15, 28 Q limbs,
-     * 7 special limbs, dnum 4 (:6-35); FHELIN_PRESET=bench selects BASELINE.json's N=2^16 / 24+6 limbs. */
+    /* Context generating/loading (reference :3-235).  The reference's parameters are N=2^15, depth 27 = 28 Q limbs,
+     * dnum 4 (:6-35).  This engine's bootstrap consumes 15 levels where OpenFHE's consumes 14, so the chain gets one more
+     * limb (29 Q + 8 special limbs) while `circuit_depth` keeps the reference's value; FHELIN_PRESET=bench selects
+     * BASELINE.json's ring N=2^16. */
     void generate_context(bool serialize = false, bool secure = false) {
         (void)secure;  // parsed but ignored by the reference as well (:3,:10)
         num_slots = 1 << 14;
         level_budget = {3, 3};
         fhelin_params p = default_params();
-        circuit_depth = p.n_q - 1;
+        circuit_depth = 1 + 12 + 14;  // 1 + levelsUsedBeforeBootstrap + GetBootstrapDepth(8, {3,3}, SPARSE_TERNARY)  (:27-31)
         cout << endl << "Ciphertexts depth: " << circuit_depth << ", available multiplications: " << 12 - 2 << endl;
         create(p);
         cout << "Context built, generating keys..." << endl;
@@ -218,7 +227,7 @@ public:
         }
         num_slots = 1 << 14;
         level_budget = {3, 3};
-        circuit_depth = p.n_q - 2;  // the reference recomputes the depth without the +1 here (:226-230, quirk Q2)
+        circuit_depth = 12 + 14;  // the reference recomputes the depth without the +1 here (:226-230, quirk Q2)
         create(p);
         fhelin_shim::check(fhelin_keygen(context), "KeyGen");
         fhelin_shim::check(fhelin_gen_relin_key(context), "EvalMultKeyGen");
@@ -675,10 +684,10 @@ private:
         const char* preset = std::getenv("FHELIN_PRESET");
         const bool bench = preset && string(preset) == "bench";
         p.log_n = bench ? 16 : 15;
-        p.n_q = bench ? 24 : 28;
+        p.n_q = 29;
         p.first_bits = 55;
         p.scale_bits = 52;
-        p.n_p = bench ? 6 : 7;
+        p.n_p = 8;
         p.special_bits = 60;
         p.dnum = 4;
         p.log_slots = 14;
