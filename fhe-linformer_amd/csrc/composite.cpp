@@ -90,15 +90,17 @@ CtPtr Composite::mask_mod_n(const CtPtr& c, int n, int padding) {
     return ev_.mult_plain(c, mask_cache_[key]);
 }
 
-CtPtr Composite::mask_first_n(const CtPtr& c, int n, double val) {
+PtPtr Composite::first_n_mask(int n, double val) {
     const std::string key = mkey("first", n, 0, val);
     if (!mask_cache_.count(key)) {
         std::vector<double> m(num_slots(), 0.0);
         for (int i = 0; i < n && i < num_slots(); ++i) m[i] = val;
         mask_plain(key, m);
     }
-    return ev_.mult_plain(c, mask_cache_[key]);
+    return mask_cache_[key];
 }
+
+CtPtr Composite::mask_first_n(const CtPtr& c, int n, double val) { return ev_.mult_plain(c, first_n_mask(n, val)); }
 
 // the reference loops `for (int i = 0; i < log2(slots); i++)` with a floating-point bound (:832,:842,:852,:862)
 static int log_steps(int slots) {
@@ -172,15 +174,13 @@ CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& we
     CtVec res(inputs.size());
     for (int j = (int)weights.size() - 1; j >= 0; --j) {
         CtVec outs = rotsum_batch(ev_.mult_plain_batch(inputs, weights[j]), 128, 128);
-        for (size_t i = 0; i < inputs.size(); ++i) {
-            CtPtr out = mask_first_n(outs[i], 128, mask_val);
-            if (j == (int)weights.size() - 1) {
-                res[i] = out;
-            } else {
-                res[i] = ev_.rotate(res[i], -64);
-                res[i] = ev_.rotate(res[i], -64);
-                res[i] = ev_.add(res[i], out);
-            }
+        CtVec masked = ev_.mult_plain_batch(outs, first_n_mask(128, mask_val));
+        if (j == (int)weights.size() - 1) {
+            res = masked;
+        } else {
+            res = ev_.rotate_batch(res, -64);
+            res = ev_.rotate_batch(res, -64);
+            for (size_t i = 0; i < inputs.size(); ++i) res[i] = ev_.add(res[i], masked[i]);
         }
     }
     if (bias)

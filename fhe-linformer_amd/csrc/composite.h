@@ -29,6 +29,7 @@ public:
     CtPtr mask_heads_128(const CtPtr& c, double v);
     CtPtr mask_mod_n(const CtPtr& c, int n, int padding);
     CtPtr mask_first_n(const CtPtr& c, int n, double v);
+    PtPtr first_n_mask(int n, double v);   // the cached mask plaintext itself (batched callers)
 
     // log-tree reductions                                                                     :829-867
     CtPtr rotsum(const CtPtr& in, int slots, int padding);

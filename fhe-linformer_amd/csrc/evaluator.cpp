@@ -177,18 +177,15 @@ CtPtr Evaluator::raw_rotate(const CtPtr& a, u64 g, const EvalKey& key, bool accu
     return o;
 }
 
-std::vector<CtPtr> Evaluator::rotate_batch(const std::vector<CtPtr>& vin, int index) {
-    std::vector<CtPtr> out;
-    for (const CtPtr& c : vin) out.push_back(rotate(c, index));
-    return out;
-}
+std::vector<CtPtr> Evaluator::rotate_batch(const std::vector<CtPtr>& vin, int index) { return rotate_batch_impl(vin, index, false); }
+std::vector<CtPtr> Evaluator::rotate_add_batch(const std::vector<CtPtr>& vin, int index) { return rotate_batch_impl(vin, index, true); }
 
-std::vector<CtPtr> Evaluator::rotate_add_batch(const std::vector<CtPtr>& vin, int index) {
+std::vector<CtPtr> Evaluator::rotate_batch_impl(const std::vector<CtPtr>& vin, int index, bool accumulate) {
     if (vin.empty()) return {};
     const int ns = vin[0]->slots > 0 ? vin[0]->slots : (1 << c_.prm.log_slots);
     std::vector<CtPtr> out(vin.size());
     if (vin.size() == 1 || index % ns == 0) {
-        for (size_t i = 0; i < vin.size(); ++i) out[i] = rotate_add(vin[i], index);
+        for (size_t i = 0; i < vin.size(); ++i) out[i] = accumulate ? rotate_add(vin[i], index) : rotate(vin[i], index);
         return out;
     }
     const u64 g = c_.galois_element(index);
@@ -200,14 +197,13 @@ std::vector<CtPtr> Evaluator::rotate_add_batch(const std::vector<CtPtr>& vin, in
     std::vector<char> done(vin.size(), 0);
     for (size_t first = 0; first < vin.size(); ++first) {
         if (done[first]) continue;
+        if (vin[first]->npoly != 2) throw Error(FHELIN_ERR_STATE, "rotate: ciphertext must have 2 components");
         std::vector<size_t> idx;
         for (size_t i = first; i < vin.size() && (int)idx.size() < batch_limit; ++i) {
             const CtPtr &a = vin[first], &b = vin[i];
-            if (!done[i] && b->npoly == 2 && a->npoly == 2 && b->ell == a->ell && b->deg == a->deg &&
-                fabsl(b->scale / a->scale - 1.0L) < 1e-9L)
+            if (!done[i] && b->npoly == 2 && b->ell == a->ell && b->deg == a->deg && fabsl(b->scale / a->scale - 1.0L) < 1e-9L)
                 idx.push_back(i);
         }
-        if (vin[first]->npoly != 2) throw Error(FHELIN_ERR_STATE, "rotate: ciphertext must have 2 components");
         std::vector<CtPtr> chunk;
         for (size_t i : idx) chunk.push_back(vin[i]);
         chunk = make_contiguous(chunk);
@@ -216,7 +212,7 @@ std::vector<CtPtr> Evaluator::rotate_add_batch(const std::vector<CtPtr>& vin, in
         const size_t pn = (size_t)ell * c_.N, ctw = 2 * pn;
         std::vector<CtPtr> o = new_ct_batch(B, 2, ell, chunk[0]->deg, chunk[0]->scale, chunk[0]->slots);
         const u64* base = chunk[0]->d;  // contiguous by construction (or a single ciphertext)
-        keyswitch_batch(B, base + pn, ctw, ell, *it->second, o[0]->d, ctw, base, nullptr, ctw, map, base, ctw);
+        keyswitch_batch(B, base + pn, ctw, ell, *it->second, o[0]->d, ctw, base, nullptr, ctw, map, accumulate ? base : nullptr, ctw);
         for (int b = 0; b < B; ++b) {
             o[b]->scale = vin[idx[b]]->scale;
             out[idx[b]] = o[b];

@@ -93,6 +93,7 @@ public:
     // batched leveled ops over independent ciphertexts of identical (level, degree, scale): one launch set per op
     std::vector<CtPtr> rotate_add_batch(const std::vector<CtPtr>& v, int index);   // v_i + rot(v_i, index)
     std::vector<CtPtr> rotate_batch(const std::vector<CtPtr>& v, int index);
+    std::vector<CtPtr> rotate_batch_impl(const std::vector<CtPtr>& v, int index, bool accumulate);
     std::vector<CtPtr> mult_plain_batch(const std::vector<CtPtr>& v, const PtPtr& p);
 
     // ---- leveled ops (functional: inputs are never modified)
