@@ -153,10 +153,14 @@ CtPtr Evaluator::raw_rescale(const CtPtr& a) {
     const size_t N = c_.N;
     hipStream_t s = c_.stream;
     u64* last = c_.dalloc<u64>((size_t)P * N);
-    for (int p = 0; p < P; ++p)
-        hip_check(hipMemcpyAsync(last + p * N, a->d + ((size_t)p * ell + ell - 1) * N, N * 8, hipMemcpyDeviceToDevice, s), "rescale copy");
     c_.stats.rescale += 1;
-    c_.ntt(LimbBatch{last, P, nullptr, ell - 1, 1}, true);
+    {
+        // INTT of the last limb of every polynomial, read in place (stride = one polynomial), written densely
+        LimbBatch lb{last, P, nullptr, ell - 1, 1, a->d + (size_t)(ell - 1) * N};
+        lb.src_group = 1;
+        lb.src_group_stride = (size_t)ell * N;
+        c_.ntt(lb, true);
+    }
     u64* lifted = c_.dalloc<u64>((size_t)P * (ell - 1) * N);
     launch_rescale_lift(c_.dt, lifted, last, P, ell, c_.d_qlmod + (size_t)(ell - 1) * (c_.L + 1), s);
     c_.ntt(LimbBatch{lifted, P * (ell - 1), nullptr, 0, ell - 1}, false);
@@ -222,10 +226,69 @@ std::vector<CtPtr> Evaluator::rotate_batch_impl(const std::vector<CtPtr>& vin, i
     return out;
 }
 
+// rescale of many ciphertexts of identical shape as ONE polynomial batch [2B][ell][N] (K5 kernels are per polynomial)
+std::vector<CtPtr> Evaluator::rescale_batch(const std::vector<CtPtr>& vin) {
+    std::vector<CtPtr> out(vin.size());
+    std::vector<char> done(vin.size(), 0);
+    for (size_t first = 0; first < vin.size(); ++first) {
+        if (done[first]) continue;
+        std::vector<size_t> idx;
+        for (size_t i = first; i < vin.size() && (int)idx.size() < batch_limit; ++i)
+            if (!done[i] && vin[i]->npoly == 2 && vin[first]->npoly == 2 && vin[i]->ell == vin[first]->ell) idx.push_back(i);
+        if (idx.size() < 2) {
+            out[first] = rescale(vin[first]);
+            done[first] = 1;
+            continue;
+        }
+        std::vector<CtPtr> chunk;
+        for (size_t i : idx) chunk.push_back(vin[i]);
+        chunk = make_contiguous(chunk);
+        const int B = (int)chunk.size(), ell = chunk[0]->ell, P = 2 * B;
+        if (ell < 2) throw Error(FHELIN_ERR_STATE, "rescale: no limb left to drop");
+        const size_t N = c_.N;
+        hipStream_t s = c_.stream;
+        const u64* base = chunk[0]->d;
+        u64* last = c_.dalloc<u64>((size_t)P * N);
+        c_.stats.rescale += (u64)B;
+        LimbBatch lb{last, P, nullptr, ell - 1, 1, base + (size_t)(ell - 1) * N};
+        lb.src_group = 1;
+        lb.src_group_stride = (size_t)ell * N;
+        c_.ntt(lb, true);
+        u64* lifted = c_.dalloc<u64>((size_t)P * (ell - 1) * N);
+        launch_rescale_lift(c_.dt, lifted, last, P, ell, c_.d_qlmod + (size_t)(ell - 1) * (c_.L + 1), s);
+        c_.ntt(LimbBatch{lifted, P * (ell - 1), nullptr, 0, ell - 1}, false);
+        std::vector<CtPtr> o = new_ct_batch(B, 2, ell - 1, 1, 0, chunk[0]->slots);
+        launch_rescale_finish(c_.dt, o[0]->d, base, lifted, P, ell, c_.d_qlinv + (size_t)(ell - 1) * (c_.L + 1) * 2, s);
+        launch_ok("rescale_batch");
+        c_.pool.free(last);
+        c_.pool.free(lifted);
+        for (int b = 0; b < B; ++b) {
+            const CtPtr& a = vin[idx[b]];
+            o[b]->scale = a->scale / (long double)c_.chain.q[ell - 1];
+            o[b]->deg = a->deg > 1 ? a->deg - 1 : 1;
+            out[idx[b]] = o[b];
+            done[idx[b]] = 1;
+        }
+    }
+    return out;
+}
+
 std::vector<CtPtr> Evaluator::mult_plain_batch(const std::vector<CtPtr>& vin, const PtPtr& p) {
     if (vin.empty()) return {};
-    std::vector<CtPtr> x;
-    for (const CtPtr& c : vin) x.push_back(c->deg >= 2 ? rescale(c) : c);
+    std::vector<CtPtr> x = vin;
+    {
+        std::vector<CtPtr> need;
+        std::vector<size_t> pos;
+        for (size_t i = 0; i < vin.size(); ++i)
+            if (vin[i]->deg >= 2) {
+                need.push_back(vin[i]);
+                pos.push_back(i);
+            }
+        if (!need.empty()) {
+            std::vector<CtPtr> r = rescale_batch(need);
+            for (size_t k = 0; k < pos.size(); ++k) x[pos[k]] = r[k];
+        }
+    }
     bool uniform = true;
     for (const CtPtr& c : x) uniform = uniform && c->npoly == 2 && c->ell == x[0]->ell && c->deg == x[0]->deg;
     if (!uniform) {

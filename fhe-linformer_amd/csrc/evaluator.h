@@ -95,6 +95,7 @@ public:
     std::vector<CtPtr> rotate_batch(const std::vector<CtPtr>& v, int index);
     std::vector<CtPtr> rotate_batch_impl(const std::vector<CtPtr>& v, int index, bool accumulate);
     std::vector<CtPtr> mult_plain_batch(const std::vector<CtPtr>& v, const PtPtr& p);
+    std::vector<CtPtr> rescale_batch(const std::vector<CtPtr>& v);
 
     // ---- leveled ops (functional: inputs are never modified)
     CtPtr add(const CtPtr& a, const CtPtr& b);
