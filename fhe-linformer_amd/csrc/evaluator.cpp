@@ -132,7 +132,7 @@ void Evaluator::keyswitch_batch(int B, const u64* c_ntt, size_t c_stride, int el
     c_.ntt(eb, false, B * (lt.beta * nt - ell));
     u64* accQ = c_.dalloc<u64>((size_t)B * 2 * ell * N);
     u64* accP = c_.dalloc<u64>((size_t)B * 2 * K * N);
-    launch_ks_inner(c_.dt, sh, accQ, accP, ext, key.d, s);
+    launch_ks_inner(c_.dt, sh, accQ, accP, ext, key.d, c_ntt, s);
     c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
     u64* conv = c_.dalloc<u64>((size_t)B * 2 * ell * N);
     launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);

@@ -41,11 +41,12 @@ struct KsShape {
     size_t post_stride = 0;  // post-add operand
 };
 // K6: cc [ell][N] coefficient form, c_ntt [ell][N] NTT form -> ext [beta][ell+k][N]
-//     (own-digit slots receive c_ntt, the others the fast-basis-extended values in coefficient form)
+//     (own-digit slots stay unused — K7 reads c_ntt there; the others get the fast-basis-extended values, coefficient form)
 void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const u64* cc, const u64* c_ntt, const u64* hatinv,
                        const u64* hatmod, hipStream_t s);
 // K7: accQ [2][ell][N], accP [2][k][N] <- sum_j ext[j][t] * evk[j][comp][limb(t)]
-void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* evk, hipStream_t s);
+void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* evk, const u64* c_ntt,
+                     hipStream_t s);
 // K8a: accP coefficient form [2][k][N] -> conv [2][ell][N] (coefficient form)
 void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
                          hipStream_t s);

@@ -27,7 +27,7 @@ __device__ __forceinline__ Barrett load_barrett(const DeviceTables& t, int limb)
     return b;
 }
 
-constexpr int TCH = 4;  // targets per block: (ell+k)/TCH blocks in z keep >2000 workgroups in flight at every level
+constexpr int TCH = 8;  // targets per block: every z-chunk re-reads the digit's source limbs, so fewer/larger chunks cut traffic
 
 // grid (N/256, beta, ceil((ell+k)/TCH))
 template <int MAXA>
@@ -55,10 +55,7 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
     u64* dst = ext + (size_t)j * nt * N + n;
     const int t0 = blockIdx.z * TCH, t1 = min(nt, t0 + TCH);
     for (int tt = t0; tt < t1; ++tt) {
-        if (tt >= lo && tt < lo + cnt) {
-            dst[(size_t)tt * N] = c_ntt[(size_t)tt * N + n];
-            continue;
-        }
+        if (tt >= lo && tt < lo + cnt) continue;  // own-digit slots: the inner product reads c (NTT form) directly
         const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
         const Barrett br = load_barrett(t, limb);
         u64 slo = 0, shi = 0;
@@ -79,11 +76,13 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
 
 // grid (N/512, ell + k)
 __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape sh, u64* accQ, u64* accP, const u64* ext,
-                                                       const u64* evk) {
+                                                       const u64* evk, const u64* c_ntt) {
     const int nt = sh.ell + sh.k;
     const int bi = blockIdx.y / nt, tt = blockIdx.y % nt;
     const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
     ext += (size_t)bi * sh.beta * nt * ((size_t)1 << t.log_n);
+    c_ntt += (size_t)bi * sh.c_stride;
+    const int own = tt < sh.ell ? tt / sh.alpha : -1;  // the digit that contains target limb tt (its slot in ext is unused)
     accQ += (size_t)bi * 2 * sh.ell * ((size_t)1 << t.log_n);
     accP += (size_t)bi * 2 * sh.k * ((size_t)1 << t.log_n);
     const Barrett br = load_barrett(t, limb);
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
         Acc30 b0 = {0, 0, 0}, b1 = {0, 0, 0}, a0 = {0, 0, 0}, a1 = {0, 0, 0};
         const int j1 = min(sh.beta, j0 + 8);
         for (int j = j0; j < j1; ++j) {
-            const u64x2 d = E[((size_t)j * nt + tt) * row + n2];
+            const u64x2 d = j == own ? reinterpret_cast<const u64x2*>(c_ntt)[(size_t)tt * row + n2] : E[((size_t)j * nt + tt) * row + n2];
             const u64x2 kb = K[(size_t)(2 * j) * kstride + (size_t)limb * row + n2];
             const u64x2 ka = K[(size_t)(2 * j + 1) * kstride + (size_t)limb * row + n2];
             u32 dx0, dx1, dy0, dy1, k0, k1;
@@ -228,9 +227,10 @@ void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const
     else
         hipLaunchKernelGGL((modup_conv_kernel<16>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod);
 }
-void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* evk, hipStream_t s) {
+void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* evk, const u64* c_ntt,
+                     hipStream_t s) {
     dim3 g((1u << t.log_n) / 512, (unsigned)(sh.batch * (sh.ell + sh.k)));
-    hipLaunchKernelGGL(ks_inner_kernel, g, dim3(256), 0, s, t, sh, accQ, accP, ext, evk);
+    hipLaunchKernelGGL(ks_inner_kernel, g, dim3(256), 0, s, t, sh, accQ, accP, ext, evk, c_ntt);
 }
 void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
                          hipStream_t s) {
