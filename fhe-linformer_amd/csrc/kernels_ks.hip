@@ -27,7 +27,7 @@ __device__ __forceinline__ Barrett load_barrett(const DeviceTables& t, int limb)
     return b;
 }
 
-constexpr int TCH = 8;  // targets per block: every z-chunk re-reads the digit's source limbs, so fewer/larger chunks cut traffic
+constexpr int TCH = 16; // targets per block: every z-chunk re-reads the digit's source limbs, so fewer/larger chunks cut traffic
 
 // grid (N/256, beta, ceil((ell+k)/TCH))
 template <int MAXA>
