@@ -91,8 +91,8 @@ int fhelin_ctx_set_stream(fhelin_ctx* c, void* hip_stream) {
     FHELIN_TRY
     c->ctx.require_device();
     c->ctx.sync();
-    if (c->ctx.own_stream && c->ctx.stream) hip_check(hipStreamDestroy(c->ctx.stream), "hipStreamDestroy");
-    c->ctx.stream = (hipStream_t)hip_stream;
+    if (c->ctx.own_stream && c->ctx.main_stream) hip_check(hipStreamDestroy(c->ctx.main_stream), "hipStreamDestroy");
+    c->ctx.stream = c->ctx.main_stream = (hipStream_t)hip_stream;
     c->ctx.own_stream = false;
     FHELIN_CATCH
 }

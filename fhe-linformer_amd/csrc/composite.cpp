@@ -125,21 +125,37 @@ CtPtr Composite::repeat(const CtPtr& in, int slots, int padding) {
     return n ? r : ev_.clone(in);
 }
 
-CtVec Composite::rotsum_batch(const CtVec& in, int slots, int padding) {
-    CtVec r = in;
+// log-tree rotate-and-add over independent rows.  Rows are cut into chunks of `batch_limit`; every chunk runs its
+// whole chain (one batched key switch per step) on its own lane, so chunks overlap on the GPU.
+CtVec Composite::tree_batch(const CtVec& in, int slots, int step_sign, int padding) {
     const int n = log_steps(slots);
-    for (int i = 0; i < n; ++i) r = ev_.rotate_add_batch(r, padding * (1 << i));
-    if (!n) for (auto& c : r) c = ev_.clone(c);
-    return r;
+    CtVec out(in.size());
+    if (!n) {
+        for (size_t i = 0; i < in.size(); ++i) out[i] = ev_.clone(in[i]);
+        return out;
+    }
+    Context& c = ev_.ctx();
+    const size_t B = (size_t)std::max(1, ev_.batch_limit);
+    const bool lanes = c.n_lanes > 0 && in.size() > B;
+    if (lanes) c.fork_lanes();
+    int k = 0;
+    for (size_t lo = 0; lo < in.size(); lo += B, ++k) {
+        const size_t hi = std::min(in.size(), lo + B);
+        CtVec r(in.begin() + lo, in.begin() + hi);
+        if (lanes) {
+            Context::LaneScope scope(c, 1 + k % c.n_lanes);
+            for (int i = 0; i < n; ++i) r = ev_.rotate_add_batch(r, padding * step_sign * (1 << i));
+        } else {
+            for (int i = 0; i < n; ++i) r = ev_.rotate_add_batch(r, padding * step_sign * (1 << i));
+        }
+        std::copy(r.begin(), r.end(), out.begin() + lo);
+    }
+    if (lanes) c.join_lanes();
+    return out;
 }
 
-CtVec Composite::repeat_batch(const CtVec& in, int slots, int padding) {
-    CtVec r = in;
-    const int n = log_steps(slots);
-    for (int i = 0; i < n; ++i) r = ev_.rotate_add_batch(r, padding * -(1 << i));
-    if (!n) for (auto& c : r) c = ev_.clone(c);
-    return r;
-}
+CtVec Composite::rotsum_batch(const CtVec& in, int slots, int padding) { return tree_batch(in, slots, +1, padding); }
+CtVec Composite::repeat_batch(const CtVec& in, int slots, int padding) { return tree_batch(in, slots, -1, padding); }
 
 CtPtr Composite::add_many(const CtVec& v) {
     if (v.empty()) throw Error(FHELIN_ERR_ARG, "add_many: empty vector");

@@ -40,6 +40,7 @@ public:
     // step: the evaluation key is read once per batch and every launch fills the GPU) — results are bit-identical
     CtVec rotsum_batch(const CtVec& in, int slots, int padding);
     CtVec repeat_batch(const CtVec& in, int slots, int padding);
+    CtVec tree_batch(const CtVec& in, int slots, int step_sign, int padding);
 
     // matmuls                                                                                 :869-1058
     CtVec matmul_pt(const CtVec& rows, const PtPtr& w, const PtPtr& bias, int slots, int padding);   // RE / CR with plaintext weight

@@ -1,6 +1,7 @@
 #include "context.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace fhelin {
@@ -11,17 +12,19 @@ void hip_check(hipError_t e, const char* what) {
 
 // ---------------------------------------------------------------- DevicePool
 DevicePool::~DevicePool() {
-    for (auto& kv : idle_) (void)hipFree(kv.second);
+    for (auto& lane : idle_)
+        for (auto& kv : lane) (void)hipFree(kv.second);
     for (auto& kv : live_) (void)hipFree(kv.first);
 }
 void* DevicePool::alloc(size_t bytes) {
     if (bytes == 0) bytes = 256;
     bytes = (bytes + 255) & ~size_t(255);
-    auto it = idle_.find(bytes);
+    auto& idle = idle_[cur_lane];
+    auto it = idle.find(bytes);
     void* p = nullptr;
-    if (it != idle_.end()) {
+    if (it != idle.end()) {
         p = it->second;
-        idle_.erase(it);
+        idle.erase(it);
     } else {
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
@@ -30,24 +33,25 @@ void* DevicePool::alloc(size_t bytes) {
         }
         reserved_ += bytes;
     }
-    live_[p] = bytes;
+    live_[p] = Live{bytes, cur_lane};
     return p;
 }
 void DevicePool::free(void* p) {
     if (!p) return;
     auto it = live_.find(p);
     if (it == live_.end()) throw Error(FHELIN_ERR_STATE, "DevicePool::free of unknown pointer");
-    idle_.emplace(it->second, p);
+    idle_[it->second.lane].emplace(it->second.bytes, p);  // back to the lane (stream) that owns it
     live_.erase(it);
 }
 void DevicePool::trim() {
-    if (idle_.empty()) return;
     (void)hipDeviceSynchronize();
-    for (auto& kv : idle_) {
-        (void)hipFree(kv.second);
-        reserved_ -= kv.first;
+    for (auto& lane : idle_) {
+        for (auto& kv : lane) {
+            (void)hipFree(kv.second);
+            reserved_ -= kv.first;
+        }
+        lane.clear();
     }
-    idle_.clear();
 }
 
 // ---------------------------------------------------------------- Context
@@ -105,7 +109,18 @@ Context::Context(const Params& p) : prm(p) {
     if (p.device >= ndev) throw Error(FHELIN_ERR_ARG, "device index out of range");
     hip_check(hipSetDevice(p.device), "hipSetDevice");
     hip_check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+    main_stream = stream;
     own_stream = true;
+    {
+        int want = 2;
+        if (const char* e = std::getenv("FHELIN_LANES")) want = std::atoi(e);
+        n_lanes = std::max(0, std::min(want, DevicePool::MAX_LANES - 1));
+        for (int k = 1; k <= n_lanes; ++k) {
+            hip_check(hipStreamCreateWithFlags(&lane_stream[k], hipStreamNonBlocking), "hipStreamCreate(lane)");
+            hip_check(hipEventCreateWithFlags(&lane_event[k], hipEventDisableTiming), "hipEventCreate(lane)");
+        }
+        hip_check(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming), "hipEventCreate(fork)");
+    }
     hip_check(hipEventCreate(&ev_start), "hipEventCreate");
     hip_check(hipEventCreate(&ev_stop), "hipEventCreate");
     has_device = true;
@@ -206,9 +221,14 @@ Context::~Context() {
         (void)hipSetDevice(prm.device);
         (void)hipDeviceSynchronize();
         for (void* p : table_allocs) (void)hipFree(p);
+        for (int k = 1; k <= n_lanes; ++k) {
+            if (lane_event[k]) (void)hipEventDestroy(lane_event[k]);
+            if (lane_stream[k]) (void)hipStreamDestroy(lane_stream[k]);
+        }
+        if (fork_event) (void)hipEventDestroy(fork_event);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
-        if (own_stream && stream) (void)hipStreamDestroy(stream);
+        if (own_stream && main_stream) (void)hipStreamDestroy(main_stream);
     }
 }
 
@@ -220,6 +240,18 @@ void Context::require_device() const {
 void Context::sync() {
     require_device();
     hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+}
+
+void Context::fork_lanes() {
+    hip_check(hipEventRecord(fork_event, main_stream), "hipEventRecord(fork)");
+    for (int k = 1; k <= n_lanes; ++k) hip_check(hipStreamWaitEvent(lane_stream[k], fork_event, 0), "hipStreamWaitEvent(fork)");
+}
+
+void Context::join_lanes() {
+    for (int k = 1; k <= n_lanes; ++k) {
+        hip_check(hipEventRecord(lane_event[k], lane_stream[k]), "hipEventRecord(lane)");
+        hip_check(hipStreamWaitEvent(main_stream, lane_event[k], 0), "hipStreamWaitEvent(join)");
+    }
 }
 
 u64 Context::galois_element(int r) const {

@@ -38,18 +38,22 @@ struct Error : std::runtime_error {
 
 void hip_check(hipError_t e, const char* what);
 
-// Size-bucketed caching allocator on one device/stream (all work is stream-ordered on Context::stream,
-// so a freed block can be handed out again immediately).
+// Size-bucketed caching allocator.  Work is stream-ordered, so a freed block can be handed out again immediately —
+// to the SAME stream.  With several lanes (streams) every block belongs to the lane that allocated it and only
+// that lane's idle list gets it back (Context::LaneScope orders lane streams against the main stream).
 class DevicePool {
 public:
+    static constexpr int MAX_LANES = 5;  // lane 0 = main stream
     ~DevicePool();
     void* alloc(size_t bytes);
     void free(void* p);
     void trim();
     size_t bytes_reserved() const { return reserved_; }
+    int cur_lane = 0;
 private:
-    std::unordered_map<void*, size_t> live_;
-    std::multimap<size_t, void*> idle_;
+    struct Live { size_t bytes; int lane; };
+    std::unordered_map<void*, Live> live_;
+    std::multimap<size_t, void*> idle_[MAX_LANES];
     size_t reserved_ = 0;
 };
 
@@ -88,8 +92,28 @@ struct Context {
     std::vector<long double> sf_real; // FLEXIBLEAUTO real scaling factor per level (0 = fresh)
 
     bool has_device = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // the CURRENT stream: main stream, or a lane's stream inside a LaneScope
+    hipStream_t main_stream = nullptr;
     bool own_stream = false;
+    // worker lanes: independent chunks of a batched op (rows of a matmul) run on different streams so that the
+    // VALU-bound NTT passes of one chunk overlap the bandwidth-bound conversion / inner-product kernels of another
+    int n_lanes = 0;
+    hipStream_t lane_stream[DevicePool::MAX_LANES] = {};
+    hipEvent_t lane_event[DevicePool::MAX_LANES] = {};
+    hipEvent_t fork_event = nullptr;
+    void fork_lanes();              // lanes wait for everything enqueued on the main stream so far
+    void join_lanes();              // the main stream waits for every lane
+    struct LaneScope {              // route launches and allocations to lane k (1-based) until destruction
+        Context& c;
+        LaneScope(Context& ctx, int k) : c(ctx) {
+            c.stream = c.lane_stream[k];
+            c.pool.cur_lane = k;
+        }
+        ~LaneScope() {
+            c.stream = c.main_stream;
+            c.pool.cur_lane = 0;
+        }
+    };
     DevicePool pool;
     DeviceTables dt{};
     std::vector<void*> table_allocs;
