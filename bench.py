@@ -226,7 +226,10 @@ def main():
         x_last = samples[-1][0]
         ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, *pf.client_inputs(w, x_last)))
         err = float(np.max(np.abs(logits[-1] - ref)))
-        assert err < 5e-2 and int(np.argmax(logits[-1])) == int(np.argmax(ref)), f"encrypted logits differ from the circuit oracle ({err})"
+        top2 = np.sort(ref)[-2:]
+        decided = (top2[1] - top2[0]) > 4e-2           # arg-max is only meaningful when the oracle's margin exceeds the tolerance
+        assert err < 2e-2, f"encrypted logits differ from the circuit oracle ({err})"
+        assert not decided or int(np.argmax(logits[-1])) == int(np.argmax(ref)), "encrypted prediction differs from the circuit oracle"
         fwd = {"elapsed": elapsed, "stats": stats, "logit_err_vs_circuit_oracle": err, "pred": int(np.argmax(logits[-1]))}
         for _, enc in samples:
             del enc
