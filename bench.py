@@ -74,8 +74,8 @@ def host_cpus():
 def micro(fa):
     eng = fa.Engine("toy", device=0)
     names = ["v_mul_lo_u32 x8", "v_mul_hi_u32 x8", "v_mad_u64_u32 x8", "harvey butterfly x4", "v_fma_f64 x64",
-             "add_u64 x8", "mulhi64 x8", "mullo64 x8"]
-    per_iter = [8, 8, 8, 4, 64, 8, 8, 8]
+             "add_u64 x8", "mulhi64 x8", "mullo64 x8", "lazy butterfly (approx quotient, no csub) x4", "harvey butterfly (variable twiddle) x4"]
+    per_iter = [8, 8, 8, 4, 64, 8, 8, 8, 4, 4]
     blocks, iters = 256 * 8, 2048
     out = {}
     for v, (nm, k) in enumerate(zip(names, per_iter)):
@@ -83,8 +83,20 @@ def micro(fa):
         ops = blocks * 256 * iters * k
         out[nm] = {"ms": round(ms, 4), "Gop_s": round(ops / ms / 1e6, 1),
                    "ops_per_clk_per_CU@2.4GHz": round(ops / (ms * 1e-3) / 2.4e9 / 256, 2)}
+    # pure issue rates (asm, 16 independent instructions per trip); "slots" = 4-cycle SIMD issue slots per instruction
+    kinds = ["v_mov_b32", "v_add_u32", "v_lshl_add_u64", "v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32",
+             "v_sub_co+s_nop1+v_subb_co (pair)", "v_cndmask_b32", "v_add3_u32", "v_xor_b32", "v_lshrrev_b64",
+             "v_mad_u32_u24", "v_mul_hi_u32/v_mad_u64_u32 alternating", "v_cndmask_b32_e64 (sgpr mask)", "v_cmp_gt_u64_e64",
+             "v_ashrrev_i32", "v_and_b32", "v_min_u32", "v_sub_co_u32 (sgpr carry out)", "v_add_co_u32 (vcc)", "v_addc_co_u32 (vcc chain)",
+             "v_cndmask_b32_e32 (vcc, no clobber)", "v_bfi_b32", "v_max_u32"]
+    per = [16, 16, 16, 16, 16, 16, 8] + [16] * 17
+    issue = {}
+    for k, (nm, n) in enumerate(zip(kinds, per)):
+        ms = min(eng.microbench(100 + k, iters, blocks) for _ in range(3))
+        ops = blocks * 256 * iters * n
+        issue[nm] = {"ms": round(ms, 4), "ops_per_clk_per_CU@2.4GHz": round(ops / (ms * 1e-3) / 2.4e9 / 256, 2)}
     eng.close()
-    print(json.dumps({"micro": out}))
+    print(json.dumps({"micro": out, "issue": issue}))
 
 
 def ntt_section(eng, orc, np, batch, steps, warmup=3):

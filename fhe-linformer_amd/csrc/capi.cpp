@@ -189,7 +189,7 @@ int fhelin_microbench(fhelin_ctx* c, int32_t variant, int32_t iters, int32_t blo
     FHELIN_TRY
     Context& x = c->ctx;
     x.require_device();
-    if (variant < 0 || variant > 7 || iters < 1 || blocks < 1) throw Error(FHELIN_ERR_ARG, "bad microbench arguments");
+    if (variant < 0 || (variant > 9 && (variant < 100 || variant > 123)) || iters < 1 || blocks < 1) throw Error(FHELIN_ERR_ARG, "bad microbench arguments");
     u64* out = x.dalloc<u64>((size_t)blocks * 256);
     launch_mulbench(out, 8, variant, blocks, x.stream);  // warm
     hip_check(hipEventRecord(x.ev_start, x.stream), "hipEventRecord");

@@ -127,14 +127,21 @@ Context::Context(const Params& p) : prm(p) {
 
     const int nl = (int)moduli.size();
     {
-        std::vector<u64> bar(2 * nl), ninv(4 * nl);
+        std::vector<u64> bar(2 * nl), ninv(8 * nl, 0);
         for (int i = 0; i < nl; ++i) {
             bar[2 * i] = barrett[i].r0;
             bar[2 * i + 1] = barrett[i].r1;
-            ninv[4 * i] = tw[i].n_inv;
-            ninv[4 * i + 1] = tw[i].n_inv_s;
-            ninv[4 * i + 2] = tw[i].w1_n_inv;
-            ninv[4 * i + 3] = tw[i].w1_n_inv_s;
+            ninv[8 * i] = tw[i].n_inv;
+            ninv[8 * i + 1] = tw[i].n_inv_s;
+            ninv[8 * i + 2] = tw[i].w1_n_inv;
+            ninv[8 * i + 3] = tw[i].w1_n_inv_s;
+            // lazy NTT path (kernels_ntt.hip reduce_lazy_2q): shift = bits(q) - 10, ratio = floor(2^(bits(q)+22) / q)
+            int bits = 0;
+            while (bits < 64 && (moduli[i] >> bits)) ++bits;
+            if (bits > 20 && bits <= 53) {
+                ninv[8 * i + 4] = (u64)(bits - 10);
+                ninv[8 * i + 5] = (u64)((((u128)1) << (bits + 22)) / moduli[i]);
+            }
         }
         dt.log_n = p.log_n;
         dt.n_limbs = nl;

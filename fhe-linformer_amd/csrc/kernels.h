@@ -33,7 +33,7 @@ struct DeviceTables {
     const u64* barrett;    // [n_limbs][2]  (r0, r1) of floor(2^128/q)
     const u64* tw_fwd;     // [n_limbs][2N]  (w, w') pairs, bit-reversed powers of psi
     const u64* tw_inv;     // [n_limbs][2N]  same for psi^{-1}
-    const u64* ninv;       // [n_limbs][4]   N^{-1}, shoup, ipsi_br[1]*N^{-1}, shoup
+    const u64* ninv;       // [n_limbs][8]   N^{-1}, shoup, ipsi_br[1]*N^{-1}, shoup, lazy shift, lazy ratio, 0, 0
 };
 
 // K1: negacyclic NTT (natural -> bit-reversed) / INTT (bit-reversed -> natural, scaled by N^{-1}).

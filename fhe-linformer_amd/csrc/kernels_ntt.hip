@@ -37,7 +37,7 @@ struct NttArgs {
     const u64* src;     // input of this pass (== data when in place)
     const u64* tw;      // [n_limbs][2N]
     const u64* moduli;  // [n_limbs]
-    const u64* ninv;    // [n_limbs][4]
+    const u64* ninv;    // [n_limbs][8]: N^-1 constants (4), lazy-reduction shift and ratio (2), spare (2)
     const int* limb_tab;
     int tab_len;
     int limb_first;
@@ -71,63 +71,109 @@ __device__ __forceinline__ int limb_of(const NttArgs& a, int vec) {
 
 typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
+// Per-limb constants of a block.
+struct LimbConst {
+    u64 q, q2;
+    u64 nq;   // 2^64 - q
+    u64 q5;   // 5q   (lazy path: upper bound of mul_shoup_lazy5)
+    u32 sh;   // lazy path: reduce_lazy_2q shift and ratio
+    u32 rr;
+};
+
+// Lazy path (q < 2^53).  No conditional subtraction inside the transform: the approximate-quotient Shoup product
+// returns T in [0,5q) for any 64-bit input, a forward butterfly maps (X, Y) -> (X + T, X + 5q - T), so the value bound
+// grows by 5q per stage: canonical input -> < (1 + 5*17)q = 86q < 2^60 after the 17 stages of N = 2^17.  The column
+// pass stores these lazy values; the row pass reduces once before its final store.
+//
 // Forward (Cooley-Tukey) stages for register-index bits KB_HI-1 .. KB_LO (descending).
 //   gbase : global index bit that register bit 0 of the window corresponds to
 //   hi    : the thread's global index bits above the window (index >> (gbase+4))
-template <int KB_LO, int KB_HI>
-__device__ __forceinline__ void fwd_round(u64 (&x)[16], const u64x2* __restrict__ tw, u64 q, u64 q2, int log_n,
+template <int KB, bool LAZY>
+__device__ __forceinline__ void fwd_stage(u64 (&x)[16], const u64x2* __restrict__ tw, const LimbConst& c, int log_n,
                                           int gbase, int hi) {
+    const int m = 1 << (log_n - (gbase + KB) - 1);
+    const int tbase = m + (hi << (3 - KB));
 #pragma unroll
-    for (int kb = KB_HI - 1; kb >= KB_LO; --kb) {
-        const int g = gbase + kb;
-        const int m = 1 << (log_n - g - 1);
-        const int tbase = m + (hi << (3 - kb));
-#pragma unroll
-        for (int k0 = 0; k0 < 16; ++k0) {
-            if (k0 & (1 << kb)) continue;
-            const int k1 = k0 | (1 << kb);
-            const u64x2 w = tw[tbase + (k0 >> (kb + 1))];
+    for (int k0 = 0; k0 < 16; ++k0) {
+        if (k0 & (1 << KB)) continue;
+        const int k1 = k0 | (1 << KB);
+        const u64x2 w = tw[tbase + (k0 >> (KB + 1))];
+        if (LAZY) {
+            const u64 X = x[k0];
+            const u64 T = mul_shoup_lazy5(x[k1], w.x, w.y, c.nq);
+            x[k0] = X + T;
+            x[k1] = X + c.q5 - T;
+        } else {
             u64 X = x[k0];
             const u64 Y = x[k1];
-            X = csub(X, q2);
-            const u64 T = mul_shoup_lazy(Y, w.x, w.y, q);
+            X = csub(X, c.q2);
+            const u64 T = mul_shoup_lazy(Y, w.x, w.y, c.q);
             x[k0] = X + T;
-            x[k1] = X - T + q2;
+            x[k1] = X - T + c.q2;
         }
     }
 }
+template <int KB_LO, int KB_HI, bool LAZY>
+__device__ __forceinline__ void fwd_round(u64 (&x)[16], const u64x2* __restrict__ tw, const LimbConst& c, int log_n,
+                                          int gbase, int hi) {
+    if constexpr (KB_LO < KB_HI) {
+        fwd_stage<KB_HI - 1, LAZY>(x, tw, c, log_n, gbase, hi);
+        fwd_round<KB_LO, KB_HI - 1, LAZY>(x, tw, c, log_n, gbase, hi);
+    }
+}
+
+// Lazy inverse stages: (X, Y) -> (X + Y, (X + B_s - Y) * w) with the product in [0,5q) and no conditional subtraction.
+// With inputs below c_s*q at stage s of a kernel, sums stay below 2*c_s*q, so c_{s+1} = max(2*c_s, 5) and B_s = c_s*q.
+// A kernel runs at most 9 stages from c_0 <= 2: c_8 = 640, every intermediate < 1280q < 2^64 for q < 2^53.
+constexpr int lazy_coef(int s, int c0) { return s == 0 ? c0 : 5 << (s - 1); }  // c0 <= 2
 
 // Inverse (Gentleman-Sande) stages for register-index bits KB_LO .. KB_HI-1 (ascending).
 // If LAST, the stage at bit KB_HI-1 is the final stage of the whole transform and carries N^{-1}.
-template <int KB_LO, int KB_HI, bool LAST>
-__device__ __forceinline__ void inv_round(u64 (&x)[16], const u64x2* __restrict__ tw, u64 q, u64 q2, int log_n,
+// Lazy path: S0 = stages of this kernel already done, C0 = bound coefficient of the kernel's input (see lazy_coef).
+template <int KB, bool FINAL, bool LAZY, int S, int C0>
+__device__ __forceinline__ void inv_stage(u64 (&x)[16], const u64x2* __restrict__ tw, const LimbConst& c, int log_n,
                                           int gbase, int hi, const u64* __restrict__ ninv) {
+    const int m = 1 << (log_n - (gbase + KB) - 1);
+    const int tbase = m + (hi << (3 - KB));
+    const u64 B = c.q * (u64)lazy_coef(S, C0);  // lazy path only
+    if constexpr (FINAL) {
+        const u64 ni = ninv[0], nis = ninv[1], wn = ninv[2], wns = ninv[3];
 #pragma unroll
-    for (int kb = KB_LO; kb < KB_HI; ++kb) {
-        const int g = gbase + kb;
-        const int m = 1 << (log_n - g - 1);
-        const int tbase = m + (hi << (3 - kb));
-        if (LAST && kb == KB_HI - 1) {
-            const u64 ni = ninv[0], nis = ninv[1], wn = ninv[2], wns = ninv[3];
-#pragma unroll
-            for (int k0 = 0; k0 < 16; ++k0) {
-                if (k0 & (1 << kb)) continue;
-                const int k1 = k0 | (1 << kb);
-                const u64 X = x[k0], Y = x[k1];
-                x[k0] = csub(mul_shoup_lazy(X + Y, ni, nis, q), q);
-                x[k1] = csub(mul_shoup_lazy(X - Y + q2, wn, wns, q), q);
-            }
-        } else {
-#pragma unroll
-            for (int k0 = 0; k0 < 16; ++k0) {
-                if (k0 & (1 << kb)) continue;
-                const int k1 = k0 | (1 << kb);
-                const u64x2 w = tw[tbase + (k0 >> (kb + 1))];
-                const u64 X = x[k0], Y = x[k1];
-                x[k0] = csub(X + Y, q2);
-                x[k1] = mul_shoup_lazy(X - Y + q2, w.x, w.y, q);
+        for (int k0 = 0; k0 < 16; ++k0) {
+            if (k0 & (1 << KB)) continue;
+            const int k1 = k0 | (1 << KB);
+            const u64 X = x[k0], Y = x[k1];
+            if (LAZY) {
+                x[k0] = csub(reduce_lazy_2q(mul_shoup_lazy5(X + Y, ni, nis, c.nq), c.q, c.sh, c.rr), c.q);
+                x[k1] = csub(reduce_lazy_2q(mul_shoup_lazy5(X + B - Y, wn, wns, c.nq), c.q, c.sh, c.rr), c.q);
+            } else {
+                x[k0] = csub(mul_shoup_lazy(X + Y, ni, nis, c.q), c.q);
+                x[k1] = csub(mul_shoup_lazy(X - Y + c.q2, wn, wns, c.q), c.q);
             }
         }
+    } else {
+#pragma unroll
+        for (int k0 = 0; k0 < 16; ++k0) {
+            if (k0 & (1 << KB)) continue;
+            const int k1 = k0 | (1 << KB);
+            const u64x2 w = tw[tbase + (k0 >> (KB + 1))];
+            const u64 X = x[k0], Y = x[k1];
+            if (LAZY) {
+                x[k0] = X + Y;
+                x[k1] = mul_shoup_lazy5(X + B - Y, w.x, w.y, c.nq);
+            } else {
+                x[k0] = csub(X + Y, c.q2);
+                x[k1] = mul_shoup_lazy(X - Y + c.q2, w.x, w.y, c.q);
+            }
+        }
+    }
+}
+template <int KB_LO, int KB_HI, bool LAST, bool LAZY, int S0 = 0, int C0 = 1>
+__device__ __forceinline__ void inv_round(u64 (&x)[16], const u64x2* __restrict__ tw, const LimbConst& c, int log_n,
+                                          int gbase, int hi, const u64* __restrict__ ninv) {
+    if constexpr (KB_LO < KB_HI) {
+        inv_stage<KB_LO, (LAST && KB_LO == KB_HI - 1), LAZY, S0, C0>(x, tw, c, log_n, gbase, hi, ninv);
+        inv_round<KB_LO + 1, KB_HI, LAST, LAZY, S0 + 1, C0>(x, tw, c, log_n, gbase, hi, ninv);
     }
 }
 
@@ -140,26 +186,35 @@ __device__ __forceinline__ void exchange(u64 (&x)[16], u64* lds, int tau, int p_
     for (int k = 0; k < 16; ++k) x[k] = lds[lds_slot(tile_index(tau, k, p_to))];
 }
 
+__device__ __forceinline__ LimbConst limb_const(const NttArgs& a, int limb) {
+    LimbConst c;
+    c.q = a.moduli[limb];
+    c.q2 = c.q << 1;
+    c.nq = 0 - c.q;
+    c.q5 = 5 * c.q;
+    c.sh = (u32)a.ninv[8 * limb + 4];
+    c.rr = (u32)a.ninv[8 * limb + 5];
+    return c;
+}
+// primes below 2^53 (the 52-bit scaling primes: most limbs) take the lazy path, the 55-bit first prime and the 60-bit
+// special primes the classic Harvey path; the choice is uniform per workgroup
+#if defined(FHELIN_NTT_FORCE_PATH)  // ISA inspection builds only (tools/isa_count.py): 1 = lazy, 0 = classic
+__device__ __forceinline__ bool lazy_prime(u64) { return FHELIN_NTT_FORCE_PATH; }
+#else
+__device__ __forceinline__ bool lazy_prime(u64 q) { return q < (1ull << 53) && q > (1ull << 20); }
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // pass A: column transforms over the high A bits of the index.  Tile = 2^A rows x CW columns.
 // tile-local index e = (row << LOGCW) | col ; global index j = (row << 8) | (tile*CW + col).
 // ------------------------------------------------------------------------------------------------
-template <int A, bool INVERSE>
-__global__ __launch_bounds__(256) void ntt_cols_kernel(NttArgs a) {
+template <int A, bool INVERSE, bool LAZY>
+__device__ __forceinline__ void cols_body(const NttArgs& a, u64* lds, int vec, int tile, int limb, const LimbConst& c) {
     constexpr int LOGCW = 12 - A;
     constexpr int CW = 1 << LOGCW;
-    constexpr int LOGTILES = A - 4;
     constexpr int LOGN = A + 8;
     constexpr int NFULL = A / 4;
     constexpr int REM = A % 4;
-    __shared__ u64 lds[LDS_WORDS];
-
-    const int vec = blockIdx.x >> LOGTILES;
-    const int tile = blockIdx.x & ((1 << LOGTILES) - 1);
-    const int limb = limb_of(a, vec);
-    if (limb < 0) return;
-    const u64 q = a.moduli[limb];
-    const u64 q2 = q << 1;
     const u64x2* tw = reinterpret_cast<const u64x2*>(a.tw) + ((size_t)limb << LOGN);
     u64* base = a.data + ((size_t)vec << LOGN) + tile * CW;
     const u64* sbase = a.src + src_offset(a, vec, LOGN) + tile * CW;
@@ -174,56 +229,116 @@ __global__ __launch_bounds__(256) void ntt_cols_kernel(NttArgs a) {
         constexpr int P0 = LOGCW + A - 4;
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = sbase[goff(tile_index(tau, k, P0))];
-        fwd_round<0, 4>(x, tw, q, q2, LOGN, 8 + P0 - LOGCW, tau >> P0);
+        fwd_round<0, 4, LAZY>(x, tw, c, LOGN, 8 + P0 - LOGCW, tau >> P0);
         int p_prev = P0;
         if constexpr (NFULL >= 2) {
             constexpr int P1 = LOGCW + A - 8;
             exchange(x, lds, tau, p_prev, P1, false);
-            fwd_round<0, 4>(x, tw, q, q2, LOGN, 8 + P1 - LOGCW, tau >> P1);
+            fwd_round<0, 4, LAZY>(x, tw, c, LOGN, 8 + P1 - LOGCW, tau >> P1);
             p_prev = P1;
         }
         if constexpr (REM > 0) {
             constexpr int PR = LOGCW;
             exchange(x, lds, tau, p_prev, PR, NFULL >= 2);
-            fwd_round<0, REM>(x, tw, q, q2, LOGN, 8, tau >> PR);
+            fwd_round<0, REM, LAZY>(x, tw, c, LOGN, 8, tau >> PR);
             p_prev = PR;
         }
+        // lazy path: values up to (1 + 5A)q go to memory as they are; the row pass bounds and reduces them
+        constexpr int PL = REM > 0 ? LOGCW : (NFULL >= 2 ? LOGCW + A - 8 : P0);
+        (void)p_prev;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) base[goff(tile_index(tau, k, p_prev))] = x[k];
+        for (int k = 0; k < 16; ++k) base[goff(tile_index(tau, k, PL))] = x[k];
     } else {
-        // inverse: bottom up.  full rounds at LOGCW, LOGCW+4, ...; remainder = top REM bits of the window at 8
-        const u64* ninv = a.ninv + 4 * limb;
+        // inverse: bottom up.  full rounds at LOGCW, LOGCW+4, ...; remainder = top REM bits of the window at 8.
+        // lazy path: the row pass hands over values below 2q (C0 = 2)
+        const u64* ninv = a.ninv + 8 * limb;
         constexpr int P0 = LOGCW;
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = sbase[goff(tile_index(tau, k, P0))];
-        inv_round<0, 4, (NFULL == 1 && REM == 0)>(x, tw, q, q2, LOGN, 8, tau >> P0, ninv);
+        inv_round<0, 4, (NFULL == 1 && REM == 0), LAZY, 0, 2>(x, tw, c, LOGN, 8, tau >> P0, ninv);
         int p_prev = P0;
         if constexpr (NFULL >= 2) {
             constexpr int P1 = LOGCW + 4;
             exchange(x, lds, tau, p_prev, P1, false);
-            inv_round<0, 4, (REM == 0)>(x, tw, q, q2, LOGN, 8 + 4, tau >> P1, ninv);
+            inv_round<0, 4, (REM == 0), LAZY, 4, 2>(x, tw, c, LOGN, 8 + 4, tau >> P1, ninv);
             p_prev = P1;
         }
         if constexpr (REM > 0) {
             constexpr int PR = 8;  // window covers tile bits 8..11; its top REM bits are still to do
             exchange(x, lds, tau, p_prev, PR, NFULL >= 2);
-            inv_round<4 - REM, 4, true>(x, tw, q, q2, LOGN, 8 + PR - LOGCW, tau >> PR, ninv);
+            inv_round<4 - REM, 4, true, LAZY, 4 * NFULL, 2>(x, tw, c, LOGN, 8 + PR - LOGCW, tau >> PR, ninv);
             p_prev = PR;
         }
+        constexpr int PL = REM > 0 ? 8 : (NFULL >= 2 ? LOGCW + 4 : P0);
+        (void)p_prev;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) base[goff(tile_index(tau, k, p_prev))] = x[k];
+        for (int k = 0; k < 16; ++k) base[goff(tile_index(tau, k, PL))] = x[k];
     }
+}
+
+template <int A, bool INVERSE>
+__global__ __launch_bounds__(256) void ntt_cols_kernel(NttArgs a) {
+    constexpr int LOGTILES = A - 4;
+    __shared__ u64 lds[LDS_WORDS];
+    const int vec = blockIdx.x >> LOGTILES;
+    const int tile = blockIdx.x & ((1 << LOGTILES) - 1);
+    const int limb = limb_of(a, vec);
+    if (limb < 0) return;
+    const LimbConst c = limb_const(a, limb);
+    if (lazy_prime(c.q))
+        cols_body<A, INVERSE, true>(a, lds, vec, tile, limb, c);
+    else
+        cols_body<A, INVERSE, false>(a, lds, vec, tile, limb, c);
 }
 
 // ------------------------------------------------------------------------------------------------
 // pass B: row transforms over the low 8 bits of the index.  Tile = 16 consecutive rows of 256
 // (4096 contiguous residues); tile-local index e == global index - tile*4096.
 // ------------------------------------------------------------------------------------------------
+template <bool INVERSE, bool LAZY>
+__device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, int tile, int limb, const LimbConst& c) {
+    const int log_n = a.log_n;
+    const u64x2* tw = reinterpret_cast<const u64x2*>(a.tw) + ((size_t)limb << log_n);
+    u64* base = a.data + ((size_t)vec << log_n) + ((size_t)tile << 12);
+    const u64* sbase = a.src + src_offset(a, vec, log_n) + ((size_t)tile << 12);
+    const int tau = threadIdx.x;
+    u64 x[16];
+
+    if (!INVERSE) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = sbase[tile_index(tau, k, 4)];
+        fwd_round<0, 4, LAZY>(x, tw, c, log_n, 4, (tile << 4) | (tau >> 4));
+        exchange(x, lds, tau, 4, 0, false);
+        fwd_round<0, 4, LAZY>(x, tw, c, log_n, 0, (tile << 8) | tau);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            x[k] = LAZY ? csub(reduce_lazy_2q(x[k], c.q, c.sh, c.rr), c.q) : csub(csub(x[k], c.q2), c.q);
+        // window at bit 0 leaves 16 consecutive residues per thread (128-byte lane stride); one more LDS exchange
+        // to the bit-8 window makes every store instruction a contiguous 512-byte wave access
+        exchange(x, lds, tau, 0, 8, true);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) base[tile_index(tau, k, 8)] = x[k];
+    } else {
+        // coalesced load through the bit-8 window, then an LDS exchange to the bit-0 window of the first GS round
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = sbase[tile_index(tau, k, 8)];
+        exchange(x, lds, tau, 8, 0, false);
+        inv_round<0, 4, false, LAZY, 0, 1>(x, tw, c, log_n, 0, (tile << 8) | tau, nullptr);
+        exchange(x, lds, tau, 0, 4, true);
+        inv_round<0, 4, false, LAZY, 4, 1>(x, tw, c, log_n, 4, (tile << 4) | (tau >> 4), nullptr);
+        if (LAZY) {  // sums have grown to < 640q: hand values below 2q to the column pass
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = reduce_lazy_2q(x[k], c.q, c.sh, c.rr);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) base[tile_index(tau, k, 4)] = x[k];
+    }
+}
+
 template <bool INVERSE>
 __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
     __shared__ u64 lds[LDS_WORDS];
-    const int log_n = a.log_n;
-    const int logtiles = log_n - 12;
+    const int logtiles = a.log_n - 12;
     // Block -> (vector, tile) map.  A row tile needs its own 4 KiB twiddle slice per (limb, tile); vectors of the same
     // limb (the two polys of a ciphertext, the rows of a batch) reuse it.  Blocks b and b+8 share an XCD (L2), so
     // each XCD gets a contiguous range of logical ids, ordered (limb, tile, repetition): the slice is fetched once
@@ -243,38 +358,11 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
     }
     const int limb = limb_of(a, vec);
     if (limb < 0) return;
-    const u64 q = a.moduli[limb];
-    const u64 q2 = q << 1;
-    const u64x2* tw = reinterpret_cast<const u64x2*>(a.tw) + ((size_t)limb << log_n);
-    u64* base = a.data + ((size_t)vec << log_n) + ((size_t)tile << 12);
-    const u64* sbase = a.src + src_offset(a, vec, log_n) + ((size_t)tile << 12);
-    const int tau = threadIdx.x;
-    u64 x[16];
-
-    if (!INVERSE) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = sbase[tile_index(tau, k, 4)];
-        fwd_round<0, 4>(x, tw, q, q2, log_n, 4, (tile << 4) | (tau >> 4));
-        exchange(x, lds, tau, 4, 0, false);
-        fwd_round<0, 4>(x, tw, q, q2, log_n, 0, (tile << 8) | tau);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = csub(csub(x[k], q2), q);
-        // window at bit 0 leaves 16 consecutive residues per thread (128-byte lane stride); one more LDS exchange
-        // to the bit-8 window makes every store instruction a contiguous 512-byte wave access
-        exchange(x, lds, tau, 0, 8, true);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) base[tile_index(tau, k, 8)] = x[k];
-    } else {
-        // coalesced load through the bit-8 window, then an LDS exchange to the bit-0 window of the first GS round
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = sbase[tile_index(tau, k, 8)];
-        exchange(x, lds, tau, 8, 0, false);
-        inv_round<0, 4, false>(x, tw, q, q2, log_n, 0, (tile << 8) | tau, nullptr);
-        exchange(x, lds, tau, 0, 4, true);
-        inv_round<0, 4, false>(x, tw, q, q2, log_n, 4, (tile << 4) | (tau >> 4), nullptr);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) base[tile_index(tau, k, 4)] = x[k];
-    }
+    const LimbConst c = limb_const(a, limb);
+    if (lazy_prime(c.q))
+        rows_body<INVERSE, true>(a, lds, vec, tile, limb, c);
+    else
+        rows_body<INVERSE, false>(a, lds, vec, tile, limb, c);
 }
 
 template <int A>

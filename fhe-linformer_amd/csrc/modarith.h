@@ -128,6 +128,54 @@ FHE_HD void acc30_flush(const Acc30& a, u64& lo, u64& hi) {
     lo = t;
 }
 
+#if defined(__HIPCC__)
+// ---- gfx950 multiply-add chains ---------------------------------------------------------------
+// The NTT is bound by VALU issue slots: what counts is the NUMBER of vector instructions per
+// butterfly.  v_mad_u64_u32 does a 32x32 multiply and a 64-bit add in one slot; chains of it (inline asm, so that
+// instruction selection cannot re-split them into v_mul_lo/v_mul_hi/v_add3 triples) carry the low words of the
+// Shoup product below.
+__device__ __forceinline__ u64 mad32(u32 a, u32 b, u64 c) {  // a*b + c (mod 2^64)
+    u64 d, cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ u64 mul32(u32 a, u32 b) {  // a*b
+    u64 d, cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(cy) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ u64 mad32s(u32 a, u32 sb, u64 c) {  // a*sb + c with sb wave-uniform (SGPR operand)
+    u64 d, cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "s"(sb), "v"(c));
+    return d;
+}
+// Shoup product with an APPROXIMATE quotient, for the lazy NTT path (primes below 2^53):
+//   h~ = x1*s1 + hi32(x0*s1) + hi32(x1*s0)  drops x0*s0 and the low words of the cross products, so
+//   h - 3 <= h~ <= h  with h = floor(x*ws/2^64), and  x*w - h~*q  lies in [0, 5q)  for ANY 64-bit x (5q < 2^64).
+// nq = 2^64 - q (wave-uniform).  11 vector instructions: 2 v_mul_hi_u32, 7 v_mad_u64_u32, 2 adds.
+__device__ __forceinline__ u64 mul_shoup_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), s0 = (u32)ws, s1 = (u32)(ws >> 32);
+    const u64 h = mad32(x1, s1, (u64)__umulhi(x0, s1)) + (u64)__umulhi(x1, s0);
+    const u32 w0 = (u32)w, w1 = (u32)(w >> 32), h0 = (u32)h, h1 = (u32)(h >> 32);
+    const u32 n0 = (u32)nq, n1 = (u32)(nq >> 32);
+    u64 c = mul32(x0, w1);  // cross terms: only their low 32 bits reach the result
+    c = mad32(x1, w0, c);
+    c = mad32s(h0, n1, c);
+    c = mad32s(h1, n0, c);
+    u64 r = mul32(x0, w0);
+    r = mad32s(h0, n0, r);
+    u32 rh;  // r += c << 32 touches the high word only (asm: keeps it one v_add_u32 instead of a 64-bit add)
+    asm("v_add_u32 %0, %1, %2" : "=v"(rh) : "v"((u32)(r >> 32)), "v"((u32)c));
+    return ((u64)rh << 32) | (u32)r;
+}
+// x mod q up to one q:  x < 2^(bits(q)+11)  ->  [0, 2q).   sh = bits(q) - 10,  rr = floor(2^(bits(q)+22) / q);
+// k~ = hi32((x >> sh) * rr) is floor(x/q) or one less (error terms < 2^-8).
+__device__ __forceinline__ u64 reduce_lazy_2q(u64 x, u64 q, u32 sh, u32 rr) {
+    const u32 k = __umulhi((u32)(x >> sh), rr);
+    return x - (u64)k * q;
+}
+#endif
+
 #if !defined(__HIP_DEVICE_COMPILE__)
 // ---- host-only helpers ------------------------------------------------------------------
 inline u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }

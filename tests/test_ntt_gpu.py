@@ -84,3 +84,26 @@ def test_ntt_linearity_full_size(engine_factory, orc):
     assert np.array_equal(orc.add(fa_, fb, eng.q), fs)
     for bf in bufs:
         bf.free()
+
+
+@pytest.mark.parametrize("preset", ["bench", "deep"])
+def test_ntt_extreme_patterns_full_size(engine_factory, orc, preset):
+    """Inputs that drive the lazy (no conditional subtraction) butterflies towards their value bounds: all residues
+    maximal, and maximal/zero alternations at the strides of the first, the tile-boundary and the last stage.
+    Forward and inverse, every limb kind (52-bit lazy path, 55-bit and 60-bit classic path), bit-exact vs the oracle."""
+    eng = engine_factory(preset)
+    n = eng.N
+    idx = np.arange(n)
+    pats = [np.ones(n, dtype=bool)] + [((idx // s) & 1).astype(bool) for s in (1, 16, 256, 4096, n // 2)]
+    for mods, psis, first in ((eng.q, eng.psi_q, 0), (eng.p, eng.psi_p, eng.n_q)):
+        mods = np.asarray(mods, dtype=np.uint64)
+        x = np.zeros((len(pats), len(mods), n), dtype=np.uint64)
+        for i, pat in enumerate(pats):
+            x[i] = np.where(pat[None, :], (mods - np.uint64(1))[:, None], np.uint64(0))
+        for inverse in (False, True):
+            buf = eng.upload(x)
+            eng.ntt(buf, x.shape[0] * x.shape[1], limb_first=first, limb_count=len(mods), inverse=inverse)
+            got = buf.download(x.shape)
+            want = orc.ntt_batch(x, mods, psis, inverse=inverse)
+            assert np.array_equal(got, want), f"first={first} inverse={inverse}"
+            buf.free()
