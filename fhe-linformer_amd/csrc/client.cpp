@@ -138,6 +138,12 @@ void ckks_fft_tables(int slots, std::vector<u32>& rot, std::vector<std::pair<dou
 }
 
 static void ld_to_i128(long double v, u64& lo, u64& hi) {
+    if (v > -9.0e18L && v < 9.0e18L) {  // fits 64 bits: same rounding (half away from zero), no 128-bit split
+        const long long r = llroundl(v);
+        lo = (u64)r;
+        hi = r < 0 ? ~0ull : 0;
+        return;
+    }
     const bool neg = v < 0;
     long double mag = roundl(fabsl(v));
     const long double two64 = 18446744073709551616.0L;
@@ -168,8 +174,7 @@ std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>
         ld_to_i128((long double)v[i].second * scale, coeffs[2 * (i * gap + N / 2)], coeffs[2 * (i * gap + N / 2) + 1]);
     }
     u64* dco = c.dalloc<u64>(2 * N);
-    hip_check(hipMemcpyAsync(dco, coeffs.data(), 2 * N * 8, hipMemcpyHostToDevice, c.stream), "encode upload");
-    hip_check(hipStreamSynchronize(c.stream), "encode sync");  // coeffs is pageable host memory
+    c.upload_async(dco, coeffs.data(), 2 * N);  // pinned staging: no stream drain (the GPU keeps its queue)
     auto e = std::make_shared<Encoding>();
     e->ctx = &c;
     e->ell = ell;
@@ -213,8 +218,7 @@ void Client::sample_small_to_ntt(u64* dst, int nlimbs_q, bool with_p, int kind) 
         co[2 * i + 1] = v < 0 ? ~0ull : 0;
     }
     u64* dco = c_.dalloc<u64>(2 * N);
-    hip_check(hipMemcpyAsync(dco, co.data(), 2 * N * 8, hipMemcpyHostToDevice, c_.stream), "sample upload");
-    hip_check(hipStreamSynchronize(c_.stream), "sample sync");
+    c_.upload_async(dco, co.data(), 2 * N);
     launch_reduce_i128(c_.dt, dst, dco, 0, nlimbs_q, c_.stream);
     launch_ntt(c_.dt, LimbBatch{dst, nlimbs_q, nullptr, 0, nlimbs_q}, false, c_.stream);
     if (with_p && c_.K > 0) {

@@ -80,6 +80,7 @@ Context::Context(const Params& p) : prm(p) {
     if (p.n_q < 1 || p.n_q > 64 || p.n_p < 0 || p.n_p > 16) throw Error(FHELIN_ERR_ARG, "bad limb counts");
     if (p.dnum < 1) throw Error(FHELIN_ERR_ARG, "dnum must be >= 1");
     if (p.first_bits > 60 || p.scale_bits > 60 || p.special_bits > 60) throw Error(FHELIN_ERR_ARG, "primes must be <= 60 bits");
+    if (p.first_bits < 20 || p.scale_bits < 20 || (p.n_p > 0 && p.special_bits < 20)) throw Error(FHELIN_ERR_ARG, "primes must be >= 20 bits");
     if (p.log_slots < 1 || p.log_slots > p.log_n - 1) throw Error(FHELIN_ERR_ARG, "log_slots out of range");
     N = 1 << p.log_n;
     L = p.n_q - 1;
@@ -122,6 +123,11 @@ Context::Context(const Params& p) : prm(p) {
         hip_check(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming), "hipEventCreate(fork)");
     }
     hip_check(hipEventCreate(&ev_start), "hipEventCreate");
+    stage_words = (size_t)2 << p.log_n;
+    for (int i = 0; i < STAGE_SLOTS; ++i) {
+        hip_check(hipHostMalloc(reinterpret_cast<void**>(&stage_buf[i]), stage_words * sizeof(u64), hipHostMallocDefault), "hipHostMalloc(stage)");
+        hip_check(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming), "hipEventCreate(stage)");
+    }
     hip_check(hipEventCreate(&ev_stop), "hipEventCreate");
     has_device = true;
 
@@ -135,10 +141,10 @@ Context::Context(const Params& p) : prm(p) {
             ninv[8 * i + 1] = tw[i].n_inv_s;
             ninv[8 * i + 2] = tw[i].w1_n_inv;
             ninv[8 * i + 3] = tw[i].w1_n_inv_s;
-            // lazy NTT path (kernels_ntt.hip reduce_lazy_2q): shift = bits(q) - 10, ratio = floor(2^(bits(q)+22) / q)
+            // NTT final reduction (modarith.h reduce_lazy_2q): shift = bits(q) - 10, ratio = floor(2^(bits(q)+22) / q)
             int bits = 0;
             while (bits < 64 && (moduli[i] >> bits)) ++bits;
-            if (bits > 20 && bits <= 53) {
+            if (bits >= 12 && bits <= 60) {
                 ninv[8 * i + 4] = (u64)(bits - 10);
                 ninv[8 * i + 5] = (u64)((((u128)1) << (bits + 22)) / moduli[i]);
             }
@@ -223,6 +229,17 @@ Context::Context(const Params& p) : prm(p) {
     }
 }
 
+void Context::upload_async(u64* dst, const u64* src, size_t words) {
+    if (words > stage_words) throw Error(FHELIN_ERR_INTERNAL, "upload_async: block larger than a staging slot");
+    const int i = stage_next;
+    stage_next = (stage_next + 1) % STAGE_SLOTS;
+    if (stage_used[i]) hip_check(hipEventSynchronize(stage_ev[i]), "hipEventSynchronize(stage)");
+    std::memcpy(stage_buf[i], src, words * sizeof(u64));
+    hip_check(hipMemcpyAsync(dst, stage_buf[i], words * sizeof(u64), hipMemcpyHostToDevice, stream), "hipMemcpyAsync(stage)");
+    hip_check(hipEventRecord(stage_ev[i], stream), "hipEventRecord(stage)");
+    stage_used[i] = true;
+}
+
 Context::~Context() {
     if (has_device) {
         (void)hipSetDevice(prm.device);
@@ -233,6 +250,10 @@ Context::~Context() {
             if (lane_stream[k]) (void)hipStreamDestroy(lane_stream[k]);
         }
         if (fork_event) (void)hipEventDestroy(fork_event);
+        for (int i = 0; i < STAGE_SLOTS; ++i) {
+            if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
+            if (stage_buf[i]) (void)hipHostFree(stage_buf[i]);
+        }
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
         if (own_stream && main_stream) (void)hipStreamDestroy(main_stream);

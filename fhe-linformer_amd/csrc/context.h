@@ -119,6 +119,17 @@ struct Context {
     std::vector<void*> table_allocs;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 
+    // Pinned staging ring for host->device uploads on the hot path (plaintext encodings, encryption randomness):
+    // the copy is queued on the current stream and the host does NOT wait for the stream to drain.  A slot is reused
+    // only after the event recorded behind its copy has completed.
+    static constexpr int STAGE_SLOTS = 8;
+    u64* stage_buf[STAGE_SLOTS] = {};
+    hipEvent_t stage_ev[STAGE_SLOTS] = {};
+    bool stage_used[STAGE_SLOTS] = {};
+    int stage_next = 0;
+    size_t stage_words = 0;
+    void upload_async(u64* dst, const u64* src, size_t words);  // words <= 2N
+
     // ModDown / rescale constants (level independent)
     const u64* d_phatinv = nullptr;  // [k][2]   (P/p)^{-1} mod p, shoup
     const u64* d_phatmod = nullptr;  // [k][L+1] (P/p) mod q_t

@@ -104,12 +104,10 @@ __device__ __forceinline__ void fwd_stage(u64 (&x)[16], const u64x2* __restrict_
             x[k0] = X + T;
             x[k1] = X + c.q5 - T;
         } else {
-            u64 X = x[k0];
-            const u64 Y = x[k1];
-            X = csub(X, c.q2);
-            const u64 T = mul_shoup_lazy(Y, w.x, w.y, c.q);
+            const u64 X = csub_mask(x[k0], c.q5);
+            const u64 T = mul_shoup_lazy5(x[k1], w.x, w.y, c.nq);
             x[k0] = X + T;
-            x[k1] = X - T + c.q2;
+            x[k1] = X + c.q5 - T;
         }
     }
 }
@@ -144,11 +142,11 @@ __device__ __forceinline__ void inv_stage(u64 (&x)[16], const u64x2* __restrict_
             const int k1 = k0 | (1 << KB);
             const u64 X = x[k0], Y = x[k1];
             if (LAZY) {
-                x[k0] = csub(reduce_lazy_2q(mul_shoup_lazy5(X + Y, ni, nis, c.nq), c.q, c.sh, c.rr), c.q);
-                x[k1] = csub(reduce_lazy_2q(mul_shoup_lazy5(X + B - Y, wn, wns, c.nq), c.q, c.sh, c.rr), c.q);
+                x[k0] = csub_mask(reduce_lazy_2q(mul_shoup_lazy5(X + Y, ni, nis, c.nq), c.q, c.sh, c.rr), c.q);
+                x[k1] = csub_mask(reduce_lazy_2q(mul_shoup_lazy5(X + B - Y, wn, wns, c.nq), c.q, c.sh, c.rr), c.q);
             } else {
-                x[k0] = csub(mul_shoup_lazy(X + Y, ni, nis, c.q), c.q);
-                x[k1] = csub(mul_shoup_lazy(X - Y + c.q2, wn, wns, c.q), c.q);
+                x[k0] = csub_mask(reduce_lazy_2q(mul_shoup_lazy5(X + Y, ni, nis, c.nq), c.q, c.sh, c.rr), c.q);
+                x[k1] = csub_mask(reduce_lazy_2q(mul_shoup_lazy5(X + c.q5 - Y, wn, wns, c.nq), c.q, c.sh, c.rr), c.q);
             }
         }
     } else {
@@ -162,8 +160,8 @@ __device__ __forceinline__ void inv_stage(u64 (&x)[16], const u64x2* __restrict_
                 x[k0] = X + Y;
                 x[k1] = mul_shoup_lazy5(X + B - Y, w.x, w.y, c.nq);
             } else {
-                x[k0] = csub(X + Y, c.q2);
-                x[k1] = mul_shoup_lazy(X - Y + c.q2, w.x, w.y, c.q);
+                x[k0] = csub_mask(X + Y, c.q5);
+                x[k1] = mul_shoup_lazy5(X + c.q5 - Y, w.x, w.y, c.nq);
             }
         }
     }
@@ -197,11 +195,11 @@ __device__ __forceinline__ LimbConst limb_const(const NttArgs& a, int limb) {
     return c;
 }
 // primes below 2^53 (the 52-bit scaling primes: most limbs) take the lazy path, the 55-bit first prime and the 60-bit
-// special primes the classic Harvey path; the choice is uniform per workgroup
+// special primes the semi-lazy path (one conditional subtraction per butterfly); the choice is uniform per workgroup
 #if defined(FHELIN_NTT_FORCE_PATH)  // ISA inspection builds only (tools/isa_count.py): 1 = lazy, 0 = classic
 __device__ __forceinline__ bool lazy_prime(u64) { return FHELIN_NTT_FORCE_PATH; }
 #else
-__device__ __forceinline__ bool lazy_prime(u64 q) { return q < (1ull << 53) && q > (1ull << 20); }
+__device__ __forceinline__ bool lazy_prime(u64 q) { return q < (1ull << 53); }
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -312,7 +310,7 @@ __device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, i
         fwd_round<0, 4, LAZY>(x, tw, c, log_n, 0, (tile << 8) | tau);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            x[k] = LAZY ? csub(reduce_lazy_2q(x[k], c.q, c.sh, c.rr), c.q) : csub(csub(x[k], c.q2), c.q);
+            x[k] = csub_mask(reduce_lazy_2q(x[k], c.q, c.sh, c.rr), c.q);   // from < 86q (lazy) or < 10q (semi-lazy)
         // window at bit 0 leaves 16 consecutive residues per thread (128-byte lane stride); one more LDS exchange
         // to the bit-8 window makes every store instruction a contiguous 512-byte wave access
         exchange(x, lds, tau, 0, 8, true);

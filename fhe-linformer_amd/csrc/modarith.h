@@ -168,6 +168,16 @@ __device__ __forceinline__ u64 mul_shoup_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
     asm("v_add_u32 %0, %1, %2" : "=v"(rh) : "v"((u32)(r >> 32)), "v"((u32)c));
     return ((u64)rh << 32) | (u32)r;
 }
+// Conditional subtraction without v_cndmask: x < 2m, m < 2^63 (so that x - m lies in [-m, m))  ->  x >= m ? x - m : x.
+// (Measured on gfx950, bench.py --micro: v_cndmask_b32 with a VCC mask issues ~5x slower than the other VALU ops, and the
+// compare + two selects of the usual form also serialise on VCC.)  The sign word comes from an asm v_ashrrev_i32 so
+// that instruction selection cannot turn the mask arithmetic back into selects.
+__device__ __forceinline__ u64 csub_mask(u64 x, u64 m) {
+    const u64 t = x - m;
+    u32 s;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(s) : "v"((u32)(t >> 32)));
+    return t + (m & (((u64)s << 32) | s));
+}
 // x mod q up to one q:  x < 2^(bits(q)+11)  ->  [0, 2q).   sh = bits(q) - 10,  rr = floor(2^(bits(q)+22) / q);
 // k~ = hi32((x >> sh) * rr) is floor(x/q) or one less (error terms < 2^-8).
 __device__ __forceinline__ u64 reduce_lazy_2q(u64 x, u64 q, u32 sh, u32 rr) {
