@@ -88,16 +88,30 @@ struct LimbConst {
 // Forward (Cooley-Tukey) stages for register-index bits KB_HI-1 .. KB_LO (descending).
 //   gbase : global index bit that register bit 0 of the window corresponds to
 //   hi    : the thread's global index bits above the window (index >> (gbase+4))
+// The (up to) 15 twiddles of one round, fetched as a block so that a kernel can issue the loads of its NEXT round before
+// the LDS exchange (their L2 latency then hides behind the barrier instead of sitting on the critical path).
+// Stage KB uses 8 >> KB twiddles, stored at t[(8 >> KB) - 1 ...].
+struct RoundTw {
+    u64x2 t[15];
+};
+template <int KB_LO, int KB_HI>
+__device__ __forceinline__ void load_round_tw(RoundTw& r, const u64x2* __restrict__ tw, int log_n, int gbase, int hi) {
+#pragma unroll
+    for (int kb = KB_LO; kb < KB_HI; ++kb) {
+        const int m = 1 << (log_n - (gbase + kb) - 1);
+        const int tbase = m + (hi << (3 - kb));
+#pragma unroll
+        for (int j = 0; j < (8 >> kb); ++j) r.t[(8 >> kb) - 1 + j] = tw[tbase + j];
+    }
+}
+
 template <int KB, bool LAZY>
-__device__ __forceinline__ void fwd_stage(u64 (&x)[16], const u64x2* __restrict__ tw, const LimbConst& c, int log_n,
-                                          int gbase, int hi) {
-    const int m = 1 << (log_n - (gbase + KB) - 1);
-    const int tbase = m + (hi << (3 - KB));
+__device__ __forceinline__ void fwd_stage(u64 (&x)[16], const RoundTw& tw, const LimbConst& c) {
 #pragma unroll
     for (int k0 = 0; k0 < 16; ++k0) {
         if (k0 & (1 << KB)) continue;
         const int k1 = k0 | (1 << KB);
-        const u64x2 w = tw[tbase + (k0 >> (KB + 1))];
+        const u64x2 w = tw.t[(8 >> KB) - 1 + (k0 >> (KB + 1))];
         if (LAZY) {
             const u64 X = x[k0];
             const u64 T = mul_shoup_lazy5(x[k1], w.x, w.y, c.nq);
@@ -112,11 +126,10 @@ __device__ __forceinline__ void fwd_stage(u64 (&x)[16], const u64x2* __restrict_
     }
 }
 template <int KB_LO, int KB_HI, bool LAZY>
-__device__ __forceinline__ void fwd_round(u64 (&x)[16], const u64x2* __restrict__ tw, const LimbConst& c, int log_n,
-                                          int gbase, int hi) {
+__device__ __forceinline__ void fwd_round(u64 (&x)[16], const RoundTw& tw, const LimbConst& c) {
     if constexpr (KB_LO < KB_HI) {
-        fwd_stage<KB_HI - 1, LAZY>(x, tw, c, log_n, gbase, hi);
-        fwd_round<KB_LO, KB_HI - 1, LAZY>(x, tw, c, log_n, gbase, hi);
+        fwd_stage<KB_HI - 1, LAZY>(x, tw, c);
+        fwd_round<KB_LO, KB_HI - 1, LAZY>(x, tw, c);
     }
 }
 
@@ -129,10 +142,7 @@ constexpr int lazy_coef(int s, int c0) { return s == 0 ? c0 : 5 << (s - 1); }  /
 // If LAST, the stage at bit KB_HI-1 is the final stage of the whole transform and carries N^{-1}.
 // Lazy path: S0 = stages of this kernel already done, C0 = bound coefficient of the kernel's input (see lazy_coef).
 template <int KB, bool FINAL, bool LAZY, int S, int C0>
-__device__ __forceinline__ void inv_stage(u64 (&x)[16], const u64x2* __restrict__ tw, const LimbConst& c, int log_n,
-                                          int gbase, int hi, const u64* __restrict__ ninv) {
-    const int m = 1 << (log_n - (gbase + KB) - 1);
-    const int tbase = m + (hi << (3 - KB));
+__device__ __forceinline__ void inv_stage(u64 (&x)[16], const RoundTw& tw, const LimbConst& c, const u64* __restrict__ ninv) {
     const u64 B = c.q * (u64)lazy_coef(S, C0);  // lazy path only
     if constexpr (FINAL) {
         const u64 ni = ninv[0], nis = ninv[1], wn = ninv[2], wns = ninv[3];
@@ -154,7 +164,7 @@ __device__ __forceinline__ void inv_stage(u64 (&x)[16], const u64x2* __restrict_
         for (int k0 = 0; k0 < 16; ++k0) {
             if (k0 & (1 << KB)) continue;
             const int k1 = k0 | (1 << KB);
-            const u64x2 w = tw[tbase + (k0 >> (KB + 1))];
+            const u64x2 w = tw.t[(8 >> KB) - 1 + (k0 >> (KB + 1))];
             const u64 X = x[k0], Y = x[k1];
             if (LAZY) {
                 x[k0] = X + Y;
@@ -167,11 +177,10 @@ __device__ __forceinline__ void inv_stage(u64 (&x)[16], const u64x2* __restrict_
     }
 }
 template <int KB_LO, int KB_HI, bool LAST, bool LAZY, int S0 = 0, int C0 = 1>
-__device__ __forceinline__ void inv_round(u64 (&x)[16], const u64x2* __restrict__ tw, const LimbConst& c, int log_n,
-                                          int gbase, int hi, const u64* __restrict__ ninv) {
+__device__ __forceinline__ void inv_round(u64 (&x)[16], const RoundTw& tw, const LimbConst& c, const u64* __restrict__ ninv) {
     if constexpr (KB_LO < KB_HI) {
-        inv_stage<KB_LO, (LAST && KB_LO == KB_HI - 1), LAZY, S0, C0>(x, tw, c, log_n, gbase, hi, ninv);
-        inv_round<KB_LO + 1, KB_HI, LAST, LAZY, S0 + 1, C0>(x, tw, c, log_n, gbase, hi, ninv);
+        inv_stage<KB_LO, (LAST && KB_LO == KB_HI - 1), LAZY, S0, C0>(x, tw, c, ninv);
+        inv_round<KB_LO + 1, KB_HI, LAST, LAZY, S0 + 1, C0>(x, tw, c, ninv);
     }
 }
 
@@ -227,18 +236,22 @@ __device__ __forceinline__ void cols_body(const NttArgs& a, u64* lds, int vec, i
         constexpr int P0 = LOGCW + A - 4;
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = sbase[goff(tile_index(tau, k, P0))];
-        fwd_round<0, 4, LAZY>(x, tw, c, LOGN, 8 + P0 - LOGCW, tau >> P0);
+        RoundTw rt, rn;
+        load_round_tw<0, 4>(rt, tw, LOGN, 8 + P0 - LOGCW, tau >> P0);
+        fwd_round<0, 4, LAZY>(x, rt, c);
         int p_prev = P0;
         if constexpr (NFULL >= 2) {
             constexpr int P1 = LOGCW + A - 8;
+            load_round_tw<0, 4>(rn, tw, LOGN, 8 + P1 - LOGCW, tau >> P1);
             exchange(x, lds, tau, p_prev, P1, false);
-            fwd_round<0, 4, LAZY>(x, tw, c, LOGN, 8 + P1 - LOGCW, tau >> P1);
+            fwd_round<0, 4, LAZY>(x, rn, c);
             p_prev = P1;
         }
         if constexpr (REM > 0) {
             constexpr int PR = LOGCW;
+            load_round_tw<0, REM>(rt, tw, LOGN, 8, tau >> PR);
             exchange(x, lds, tau, p_prev, PR, NFULL >= 2);
-            fwd_round<0, REM, LAZY>(x, tw, c, LOGN, 8, tau >> PR);
+            fwd_round<0, REM, LAZY>(x, rt, c);
             p_prev = PR;
         }
         // lazy path: values up to (1 + 5A)q go to memory as they are; the row pass bounds and reduces them
@@ -253,18 +266,22 @@ __device__ __forceinline__ void cols_body(const NttArgs& a, u64* lds, int vec, i
         constexpr int P0 = LOGCW;
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = sbase[goff(tile_index(tau, k, P0))];
-        inv_round<0, 4, (NFULL == 1 && REM == 0), LAZY, 0, 2>(x, tw, c, LOGN, 8, tau >> P0, ninv);
+        RoundTw rt, rn;
+        load_round_tw<0, 4>(rt, tw, LOGN, 8, tau >> P0);
+        inv_round<0, 4, (NFULL == 1 && REM == 0), LAZY, 0, 2>(x, rt, c, ninv);
         int p_prev = P0;
         if constexpr (NFULL >= 2) {
             constexpr int P1 = LOGCW + 4;
+            load_round_tw<0, 4>(rn, tw, LOGN, 8 + 4, tau >> P1);
             exchange(x, lds, tau, p_prev, P1, false);
-            inv_round<0, 4, (REM == 0), LAZY, 4, 2>(x, tw, c, LOGN, 8 + 4, tau >> P1, ninv);
+            inv_round<0, 4, (REM == 0), LAZY, 4, 2>(x, rn, c, ninv);
             p_prev = P1;
         }
         if constexpr (REM > 0) {
             constexpr int PR = 8;  // window covers tile bits 8..11; its top REM bits are still to do
+            load_round_tw<4 - REM, 4>(rt, tw, LOGN, 8 + PR - LOGCW, tau >> PR);
             exchange(x, lds, tau, p_prev, PR, NFULL >= 2);
-            inv_round<4 - REM, 4, true, LAZY, 4 * NFULL, 2>(x, tw, c, LOGN, 8 + PR - LOGCW, tau >> PR, ninv);
+            inv_round<4 - REM, 4, true, LAZY, 4 * NFULL, 2>(x, rt, c, ninv);
             p_prev = PR;
         }
         constexpr int PL = REM > 0 ? 8 : (NFULL >= 2 ? LOGCW + 4 : P0);
@@ -305,9 +322,12 @@ __device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, i
     if (!INVERSE) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = sbase[tile_index(tau, k, 4)];
-        fwd_round<0, 4, LAZY>(x, tw, c, log_n, 4, (tile << 4) | (tau >> 4));
+        RoundTw rt, rn;
+        load_round_tw<0, 4>(rt, tw, log_n, 4, (tile << 4) | (tau >> 4));
+        fwd_round<0, 4, LAZY>(x, rt, c);
+        load_round_tw<0, 4>(rn, tw, log_n, 0, (tile << 8) | tau);   // per-thread twiddles of the last four stages
         exchange(x, lds, tau, 4, 0, false);
-        fwd_round<0, 4, LAZY>(x, tw, c, log_n, 0, (tile << 8) | tau);
+        fwd_round<0, 4, LAZY>(x, rn, c);
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             x[k] = csub_mask(reduce_lazy_2q(x[k], c.q, c.sh, c.rr), c.q);   // from < 86q (lazy) or < 10q (semi-lazy)
@@ -320,10 +340,13 @@ __device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, i
         // coalesced load through the bit-8 window, then an LDS exchange to the bit-0 window of the first GS round
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = sbase[tile_index(tau, k, 8)];
+        RoundTw rt, rn;
+        load_round_tw<0, 4>(rt, tw, log_n, 0, (tile << 8) | tau);   // per-thread twiddles of the first four stages
         exchange(x, lds, tau, 8, 0, false);
-        inv_round<0, 4, false, LAZY, 0, 1>(x, tw, c, log_n, 0, (tile << 8) | tau, nullptr);
+        inv_round<0, 4, false, LAZY, 0, 1>(x, rt, c, nullptr);
+        load_round_tw<0, 4>(rn, tw, log_n, 4, (tile << 4) | (tau >> 4));
         exchange(x, lds, tau, 0, 4, true);
-        inv_round<0, 4, false, LAZY, 4, 1>(x, tw, c, log_n, 4, (tile << 4) | (tau >> 4), nullptr);
+        inv_round<0, 4, false, LAZY, 4, 1>(x, rn, c, nullptr);
         if (LAZY) {  // sums have grown to < 640q: hand values below 2q to the column pass
 #pragma unroll
             for (int k = 0; k < 16; ++k) x[k] = reduce_lazy_2q(x[k], c.q, c.sh, c.rr);
