@@ -94,6 +94,8 @@ def load_library():
         "fhelin_mult_plain": (i32, [vp, vp, vp, C.POINTER(vp)]),
         "fhelin_mult": (i32, [vp, vp, vp, C.POINTER(vp)]),
         "fhelin_rotate": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "fhelin_rotate_many": (i32, [vp, vp, C.POINTER(i32), i32, C.POINTER(vp)]),
+        "fhelin_rotate_each": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(vp)]),
         "fhelin_rescale": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_level_reduce": (i32, [vp, vp, i32, C.POINTER(vp)]),
         "fhelin_raw_rescale": (i32, [vp, vp, C.POINTER(vp)]),
@@ -333,6 +335,19 @@ class Engine:
 
     def rotate(self, a, index):
         return self._un(self.lib.fhelin_rotate, a, index)
+
+    def rotate_many(self, a, indices):
+        """hoisted rotations of one ciphertext (one ModUp, bit-identical to rotate(a, i) for every i)"""
+        idx = (C.c_int32 * len(indices))(*indices)
+        outs = self._outs(len(indices))
+        self._ck(self.lib.fhelin_rotate_many(self.h, a.h, idx, len(indices), outs))
+        return self._cts(outs, len(indices))
+
+    def rotate_each(self, v, indices):
+        idx = (C.c_int32 * len(indices))(*indices)
+        outs = self._outs(len(v))
+        self._ck(self.lib.fhelin_rotate_each(self.h, self._harr(v), idx, len(v), outs))
+        return self._cts(outs, len(v))
 
     def rescale(self, a):
         return self._un(self.lib.fhelin_rescale, a)

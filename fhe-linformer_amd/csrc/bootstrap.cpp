@@ -204,22 +204,30 @@ CtPtr Bootstrapper::mult_i(const CtPtr& x) {
 
 CtPtr Bootstrapper::apply(const LinStage& st, const CtPtr& xin) {
     CtPtr x = xin->deg >= 2 ? ev_.rescale(xin) : xin;
+    // baby steps: every rotation of x in ONE hoisted key switch (one ModUp of x, per-index inner product + ModDown)
+    std::vector<int> bidx;
+    for (const auto& t : st.terms)
+        if (std::find(bidx.begin(), bidx.end(), t.baby) == bidx.end()) bidx.push_back(t.baby);
+    std::vector<CtPtr> brot = ev_.rotate_many(x, bidx);
     std::map<int, CtPtr> babies;
-    babies[0] = x;
+    for (size_t i = 0; i < bidx.size(); ++i) babies[bidx[i]] = brot[i];
     std::map<int, CtPtr> inner;
     for (const auto& t : st.terms) {
-        auto it = babies.find(t.baby);
-        if (it == babies.end()) it = babies.emplace(t.baby, ev_.rotate(x, t.baby)).first;
-        CtPtr term = ev_.mult_plain(it->second, t.diag);
+        CtPtr term = ev_.mult_plain(babies[t.baby], t.diag);
         auto g = inner.find(t.giant);
         if (g == inner.end()) inner[t.giant] = term;
         else g->second = ev_.add(g->second, term);
     }
-    CtPtr out;
+    // giant steps: different inputs, different keys, same shape -> one batched key switch with per-row keys
+    std::vector<CtPtr> gin;
+    std::vector<int> gidx;
     for (auto& g : inner) {
-        CtPtr v = g.first ? ev_.rotate(g.second, g.first) : g.second;
-        out = out ? ev_.add(out, v) : v;
+        gin.push_back(g.second);
+        gidx.push_back(g.first);
     }
+    std::vector<CtPtr> grot = ev_.rotate_each(gin, gidx);
+    CtPtr out;
+    for (auto& v : grot) out = out ? ev_.add(out, v) : v;
     return out;
 }
 

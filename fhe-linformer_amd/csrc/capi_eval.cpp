@@ -179,6 +179,25 @@ int fhelin_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** 
     *out = wrap(c->ev.rotate(a->p, index));
     FHELIN_CATCH
 }
+int fhelin_rotate_many(fhelin_ctx* c, const fhelin_ct* a, const int32_t* indices, int32_t n, fhelin_ct** outs) {
+    NEED(c && a && indices && outs && n >= 0);
+    FHELIN_TRY
+    std::vector<CtPtr> r = c->ev.rotate_many(a->p, std::vector<int>(indices, indices + n));
+    for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
+    FHELIN_CATCH
+}
+int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* indices, int32_t n, fhelin_ct** outs) {
+    NEED(c && v && indices && outs && n >= 0);
+    FHELIN_TRY
+    std::vector<CtPtr> in;
+    for (int i = 0; i < n; ++i) {
+        if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext in array");
+        in.push_back(v[i]->p);
+    }
+    std::vector<CtPtr> r = c->ev.rotate_each(in, std::vector<int>(indices, indices + n));
+    for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
+    FHELIN_CATCH
+}
 int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY

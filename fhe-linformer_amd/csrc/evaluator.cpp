@@ -104,6 +104,20 @@ void Evaluator::keyswitch(const u64* c_ntt, int ell, const EvalKey& key, u64* ou
 void Evaluator::keyswitch_batch(int B, const u64* c_ntt, size_t c_stride, int ell, const EvalKey& key, u64* out, size_t out_stride,
                                 const u64* add0, const u64* add1, size_t add_stride, const u32* map, const u64* post,
                                 size_t post_stride) {
+    keyswitch_impl(B, nullptr, c_ntt, c_stride, ell, &key, out, out_stride, add0, add1, add_stride, map, post, post_stride);
+}
+
+void Evaluator::keyswitch_rows(const KsRows& rows, const u64* c_ntt, size_t c_stride, int ell, u64* out, size_t out_stride,
+                               const u64* add0, size_t add_stride) {
+    const int B = (int)rows.keys.size();
+    if (B < 1) return;
+    if (B > KsShape::MAX_ROWS || rows.maps.size() != rows.keys.size()) throw Error(FHELIN_ERR_ARG, "keyswitch_rows: bad row count");
+    keyswitch_impl(B, &rows, c_ntt, c_stride, ell, nullptr, out, out_stride, add0, nullptr, add_stride, nullptr, nullptr, 0);
+}
+
+void Evaluator::keyswitch_impl(int B, const KsRows* rows, const u64* c_ntt, size_t c_stride, int ell, const EvalKey* key, u64* out,
+                               size_t out_stride, const u64* add0, const u64* add1, size_t add_stride, const u32* map, const u64* post,
+                               size_t post_stride) {
     c_.require_device();
     if (c_.K < 1) throw Error(FHELIN_ERR_STATE, "hybrid key switching needs at least one special prime");
     if (B < 1) return;
@@ -112,27 +126,39 @@ void Evaluator::keyswitch_batch(int B, const u64* c_ntt, size_t c_stride, int el
     const LevelTables& lt = c_.lvl[ell];
     const int nt = ell + K;
     KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, c_stride, out_stride, add_stride, post_stride};
+    const bool shared = rows && rows->shared_input;
+    if (rows) {
+        sh.per_row = 1;
+        sh.shared_input = shared ? 1 : 0;
+        for (int b = 0; b < B; ++b) {
+            sh.evk_row[b] = rows->keys[b]->d;
+            sh.map_row[b] = rows->maps[b];
+        }
+    }
+    const int Bu = shared ? 1 : B;  // polynomials that go through ModUp
+    KsShape shu = sh;
+    shu.batch = Bu;
     hipStream_t s = c_.stream;
-    u64* cc = c_.dalloc<u64>((size_t)B * ell * N);
+    u64* cc = c_.dalloc<u64>((size_t)Bu * ell * N);
     c_.stats.keyswitch += (u64)B;
     c_.stats.keyswitch_limbs += (u64)B * ell;
     {
         // out of place: cc = INTT(c); the inputs of a batch are strided (c1 of consecutive ciphertexts)
-        LimbBatch ib{cc, B * ell, nullptr, 0, ell, c_ntt};
-        if (B > 1 && c_stride != (size_t)ell * N) {
+        LimbBatch ib{cc, Bu * ell, nullptr, 0, ell, c_ntt};
+        if (Bu > 1 && c_stride != (size_t)ell * N) {
             ib.src_group = ell;
             ib.src_group_stride = c_stride;
         }
         c_.ntt(ib, true);
     }
-    u64* ext = c_.dalloc<u64>((size_t)B * lt.beta * nt * N);
-    launch_modup_conv(c_.dt, sh, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod, s);
-    LimbBatch eb{ext, B * lt.beta * nt, lt.ext_limb_tab, 0, 1};
+    u64* ext = c_.dalloc<u64>((size_t)Bu * lt.beta * nt * N);
+    launch_modup_conv(c_.dt, shu, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod, s);
+    LimbBatch eb{ext, Bu * lt.beta * nt, lt.ext_limb_tab, 0, 1};
     eb.tab_len = lt.beta * nt;
-    c_.ntt(eb, false, B * (lt.beta * nt - ell));
+    c_.ntt(eb, false, Bu * (lt.beta * nt - ell));
     u64* accQ = c_.dalloc<u64>((size_t)B * 2 * ell * N);
     u64* accP = c_.dalloc<u64>((size_t)B * 2 * K * N);
-    launch_ks_inner(c_.dt, sh, accQ, accP, ext, key.d, c_ntt, s);
+    launch_ks_inner(c_.dt, sh, accQ, accP, ext, key ? key->d : nullptr, c_ntt, s);
     c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
     u64* conv = c_.dalloc<u64>((size_t)B * 2 * ell * N);
     launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
@@ -144,6 +170,94 @@ void Evaluator::keyswitch_batch(int B, const u64* c_ntt, size_t c_stride, int el
     c_.pool.free(accQ);
     c_.pool.free(accP);
     c_.pool.free(conv);
+}
+
+// hoisted rotations of one ciphertext.  A rotation here is KeySwitch_{s -> sigma^-1(s)}(c1) + c0 followed by the NTT-domain
+// automorphism gather in the ModDown epilogue, so the ModUp of c1 does not depend on the rotation index: it is computed
+// once and every index runs only its own inner product + ModDown.  Bit-identical to rotate(a, i).
+std::vector<CtPtr> Evaluator::rotate_many(const CtPtr& a, const std::vector<int>& indices) {
+    if (a->npoly != 2) throw Error(FHELIN_ERR_STATE, "rotate: ciphertext must have 2 components");
+    const int ns = a->slots > 0 ? a->slots : (1 << c_.prm.log_slots);
+    std::vector<CtPtr> out(indices.size());
+    std::vector<size_t> todo;
+    for (size_t i = 0; i < indices.size(); ++i) {
+        if (indices[i] % ns == 0) out[i] = a;
+        else todo.push_back(i);
+    }
+    const size_t pn = (size_t)a->ell * c_.N, ctw = 2 * pn;
+    for (size_t first = 0; first < todo.size(); first += KsShape::MAX_ROWS) {
+        const int B = (int)std::min(todo.size() - first, (size_t)KsShape::MAX_ROWS);
+        if (B == 1) {
+            out[todo[first]] = rotate(a, indices[todo[first]]);
+            continue;
+        }
+        KsRows rows;
+        rows.shared_input = true;
+        for (int b = 0; b < B; ++b) {
+            const int index = indices[todo[first + b]];
+            const u64 g = c_.galois_element(index);
+            auto it = rot_keys.find(g);
+            if (it == rot_keys.end())
+                throw Error(FHELIN_ERR_KEY, "no rotation key for index " + std::to_string(index) + " (EvalRotateKeyGen list)");
+            rows.keys.push_back(it->second.get());
+            rows.maps.push_back(c_.automorph_map(g));
+        }
+        std::vector<CtPtr> o = new_ct_batch(B, 2, a->ell, a->deg, a->scale, a->slots);
+        keyswitch_rows(rows, a->d + pn, 0, a->ell, o[0]->d, ctw, a->d, 0);
+        for (int b = 0; b < B; ++b) out[todo[first + b]] = o[b];
+    }
+    return out;
+}
+
+std::vector<CtPtr> Evaluator::rotate_each(const std::vector<CtPtr>& vin, const std::vector<int>& indices) {
+    if (vin.size() != indices.size()) throw Error(FHELIN_ERR_ARG, "rotate_each: one index per ciphertext");
+    std::vector<CtPtr> out(vin.size());
+    std::vector<char> done(vin.size(), 0);
+    for (size_t first = 0; first < vin.size(); ++first) {
+        if (done[first]) continue;
+        const CtPtr& a = vin[first];
+        if (a->npoly != 2) throw Error(FHELIN_ERR_STATE, "rotate: ciphertext must have 2 components");
+        const int ns = a->slots > 0 ? a->slots : (1 << c_.prm.log_slots);
+        if (indices[first] % ns == 0) {
+            out[first] = clone(a);
+            done[first] = 1;
+            continue;
+        }
+        std::vector<size_t> idx;
+        for (size_t i = first; i < vin.size() && (int)idx.size() < std::min(batch_limit, (int)KsShape::MAX_ROWS); ++i) {
+            const CtPtr& b = vin[i];
+            if (!done[i] && indices[i] % ns != 0 && b->npoly == 2 && b->ell == a->ell && b->deg == a->deg &&
+                fabsl(b->scale / a->scale - 1.0L) < 1e-9L)
+                idx.push_back(i);
+        }
+        if (idx.size() < 2) {
+            out[first] = rotate(a, indices[first]);
+            done[first] = 1;
+            continue;
+        }
+        std::vector<CtPtr> chunk;
+        KsRows rows;
+        for (size_t i : idx) {
+            chunk.push_back(vin[i]);
+            const u64 g = c_.galois_element(indices[i]);
+            auto it = rot_keys.find(g);
+            if (it == rot_keys.end())
+                throw Error(FHELIN_ERR_KEY, "no rotation key for index " + std::to_string(indices[i]) + " (EvalRotateKeyGen list)");
+            rows.keys.push_back(it->second.get());
+            rows.maps.push_back(c_.automorph_map(g));
+        }
+        chunk = make_contiguous(chunk);
+        const int B = (int)chunk.size();
+        const size_t pn = (size_t)a->ell * c_.N, ctw = 2 * pn;
+        std::vector<CtPtr> o = new_ct_batch(B, 2, a->ell, a->deg, a->scale, a->slots);
+        keyswitch_rows(rows, chunk[0]->d + pn, ctw, a->ell, o[0]->d, ctw, chunk[0]->d, ctw);
+        for (int b = 0; b < B; ++b) {
+            o[b]->scale = vin[idx[b]]->scale;
+            out[idx[b]] = o[b];
+            done[idx[b]] = 1;
+        }
+    }
+    return out;
 }
 
 // ------------------------------------------------------------------------------------------------ raw ops

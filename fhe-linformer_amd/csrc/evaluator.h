@@ -90,6 +90,19 @@ public:
     // the same for `batch` independent polynomials laid out with the given element strides
     void keyswitch_batch(int batch, const u64* c_ntt, size_t c_stride, int ell, const EvalKey& key, u64* out, size_t out_stride,
                          const u64* add0, const u64* add1, size_t add_stride, const u32* map, const u64* post, size_t post_stride);
+    // rows with their own evaluation key / automorphism map; shared_input: all rows key-switch the SAME polynomial
+    // (c_stride ignored, ModUp done once).  At most KsShape::MAX_ROWS rows.
+    struct KsRows {
+        std::vector<const EvalKey*> keys;
+        std::vector<const u32*> maps;
+        bool shared_input = false;
+    };
+    void keyswitch_rows(const KsRows& rows, const u64* c_ntt, size_t c_stride, int ell, u64* out, size_t out_stride, const u64* add0,
+                        size_t add_stride);
+    // hoisted rotations: rot(a, i) for every i in `indices` with ONE ModUp of a (results identical to rotate(a, i))
+    std::vector<CtPtr> rotate_many(const CtPtr& a, const std::vector<int>& indices);
+    // rot(v[i], indices[i]) for ciphertexts of identical shape, one batched key switch per chunk of rows
+    std::vector<CtPtr> rotate_each(const std::vector<CtPtr>& v, const std::vector<int>& indices);
     // batched leveled ops over independent ciphertexts of identical (level, degree, scale): one launch set per op
     std::vector<CtPtr> rotate_add_batch(const std::vector<CtPtr>& v, int index);   // v_i + rot(v_i, index)
     std::vector<CtPtr> rotate_batch(const std::vector<CtPtr>& v, int index);
@@ -128,6 +141,9 @@ public:
 
 private:
     Context& c_;
+    void keyswitch_impl(int batch, const KsRows* rows, const u64* c_ntt, size_t c_stride, int ell, const EvalKey* key, u64* out,
+                        size_t out_stride, const u64* add0, const u64* add1, size_t add_stride, const u32* map, const u64* post,
+                        size_t post_stride);
     CtPtr cheb_recurse(const std::vector<double>& c, const std::vector<CtPtr>& T, const std::map<int, CtPtr>& G, int baby);
     void match(const CtPtr& a, const CtPtr& b, CtPtr& ao, CtPtr& bo);
 };

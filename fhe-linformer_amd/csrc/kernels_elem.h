@@ -39,6 +39,14 @@ struct KsShape {
     size_t out_stride = 0;   // output [2][ell][N]
     size_t add_stride = 0;   // add0 / add1
     size_t post_stride = 0;  // post-add operand
+    // Rows that rotate by different amounts: per-row evaluation keys and automorphism maps (per_row = 1), and rows
+    // that all extend the SAME input polynomial (shared_input = 1: hoisted rotations — ModUp runs once, the digits
+    // are reused by every row's inner product).
+    static constexpr int MAX_ROWS = 16;
+    int per_row = 0;
+    int shared_input = 0;
+    const u64* evk_row[MAX_ROWS] = {};
+    const u32* map_row[MAX_ROWS] = {};
 };
 // K6: cc [ell][N] coefficient form, c_ntt [ell][N] NTT form -> ext [beta][ell+k][N]
 //     (own-digit slots stay unused — K7 reads c_ntt there; the others get the fast-basis-extended values, coefficient form)

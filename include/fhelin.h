@@ -124,6 +124,11 @@ int fhelin_add_plain(fhelin_ctx* c, const fhelin_ct* a, const fhelin_pt* p, fhel
 int fhelin_mult_plain(fhelin_ctx* c, const fhelin_ct* a, const fhelin_pt* p, fhelin_ct** out);   /* EvalMult(ct,pt)  :427 */
 int fhelin_mult(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b, fhelin_ct** out);         /* EvalMult(ct,ct)  :431 */
 int fhelin_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** out);            /* EvalRotate       :435,:833,:843 */
+/* hoisted rotations: outs[i] = EvalRotate(a, indices[i]) for all i with ONE decomposition of a (OpenFHE's
+ * EvalFastRotationPrecompute + EvalFastRotation pair); the results are bit-identical to n calls of fhelin_rotate */
+int fhelin_rotate_many(fhelin_ctx* c, const fhelin_ct* a, const int32_t* indices, int32_t n, fhelin_ct** outs);
+/* outs[i] = EvalRotate(v[i], indices[i]): rows of identical (level, degree, scale) share one batched key switch */
+int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* indices, int32_t n, fhelin_ct** outs);
 int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);                          /* ModReduce (implicit in :427/:431) */
 int fhelin_level_reduce(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhelin_ct** out);
 

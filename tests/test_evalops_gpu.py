@@ -107,3 +107,29 @@ def test_rotation_composition_full_size(engine_factory, orc):
     r3 = eng.raw_rotate(c, 3).export()
     assert np.array_equal(r12, r3)
     assert not r3[1].any()
+
+
+@pytest.mark.parametrize("preset,ell,rots", [("toy13", 5, [1, -2, 3, 0, 64]), ("bench", 17, list(range(1, 19)))])
+def test_hoisted_and_per_row_rotations_bit_exact(engine_factory, orc, preset, ell, rots):
+    """rotate_many (one ModUp shared by all indices) and rotate_each (different inputs, different keys, one batched key
+    switch) against the oracle's plain rotation: hoisting must not change a single residue.  18 indices at N=2^16 also
+    cross the 16-row chunk limit of the kernel arguments."""
+    eng = engine_factory(preset)
+    evks = {}
+    for r in rots:
+        if r % (eng.N // 2) == 0:
+            continue
+        evks[r] = _evk(orc, eng, 7000 + 13 * r)
+        eng.key_import(1, r, evks[r])
+    x = _ct(orc, eng, 4242, ell)
+    cx = eng.ct_import(x)
+    want = {r: (x if r not in evks else orc.rotate(x, evks[r], orc.galois(eng.log_n, r), eng.alpha, eng.q, eng.p, eng.psi_q, eng.psi_p))
+            for r in rots}
+    got = eng.rotate_many(cx, rots)
+    for r, g in zip(rots, got):
+        assert np.array_equal(g.export(), want[r]), ("rotate_many", preset, r)
+    ys = [_ct(orc, eng, 4300 + i, ell) for i in range(len(rots))]
+    got = eng.rotate_each([eng.ct_import(y) for y in ys], rots)
+    for r, y, g in zip(rots, ys, got):
+        w = y if r not in evks else orc.rotate(y, evks[r], orc.galois(eng.log_n, r), eng.alpha, eng.q, eng.p, eng.psi_q, eng.psi_p)
+        assert np.array_equal(g.export(), w), ("rotate_each", preset, r)
