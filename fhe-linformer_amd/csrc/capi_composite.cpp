@@ -11,11 +11,11 @@ static fhelin_ct* wrap(const CtPtr& p) {
     h->p = p;
     return h;
 }
-static CtVec vec_of(const fhelin_ct* const* v, int n) {
+static CtVec vec_of(fhelin_ctx* c, const fhelin_ct* const* v, int n) {
     CtVec out;
     for (int i = 0; i < n; ++i) {
         if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext handle in array");
-        out.push_back(v[i]->p);
+        out.push_back(ct_in(c, v[i]));
     }
     return out;
 }
@@ -29,18 +29,18 @@ extern "C" {
 int fhelin_fc_mult_const(fhelin_ctx* c, const fhelin_ct* a, double d, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->comp.mult_const(a->p, d));
+    *out = wrap(c->comp.mult_const(ct_in(c, a), d));
     FHELIN_CATCH
 }
 int fhelin_fc_mask(fhelin_ctx* c, const fhelin_ct* a, int32_t kind, int32_t x, int32_t y, double v, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
     switch (kind) {
-        case 0: *out = wrap(c->comp.mask_block(a->p, x, y, v)); break;
-        case 1: *out = wrap(c->comp.mask_heads(a->p, v)); break;
-        case 2: *out = wrap(c->comp.mask_heads_128(a->p, v)); break;
-        case 3: *out = wrap(c->comp.mask_mod_n(a->p, x, y)); break;
-        case 4: *out = wrap(c->comp.mask_first_n(a->p, x, v)); break;
+        case 0: *out = wrap(c->comp.mask_block(ct_in(c, a), x, y, v)); break;
+        case 1: *out = wrap(c->comp.mask_heads(ct_in(c, a), v)); break;
+        case 2: *out = wrap(c->comp.mask_heads_128(ct_in(c, a), v)); break;
+        case 3: *out = wrap(c->comp.mask_mod_n(ct_in(c, a), x, y)); break;
+        case 4: *out = wrap(c->comp.mask_first_n(ct_in(c, a), x, v)); break;
         default: throw Error(FHELIN_ERR_ARG, "unknown mask kind");
     }
     FHELIN_CATCH
@@ -48,33 +48,33 @@ int fhelin_fc_mask(fhelin_ctx* c, const fhelin_ct* a, int32_t kind, int32_t x, i
 int fhelin_fc_rotsum(fhelin_ctx* c, const fhelin_ct* a, int32_t slots, int32_t padding, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->comp.rotsum(a->p, slots, padding));
+    *out = wrap(c->comp.rotsum(ct_in(c, a), slots, padding));
     FHELIN_CATCH
 }
 int fhelin_fc_repeat(fhelin_ctx* c, const fhelin_ct* a, int32_t slots, int32_t padding, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->comp.repeat(a->p, slots, padding));
+    *out = wrap(c->comp.repeat(ct_in(c, a), slots, padding));
     FHELIN_CATCH
 }
 int fhelin_fc_add_many(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
     NEED(c && v && out);
     FHELIN_TRY
-    *out = wrap(c->comp.add_many(vec_of(v, n)));
+    *out = wrap(c->comp.add_many(vec_of(c, v, n)));
     FHELIN_CATCH
 }
 int fhelin_fc_matmul_pt(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* w, const fhelin_pt* bias,
                         int32_t slots, int32_t padding, fhelin_ct** outs) {
     NEED(c && rows && w && outs);
     FHELIN_TRY
-    emit(c->comp.matmul_pt(vec_of(rows, n), w->p, opt(bias), slots, padding), outs);
+    emit(c->comp.matmul_pt(vec_of(c, rows, n), w->p, opt(bias), slots, padding), outs);
     FHELIN_CATCH
 }
 int fhelin_fc_matmul_ct(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_ct* w, int32_t slots,
                         int32_t padding, fhelin_ct** outs) {
     NEED(c && rows && w && outs);
     FHELIN_TRY
-    emit(c->comp.matmul_ct(vec_of(rows, n), w->p, slots, padding), outs);
+    emit(c->comp.matmul_ct(vec_of(c, rows, n), ct_in(c, w), slots, padding), outs);
     FHELIN_CATCH
 }
 int fhelin_fc_matmulRElarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* const* weights, int32_t nw,
@@ -86,7 +86,7 @@ int fhelin_fc_matmulRElarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t
         if (!weights[i]) throw Error(FHELIN_ERR_ARG, "null weight");
         w.push_back(weights[i]->p);
     }
-    emit(c->comp.matmulRElarge(vec_of(rows, n), w, opt(bias), mask_val), outs);
+    emit(c->comp.matmulRElarge(vec_of(c, rows, n), w, opt(bias), mask_val), outs);
     FHELIN_CATCH
 }
 int fhelin_fc_matmulCRlarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* const* weights,
@@ -99,51 +99,51 @@ int fhelin_fc_matmulCRlarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t
         w.push_back(weights[i]->p);
     }
     std::vector<CtVec> r;
-    for (int i = 0; i < n; ++i) r.push_back(vec_of(rows + 4 * i, 4));
+    for (int i = 0; i < n; ++i) r.push_back(vec_of(c, rows + 4 * i, 4));
     emit(c->comp.matmulCRlarge(r, w, opt(bias)), outs);
     FHELIN_CATCH
 }
 int fhelin_fc_matmulScores(fhelin_ctx* c, const fhelin_ct* const* queries, int32_t n, const fhelin_ct* key, fhelin_ct** out) {
     NEED(c && queries && key && out);
     FHELIN_TRY
-    *out = wrap(c->comp.matmulScores(vec_of(queries, n), key->p));
+    *out = wrap(c->comp.matmulScores(vec_of(c, queries, n), ct_in(c, key)));
     FHELIN_CATCH
 }
 int fhelin_fc_wrapUpRepeated(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
     NEED(c && v && out);
     FHELIN_TRY
-    *out = wrap(c->comp.wrapUpRepeated(vec_of(v, n)));
+    *out = wrap(c->comp.wrapUpRepeated(vec_of(c, v, n)));
     FHELIN_CATCH
 }
 int fhelin_fc_wrapUpExpanded(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
     NEED(c && v && out);
     FHELIN_TRY
-    *out = wrap(c->comp.wrapUpExpanded(vec_of(v, n)));
+    *out = wrap(c->comp.wrapUpExpanded(vec_of(c, v, n)));
     FHELIN_CATCH
 }
 int fhelin_fc_unwrapExpanded(fhelin_ctx* c, const fhelin_ct* a, int32_t n, fhelin_ct** outs) {
     NEED(c && a && outs);
     FHELIN_TRY
-    emit(c->comp.unwrapExpanded(a->p, n), outs);
+    emit(c->comp.unwrapExpanded(ct_in(c, a), n), outs);
     FHELIN_CATCH
 }
 int fhelin_fc_unwrapScoresExpanded(fhelin_ctx* c, const fhelin_ct* a, int32_t n, fhelin_ct** outs) {
     NEED(c && a && outs);
     FHELIN_TRY
-    emit(c->comp.unwrapScoresExpanded(a->p, n), outs);
+    emit(c->comp.unwrapScoresExpanded(ct_in(c, a), n), outs);
     FHELIN_CATCH
 }
 int fhelin_fc_unwrap_512_in_4_128(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** outs4) {
     NEED(c && a && outs4);
     FHELIN_TRY
-    emit(c->comp.unwrap_512_in_4_128(a->p, index), outs4);
+    emit(c->comp.unwrap_512_in_4_128(ct_in(c, a), index), outs4);
     FHELIN_CATCH
 }
 int fhelin_fc_unwrapRepeatedLarge(fhelin_ctx* c, const fhelin_ct* const* containers, int32_t nc, int32_t input_number,
                                   fhelin_ct** outs) {
     NEED(c && containers && outs);
     FHELIN_TRY
-    auto r = c->comp.unwrapRepeatedLarge(vec_of(containers, nc), input_number);
+    auto r = c->comp.unwrapRepeatedLarge(vec_of(c, containers, nc), input_number);
     for (size_t i = 0; i < r.size(); ++i) emit(r[i], outs + 4 * i);
     FHELIN_CATCH
 }
@@ -151,7 +151,7 @@ int fhelin_fc_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs,
                                   fhelin_ct** outs, int32_t* n_out) {
     NEED(c && inputs && outs);
     FHELIN_TRY
-    auto r = c->comp.generate_containers(vec_of(inputs, n), opt(bias));
+    auto r = c->comp.generate_containers(vec_of(c, inputs, n), opt(bias));
     emit(r, outs);
     if (n_out) *n_out = (int)r.size();
     FHELIN_CATCH
@@ -159,38 +159,40 @@ int fhelin_fc_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs,
 int fhelin_fc_wrap_containers(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t inputs_number, fhelin_ct** out) {
     NEED(c && v && out);
     FHELIN_TRY
-    *out = wrap(c->comp.wrap_containers(vec_of(v, n), inputs_number));
+    *out = wrap(c->comp.wrap_containers(vec_of(c, v, n), inputs_number));
     FHELIN_CATCH
 }
 
 int fhelin_mult_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.mult_real(a->p, k));
+    *out = wrap(c->ev.mult_real(ct_in(c, a), k));
     FHELIN_CATCH
 }
 int fhelin_add_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.add_real(a->p, k));
+    *out = wrap(c->ev.add_real(ct_in(c, a), k));
     FHELIN_CATCH
 }
 int fhelin_mult_many(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
     NEED(c && v && out);
     FHELIN_TRY
-    *out = wrap(c->ev.mult_many(vec_of(v, n)));
+    *out = wrap(c->ev.mult_many(vec_of(c, v, n)));
     FHELIN_CATCH
 }
 int fhelin_eval_poly(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, int32_t n, fhelin_ct** out) {
     NEED(c && x && coeffs && out);
     FHELIN_TRY
-    *out = wrap(c->ev.eval_poly(x->p, std::vector<double>(coeffs, coeffs + n)));
+    const std::vector<double> cf(coeffs, coeffs + n);
+    *out = wrap(run_heavy(c, x, [&](const CtPtr& in) { return c->ev.eval_poly(in, cf); }));
     FHELIN_CATCH
 }
 int fhelin_eval_chebyshev(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, int32_t n, double a, double b, fhelin_ct** out) {
     NEED(c && x && coeffs && out);
     FHELIN_TRY
-    *out = wrap(c->ev.eval_chebyshev(x->p, std::vector<double>(coeffs, coeffs + n), a, b));
+    const std::vector<double> cf(coeffs, coeffs + n);
+    *out = wrap(run_heavy(c, x, [&](const CtPtr& in) { return c->ev.eval_chebyshev(in, cf, a, b); }));
     FHELIN_CATCH
 }
 int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t budget_enc, int32_t budget_dec, int32_t slots) {
@@ -202,13 +204,13 @@ int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t budget_enc, int32_t budget_dec
 int fhelin_bootstrap(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->boot.bootstrap(a->p));
+    *out = wrap(run_heavy(c, a, [&](const CtPtr& in) { return c->boot.bootstrap(in); }));
     FHELIN_CATCH
 }
 int fhelin_bootstrap_partial(fhelin_ctx* c, const fhelin_ct* a, int32_t stage, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->boot.partial(a->p, stage));
+    *out = wrap(c->boot.partial(ct_in(c, a), stage));
     FHELIN_CATCH
 }
 int fhelin_bootstrap_config(fhelin_ctx* c, int32_t K, int32_t R, int32_t cheb_degree, int32_t correction) {

@@ -102,7 +102,7 @@ int fhelin_encrypt(fhelin_ctx* c, const fhelin_pt* p, fhelin_ct** out) {
 int fhelin_decrypt(fhelin_ctx* c, const fhelin_ct* ct, double* out, int32_t slots) {
     NEED(c && ct && out);
     FHELIN_TRY
-    auto v = c->cl.decrypt(ct->p, slots);
+    auto v = c->cl.decrypt(ct_in(c, ct), slots);
     std::memcpy(out, v.data(), v.size() * sizeof(double));
     FHELIN_CATCH
 }
@@ -120,7 +120,7 @@ int fhelin_ct_export(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* out, size_t c
     NEED(c && ct && out);
     FHELIN_TRY
     if (cap < ct->p->words()) throw Error(FHELIN_ERR_ARG, "buffer too small");
-    hip_check(hipMemcpyAsync(out, ct->p->d, ct->p->words() * 8, hipMemcpyDeviceToHost, c->ctx.stream), "ct export");
+    hip_check(hipMemcpyAsync(out, ct_in(c, ct)->d, ct->p->words() * 8, hipMemcpyDeviceToHost, c->ctx.stream), "ct export");
     c->ctx.sync();
     FHELIN_CATCH
 }
@@ -137,7 +137,7 @@ int fhelin_ct_info(const fhelin_ct* ct, int32_t* npoly, int32_t* ell, int32_t* l
 int fhelin_ct_clone(fhelin_ctx* c, const fhelin_ct* ct, fhelin_ct** out) {
     NEED(c && ct && out);
     FHELIN_TRY
-    *out = wrap(c->ev.clone(ct->p));
+    *out = wrap(c->ev.clone(ct_in(c, ct)));
     FHELIN_CATCH
 }
 void fhelin_ct_free(fhelin_ct* ct) { delete ct; }
@@ -149,40 +149,40 @@ void fhelin_ct_free(fhelin_ct* ct) { delete ct; }
         *out = wrap(expr);                                                                  \
         FHELIN_CATCH                                                                        \
     }
-BINOP(fhelin_add, c->ev.add(a->p, b->p))
-BINOP(fhelin_sub, c->ev.sub(a->p, b->p))
-BINOP(fhelin_mult, c->ev.mult(a->p, b->p))
-BINOP(fhelin_raw_mult_relin, (c->ev.relin_key ? c->ev.raw_mult_relin(a->p, b->p, *c->ev.relin_key)
+BINOP(fhelin_add, c->ev.add(ct_in(c, a), ct_in(c, b)))
+BINOP(fhelin_sub, c->ev.sub(ct_in(c, a), ct_in(c, b)))
+BINOP(fhelin_mult, c->ev.mult(ct_in(c, a), ct_in(c, b)))
+BINOP(fhelin_raw_mult_relin, (c->ev.relin_key ? c->ev.raw_mult_relin(ct_in(c, a), ct_in(c, b), *c->ev.relin_key)
                                               : throw Error(FHELIN_ERR_KEY, "no relinearisation key")))
 
 int fhelin_negate(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.negate(a->p));
+    *out = wrap(c->ev.negate(ct_in(c, a)));
     FHELIN_CATCH
 }
 int fhelin_add_plain(fhelin_ctx* c, const fhelin_ct* a, const fhelin_pt* p, fhelin_ct** out) {
     NEED(c && a && p && out);
     FHELIN_TRY
-    *out = wrap(c->ev.add_plain(a->p, p->p));
+    *out = wrap(c->ev.add_plain(ct_in(c, a), p->p));
     FHELIN_CATCH
 }
 int fhelin_mult_plain(fhelin_ctx* c, const fhelin_ct* a, const fhelin_pt* p, fhelin_ct** out) {
     NEED(c && a && p && out);
     FHELIN_TRY
-    *out = wrap(c->ev.mult_plain(a->p, p->p));
+    *out = wrap(c->ev.mult_plain(ct_in(c, a), p->p));
     FHELIN_CATCH
 }
 int fhelin_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.rotate(a->p, index));
+    *out = wrap(c->ev.rotate(ct_in(c, a), index));
     FHELIN_CATCH
 }
 int fhelin_rotate_many(fhelin_ctx* c, const fhelin_ct* a, const int32_t* indices, int32_t n, fhelin_ct** outs) {
     NEED(c && a && indices && outs && n >= 0);
     FHELIN_TRY
-    std::vector<CtPtr> r = c->ev.rotate_many(a->p, std::vector<int>(indices, indices + n));
+    std::vector<CtPtr> r = c->ev.rotate_many(ct_in(c, a), std::vector<int>(indices, indices + n));
     for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
     FHELIN_CATCH
 }
@@ -192,7 +192,7 @@ int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* 
     std::vector<CtPtr> in;
     for (int i = 0; i < n; ++i) {
         if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext in array");
-        in.push_back(v[i]->p);
+        in.push_back(ct_in(c, v[i]));
     }
     std::vector<CtPtr> r = c->ev.rotate_each(in, std::vector<int>(indices, indices + n));
     for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
@@ -201,19 +201,19 @@ int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* 
 int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.rescale(a->p));
+    *out = wrap(c->ev.rescale(ct_in(c, a)));
     FHELIN_CATCH
 }
 int fhelin_level_reduce(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.level_reduce(a->p, new_ell));
+    *out = wrap(c->ev.level_reduce(ct_in(c, a), new_ell));
     FHELIN_CATCH
 }
 int fhelin_raw_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.raw_rescale(a->p));
+    *out = wrap(c->ev.raw_rescale(ct_in(c, a)));
     FHELIN_CATCH
 }
 int fhelin_raw_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** out) {
@@ -222,7 +222,7 @@ int fhelin_raw_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_c
     const u64 g = c->ctx.galois_element(index);
     auto it = c->ev.rot_keys.find(g);
     if (it == c->ev.rot_keys.end() || !it->second) throw Error(FHELIN_ERR_KEY, "no rotation key for this index");
-    *out = wrap(c->ev.raw_rotate(a->p, g, *it->second));
+    *out = wrap(c->ev.raw_rotate(ct_in(c, a), g, *it->second));
     FHELIN_CATCH
 }
 

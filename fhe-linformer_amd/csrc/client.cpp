@@ -192,6 +192,8 @@ std::shared_ptr<Encoding> Plaintext::at(int ell, long double scale) {
     for (auto& e : cache)
         if (e->ell == ell && fabsl(e->scale / scale - 1.0L) < 1e-12L) return e;
     auto e = encode_to_device(*ctx, values, imag, slots, ell, scale);
+    // an encoding made on a worker lane is cached and may be read from any other stream next: finish it first
+    if (ctx->stream != ctx->main_stream) hip_check(hipStreamSynchronize(ctx->stream), "encode sync (lane)");
     cache.push_back(e);
     return e;
 }

@@ -121,6 +121,7 @@ Context::Context(const Params& p) : prm(p) {
             hip_check(hipEventCreateWithFlags(&lane_event[k], hipEventDisableTiming), "hipEventCreate(lane)");
         }
         hip_check(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming), "hipEventCreate(fork)");
+        if (const char* e = std::getenv("FHELIN_ASYNC")) async_lanes = std::atoi(e) != 0;
     }
     hip_check(hipEventCreate(&ev_start), "hipEventCreate");
     stage_words = (size_t)2 << p.log_n;
@@ -268,6 +269,18 @@ void Context::require_device() const {
 void Context::sync() {
     require_device();
     hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (stream == main_stream) {  // asynchronous lane work counts as issued work of the context
+        for (int k = 1; k <= n_lanes; ++k) {
+            hip_check(hipStreamSynchronize(lane_stream[k]), "hipStreamSynchronize(lane)");
+            lane_hold[k].clear();
+        }
+    }
+}
+
+void Context::release_holds(int lane, u64 up_to_seq) {
+    auto& h = lane_hold[lane];
+    h.erase(std::remove_if(h.begin(), h.end(), [&](const std::pair<u64, std::shared_ptr<void>>& e) { return e.first <= up_to_seq; }),
+            h.end());
 }
 
 void Context::fork_lanes() {

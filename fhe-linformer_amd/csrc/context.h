@@ -101,6 +101,14 @@ struct Context {
     hipStream_t lane_stream[DevicePool::MAX_LANES] = {};
     hipEvent_t lane_event[DevicePool::MAX_LANES] = {};
     hipEvent_t fork_event = nullptr;
+    // Heavy single-ciphertext ops (bootstrap, polynomial evaluation) issued back to back by the caller run on
+    // alternating lanes WITHOUT joining: the result carries an event, the main stream waits for it only when the result
+    // is consumed.  An op's input is kept alive until the main stream has passed the op's event (lane_hold).
+    bool async_lanes = true;        // FHELIN_ASYNC=0 disables
+    int async_rr = 0;
+    u64 lane_seq[DevicePool::MAX_LANES] = {};
+    std::vector<std::pair<u64, std::shared_ptr<void>>> lane_hold[DevicePool::MAX_LANES];
+    void release_holds(int lane, u64 up_to_seq);
     void fork_lanes();              // lanes wait for everything enqueued on the main stream so far
     void join_lanes();              // the main stream waits for every lane
     struct LaneScope {              // route launches and allocations to lane k (1-based) until destruction

@@ -10,6 +10,7 @@ DevBlock::~DevBlock() {
     }
 }
 Ciphertext::~Ciphertext() {
+    if (async_ev) (void)hipEventDestroy(async_ev);
     if (d && ctx && !block) {
         try { ctx->pool.free(d); } catch (...) {}
     }

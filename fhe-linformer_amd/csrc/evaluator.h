@@ -27,6 +27,12 @@ struct Ciphertext {
     int deg = 1;          // noiseScaleDeg: 1 after rescale / fresh, 2 after a multiplication
     long double scale = 0;
     int slots = 0;
+    // set when the ciphertext was produced by a heavy op running asynchronously on a worker lane (capi_internal.h):
+    // its data is valid on other streams only after async_ev
+    bool async_pending = false;
+    int async_lane = 0;
+    u64 async_seq = 0;
+    hipEvent_t async_ev = nullptr;
     ~Ciphertext();
     int level() const { return ctx->L + 1 - ell; }
     size_t words() const { return (size_t)npoly * ell * ctx->N; }
