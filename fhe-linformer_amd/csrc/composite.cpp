@@ -218,18 +218,47 @@ CtVec Composite::matmulCRlarge(const std::vector<CtVec>& rows, const std::vector
     return out;
 }
 
+// sum_i rot(terms[i], step * i).  The reference builds these sums as a Horner chain (rotate the running sum by `step`,
+// add the next term: n-1 DEPENDENT key switches); the same sum as a binary tree needs the same n-1 rotations but
+// only ceil(log2 n) dependent steps, each a batched key switch with one key (step * 2^level): every launch fills the
+// GPU and the noise passes through log n instead of n key switches.
+CtPtr Composite::shift_sum(const CtVec& terms, int step) {
+    if (terms.empty()) throw Error(FHELIN_ERR_ARG, "shift_sum: empty vector");
+    CtVec cur = terms;
+    for (int level = 0; cur.size() > 1; ++level) {
+        CtVec odd;
+        for (size_t j = 1; j < cur.size(); j += 2) odd.push_back(cur[j]);
+        CtVec rot = ev_.rotate_batch(odd, step * (1 << level));
+        CtVec nxt;
+        for (size_t j = 0; j < cur.size(); j += 2) nxt.push_back(j + 1 < cur.size() ? ev_.add(cur[j], rot[j / 2]) : cur[j]);
+        cur.swap(nxt);
+    }
+    return cur[0];
+}
+
+// rot(c, step * i) for i = 0..n-1 by doubling: level b rotates everything known so far by step * 2^b (one batched key
+// switch per level) instead of n-1 dependent rotations by `step`.
+CtVec Composite::shift_fan(const CtPtr& c, int n, int step) {
+    CtVec out(n);
+    if (n < 1) return out;
+    out[0] = c;
+    for (int have = 1; have < n; have *= 2) {
+        const int cnt = std::min(have, n - have);
+        CtVec src(out.begin(), out.begin() + cnt);
+        CtVec rot = ev_.rotate_batch(src, step * have);
+        for (int i = 0; i < cnt; ++i) out[have + i] = rot[i];
+    }
+    return out;
+}
+
 CtPtr Composite::matmulScores(const CtVec& queries, const CtPtr& key) {
     if (queries.empty()) throw Error(FHELIN_ERR_ARG, "matmulScores: no queries");
     CtVec scores = matmul_ct(queries, key, 128, 1);
     const double r = 1 / 8.0;  // "later corrected with e^(x/r)"  (:1031)
-    if (scores.size() == 1) return mask_heads_128(scores[0], 1 / 8.0 * r);
-    CtPtr wrapped = mask_heads_128(scores.back(), 1 / 8.0 * r);
-    wrapped = ev_.rotate(wrapped, -1);
-    for (int i = (int)scores.size() - 2; i >= 0; --i) {
-        wrapped = ev_.add(wrapped, mask_heads_128(scores[i], 1 / 8.0 * r));
-        if (i > 0) wrapped = ev_.rotate(wrapped, -1);
-    }
-    return wrapped;
+    // :1036-1044 rotate-by(-1)-and-add chain == sum_i rot(masked_i, -i)
+    CtVec masked;
+    for (const auto& sc : scores) masked.push_back(mask_heads_128(sc, 1 / 8.0 * r));
+    return shift_sum(masked, -1);
 }
 
 CtPtr Composite::wrapUpRepeated(const CtVec& v) {
@@ -240,33 +269,29 @@ CtPtr Composite::wrapUpRepeated(const CtVec& v) {
 
 CtPtr Composite::wrapUpExpanded(const CtVec& v) {
     if (v.empty()) throw Error(FHELIN_ERR_ARG, "wrapUpExpanded: empty vector");
-    CtPtr masked = mask_mod_n(v.back(), 128, 0);
-    if (v.size() > 1) masked = ev_.rotate(masked, -1);
-    for (int i = (int)v.size() - 2; i >= 0; --i) {
-        masked = ev_.add(masked, mask_mod_n(v[i], 128, 0));
-        if (i > 0) masked = ev_.rotate(masked, -1);
-    }
-    return masked;
+    // :1072-1084 rotate-by(-1)-and-add chain == sum_i rot(mask(v_i), -i)
+    CtVec masked;
+    for (const auto& x : v) masked.push_back(mask_mod_n(x, 128, 0));
+    return shift_sum(masked, -1);
 }
 
 CtVec Composite::unwrapExpanded(CtPtr c, int n) {
-    // the mask/rotate chain is sequential (:1089-1097); the `repeat` of every extracted token is independent
+    // :1089-1097 masks rot(c, i) for i = 0..n-1 (there: n-1 dependent rotations by 1); the `repeat` of every extracted
+    // token is independent
     CtVec masked;
-    for (int i = 0; i < n; ++i) {
-        masked.push_back(mask_mod_n(c, 128, 0));
-        if (i < n - 1) c = ev_.rotate(c, 1);
-    }
+    for (const auto& r : shift_fan(c, n, 1)) masked.push_back(mask_mod_n(r, 128, 0));
     return repeat_batch(masked, 128, 1);
 }
 
 CtVec Composite::unwrapScoresExpanded(CtPtr c, int n) {
-    CtVec result;
-    for (int i = 0; i < n; ++i) {
-        CtPtr a = repeat(mask_mod_n(c, 128, 0), 64, 1);
-        CtPtr b = repeat(mask_mod_n(c, 128, 64), 64, 1);
-        if (i < n - 1) c = ev_.rotate(c, 1);
-        result.push_back(ev_.add(a, b));
+    CtVec ma, mb;
+    for (const auto& r : shift_fan(c, n, 1)) {
+        ma.push_back(mask_mod_n(r, 128, 0));
+        mb.push_back(mask_mod_n(r, 128, 64));
     }
+    CtVec a = repeat_batch(ma, 64, 1), b = repeat_batch(mb, 64, 1);
+    CtVec result;
+    for (int i = 0; i < n; ++i) result.push_back(ev_.add(a[i], b[i]));
     return result;
 }
 
@@ -301,12 +326,10 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
 
 CtPtr Composite::wrap_containers(const CtVec& c, int n) {
     if (c.empty() || n > (int)c.size()) throw Error(FHELIN_ERR_ARG, "wrap_containers: bad input count");
-    CtPtr result = c[0];
-    for (int i = 1; i < n; ++i) {
-        result = ev_.rotate(result, -512);
-        result = ev_.add(result, c[i]);
-    }
-    return result;
+    // :1186-1193 result = rot(result, -512) + c[i]  ==  sum_i rot(c[n-1-i], -512 i)
+    CtVec terms(c.begin(), c.begin() + n);
+    std::reverse(terms.begin(), terms.end());
+    return shift_sum(terms, -512);
 }
 
 CtVec Composite::generate_containers(const CtVec& inputs, const PtPtr& bias) {

@@ -49,6 +49,10 @@ public:
     CtVec matmulCRlarge(const std::vector<CtVec>& rows, const std::vector<PtPtr>& weights, const PtPtr& bias);
     CtPtr matmulScores(const CtVec& queries, const CtPtr& key);
 
+    // shifted sums / fans shared by the layout shuffles (log-depth forms of the reference's rotate-by-one chains)
+    CtPtr shift_sum(const CtVec& terms, int step);          // sum_i rot(terms[i], step * i)
+    CtVec shift_fan(const CtPtr& c, int n, int step);       // rot(c, step * i), i = 0..n-1
+
     // layout shuffles                                                                         :1060-1205
     CtPtr wrapUpRepeated(const CtVec& v);
     CtPtr wrapUpExpanded(const CtVec& v);
