@@ -25,6 +25,17 @@ typedef uint64_t u64;
 typedef uint32_t u32;
 typedef unsigned __int128 u128;
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// sign word of a 64-bit value through an asm v_ashrrev_i32, so that instruction selection cannot turn the mask
+// arithmetic of the conditional subtractions below back into compare + v_cndmask (measured on gfx950, bench.py
+// --micro: v_cndmask_b32 with a VCC mask issues ~5x slower than other VALU instructions)
+__device__ __forceinline__ u64 sign_mask64(u64 t) {
+    u32 s;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(s) : "v"((u32)(t >> 32)));
+    return ((u64)s << 32) | s;
+}
+#endif
+
 FHE_HD u64 mulhi64(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __umul64hi(a, b);
@@ -39,18 +50,25 @@ FHE_HD u64 mul_shoup_lazy(u64 x, u64 w, u64 ws, u64 q) {
     u64 h = mulhi64(x, ws);
     return x * w - h * q;
 }
-FHE_HD u64 mul_shoup(u64 x, u64 w, u64 ws, u64 q) {
-    u64 r = mul_shoup_lazy(x, w, ws, q);
-    return r >= q ? r - q : r;
-}
-
+// x < 2q, q < 2^63 (so that x - q lies in [-q, q))  ->  x >= q ? x - q : x
 FHE_HD u64 csub(u64 x, u64 q) {
-    u64 t;
-    const bool borrow = __builtin_sub_overflow(x, q, &t);  // the subtraction's borrow IS the comparison x < q
-    return borrow ? x : t;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u64 t = x - q;
+    return t + (q & sign_mask64(t));
+#else
+    return x >= q ? x - q : x;
+#endif
 }
+FHE_HD u64 mul_shoup(u64 x, u64 w, u64 ws, u64 q) { return csub(mul_shoup_lazy(x, w, ws, q), q); }
 FHE_HD u64 add_mod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
-FHE_HD u64 sub_mod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+FHE_HD u64 sub_mod(u64 a, u64 b, u64 q) {  // a, b < q < 2^63
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u64 t = a - b;
+    return t + (q & sign_mask64(t));
+#else
+    return a >= b ? a - b : a + q - b;
+#endif
+}
 FHE_HD u64 neg_mod(u64 a, u64 q) { return a ? q - a : 0; }
 
 // ---- Barrett: ratio (r1:r0) = floor(2^128 / q) ------------------------------------------
@@ -76,9 +94,9 @@ FHE_HD u64 barrett_reduce128(u64 lo, u64 hi, const Barrett& b) {
     u64 s2 = s1 + t_lo;
     u64 c2 = t_hi + (s2 < t_lo);
     u64 qhat = hi * b.r1 + c1 + c2;
-    u64 r = lo - qhat * b.q;
-    r = r >= b.q ? r - b.q : r;
-    r = r >= b.q ? r - b.q : r;
+    u64 r = lo - qhat * b.q;  // < 3q
+    r = csub(r, b.q);
+    r = csub(r, b.q);
     return r;
 }
 
@@ -168,16 +186,7 @@ __device__ __forceinline__ u64 mul_shoup_lazy5(u64 x, u64 w, u64 ws, u64 nq) {
     asm("v_add_u32 %0, %1, %2" : "=v"(rh) : "v"((u32)(r >> 32)), "v"((u32)c));
     return ((u64)rh << 32) | (u32)r;
 }
-// Conditional subtraction without v_cndmask: x < 2m, m < 2^63 (so that x - m lies in [-m, m))  ->  x >= m ? x - m : x.
-// (Measured on gfx950, bench.py --micro: v_cndmask_b32 with a VCC mask issues ~5x slower than the other VALU ops, and the
-// compare + two selects of the usual form also serialise on VCC.)  The sign word comes from an asm v_ashrrev_i32 so
-// that instruction selection cannot turn the mask arithmetic back into selects.
-__device__ __forceinline__ u64 csub_mask(u64 x, u64 m) {
-    const u64 t = x - m;
-    u32 s;
-    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(s) : "v"((u32)(t >> 32)));
-    return t + (m & (((u64)s << 32) | s));
-}
+__device__ __forceinline__ u64 csub_mask(u64 x, u64 m) { return csub(x, m); }  // x < 2m: x >= m ? x - m : x (mask form)
 // x mod q up to one q:  x < 2^(bits(q)+11)  ->  [0, 2q).   sh = bits(q) - 10,  rr = floor(2^(bits(q)+22) / q);
 // k~ = hi32((x >> sh) * rr) is floor(x/q) or one less (error terms < 2^-8).
 __device__ __forceinline__ u64 reduce_lazy_2q(u64 x, u64 q, u32 sh, u32 rr) {
