@@ -273,7 +273,7 @@ def main():
                     "kernel": "ntt_cols_kernel + ntt_rows_kernel (one limb-NTT = one tile pass of each)",
                     "limb_ntt_per_s_per_gpu": round(n_ntt / (ntt_ms * 1e-3), 1),
                     "algorithmic_bytes_per_limb_ntt": alg_bytes,
-                    "note": "64-bit modular-integer butterflies: VALU-integer ceiling ~3.3 TB/s algorithmic (DESIGN.md §6)"}
+                    "note": "64-bit modular-integer butterflies: bound by VALU issue slots (88 % busy, 15 instr/butterfly), ceiling ~2.3 TB/s algorithmic at the sustained clock (DESIGN.md §6)"}
         if args.workload == "forward":
             value = fwd["elapsed"] * 1e3 / (args.steps * world)
             line = {

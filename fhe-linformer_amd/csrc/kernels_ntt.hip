@@ -14,17 +14,18 @@
 //             pass B (row transforms over the low 8 index bits, one 256-entry twiddle slice per row)
 //   inverse : pass B' then pass A' (Gentleman-Sande order), N^{-1} folded into the last stage.
 // A workgroup (256 threads = 4 wavefronts) owns a tile of 4096 residues; each thread keeps 16 residues
-// in VGPRs and runs 4 stages on them between LDS exchanges ("rounds").  Butterflies are Harvey lazy
-// butterflies (values in [0,4q) forward / [0,2q) inverse) with Shoup twiddles, canonicalised only on
-// the final store.  This is 64-bit modular-integer work: no MFMA.
+// in VGPRs and runs 4 stages on them between LDS exchanges ("rounds").  Butterflies use Shoup twiddles with an
+// approximate quotient (product in [0,5q), 11 VALU instructions) and carry NO conditional subtraction for primes
+// below 2^53 (value bounds proven per stage, one reduction before the final store), one mask-form conditional
+// subtraction per butterfly for the 55/60-bit primes.  This is 64-bit modular-integer work: no MFMA.
 //
 // Memory behaviour: every global access of a wave instruction is a run of whole 128-byte lines (column pass:
 // 4 row segments of 128 B; row pass: 512 B contiguous, reached through one extra LDS exchange).  The first pass can
 // read out of place and strided (LimbBatch::src / src_group), which is how key switching and rescale avoid staging
 // copies.  The row pass maps workgroups to (limb, tile, repetition) in XCD-contiguous order so that the 4 KiB
 // twiddle slice of a (limb, tile) is shared by the vectors of a batch in one L2.
-// Measured (profiles/): 1.6 M limb-NTT/s at N=2^16, VALU-bound (~87 % VALU busy, ~32 VALU
-// instructions per butterfly of which 10 are half-rate 32x32 multiplies), 1.9x algorithmic HBM traffic.
+// Measured (profiles/): 1.95 M limb-NTT/s at N=2^16, bound by VALU issue slots (88 % busy; 15 VALU
+// instructions per lazy butterfly, 9 of them 32x32 multiplies), 2.07x algorithmic HBM traffic (two passes + twiddles).
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 
