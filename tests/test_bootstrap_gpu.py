@@ -59,3 +59,38 @@ def test_bootstrap_requires_setup_and_two_limbs(fa):
         e.bootstrap(ct)
     assert ei.value.code == 4                                 # EvalBootstrapSetup has not been called
     e.close()
+
+
+def test_async_heavy_ops_match_the_synchronous_path(fa, monkeypatch):
+    """Heavy ops issued back to back run on alternating worker lanes and are joined when their results are used
+    (capi_internal.h run_heavy).  The residues must not depend on that: the same call sequence with FHELIN_ASYNC=0
+    (everything on the main stream) has to export bit-identical ciphertexts — chains on one ciphertext (polynomial then
+    bootstrap), independent ciphertexts interleaved, results consumed in the opposite order, and an input freed by the
+    host while its consumer may still be running."""
+    cheb = [0.0, 1.0, 0.0, -0.25, 0.0, 0.05, 0.0, -0.01]
+
+    def run(async_on):
+        monkeypatch.setenv("FHELIN_ASYNC", "1" if async_on else "0")
+        eng = _engine(fa, 10)
+        try:
+            rng = np.random.default_rng(11)
+            ms = [rng.uniform(-0.5, 0.5, 1 << 10) for _ in range(3)]
+            outs = []
+            for m in ms:
+                ct = eng.encrypt(m, level=eng.n_q - 6)
+                p = eng.eval_chebyshev(ct, cheb, -1.0, 1.0)     # lane k
+                del ct                                           # the host drops the input while lane k may still read it
+                outs.append(eng.bootstrap(p))                   # same lane (chain), next ciphertext -> other lane
+            s = eng.add(outs[2], outs[0])                       # consume in a different order than produced
+            s = eng.add(s, outs[1])
+            return [o.export() for o in outs] + [s.export()], [eng.decrypt(o) for o in outs], ms
+        finally:
+            eng.close()
+
+    a, dec, ms = run(True)
+    b, _, _ = run(False)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    u = [np.polynomial.chebyshev.chebval(m, [cheb[0] / 2] + cheb[1:]) for m in ms]
+    for d, w in zip(dec, u):
+        assert np.max(np.abs(d - w)) < 5e-4
