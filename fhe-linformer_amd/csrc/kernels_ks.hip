@@ -31,8 +31,8 @@ constexpr int TCH = 16; // targets per block: every z-chunk re-reads the digit's
 
 // grid (N/256, beta, ceil((ell+k)/TCH))
 template <int MAXA>
-__global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape sh, u64* ext, const u64* cc, const u64* c_ntt,
-                                                         const u64* hatinv, const u64* hatmod) {
+__global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape sh, u64* __restrict__ ext, const u64* __restrict__ cc, const u64* __restrict__ c_ntt,
+                                                         const u64* __restrict__ hatinv, const u64* __restrict__ hatmod) {
     const int bi = blockIdx.y / sh.beta, j = blockIdx.y % sh.beta;
     const size_t N = (size_t)1 << t.log_n;
     const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
 }
 
 // grid (N/512, ell + k)
-__global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape sh, u64* accQ, u64* accP, const u64* ext,
-                                                       const u64* evk, const u64* c_ntt) {
+__global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape sh, u64* __restrict__ accQ, u64* __restrict__ accP, const u64* __restrict__ ext,
+                                                       const u64* __restrict__ evk, const u64* __restrict__ c_ntt) {
     const int nt = sh.ell + sh.k;
     const int bi = blockIdx.y / nt, tt = blockIdx.y % nt;
     const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
@@ -138,8 +138,8 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
 
 // grid (N/256, 2, ceil(ell/TCH))
 template <int MAXK>
-__global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsShape sh, u64* conv, const u64* accP, const u64* phatinv,
-                                                           const u64* phatmod) {
+__global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsShape sh, u64* __restrict__ conv, const u64* __restrict__ accP, const u64* __restrict__ phatinv,
+                                                           const u64* __restrict__ phatmod) {
     const int bi = blockIdx.y >> 1, c = blockIdx.y & 1;
     const size_t N = (size_t)1 << t.log_n;
     const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -175,9 +175,9 @@ __global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsSha
 }
 
 // grid (N/512, 2*ell)
-__global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsShape sh, u64* out, const u64* accQ, const u64* conv,
-                                                             const u64* pinv, const u64* add0, const u64* add1, const u32* map,
-                                                             const u64* post) {
+__global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsShape sh, u64* __restrict__ out, const u64* __restrict__ accQ, const u64* __restrict__ conv,
+                                                             const u64* __restrict__ pinv, const u64* __restrict__ add0, const u64* __restrict__ add1, const u32* __restrict__ map,
+                                                             const u64* __restrict__ post) {
     const int bi = blockIdx.y / (2 * sh.ell), v = blockIdx.y % (2 * sh.ell);
     const int c = v / sh.ell, tt = v % sh.ell;
     const u64 q = t.moduli[tt];
