@@ -162,6 +162,26 @@ Context::Context(const Params& p) : prm(p) {
         }
         dt.tw_fwd = upload_table(f);
         dt.tw_inv = upload_table(g);
+        // row-pass layout (kernels_ntt.hip load_round_tw_rows): slot s = (8 >> kb) - 1 + j of thread tau in tile T is
+        // tw[m_kb + (((T << 8) | tau) << (3 - kb)) + j],  m_kb = N >> (kb + 1),  kb = 0..3 (global stage bit)
+        const size_t tiles = N >> 12;
+        const size_t per_limb = tiles * 15 * 256 * 2;
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::vector<u64>& src = dir ? g : f;
+            std::vector<u64> r((size_t)nl * per_limb);
+            for (int i = 0; i < nl; ++i)
+                for (size_t T = 0; T < tiles; ++T)
+                    for (int kb = 0; kb < 4; ++kb)
+                        for (int j = 0; j < (8 >> kb); ++j)
+                            for (size_t tau = 0; tau < 256; ++tau) {
+                                const size_t idx = (N >> (kb + 1)) + ((((T << 8) | tau)) << (3 - kb)) + j;
+                                const size_t s_ = (size_t)(8 >> kb) - 1 + j;
+                                const size_t o = (size_t)i * per_limb + ((T * 15 + s_) * 256 + tau) * 2;
+                                r[o] = src[(size_t)i * 2 * N + 2 * idx];
+                                r[o + 1] = src[(size_t)i * 2 * N + 2 * idx + 1];
+                            }
+            (dir ? dt.tw_rows_inv : dt.tw_rows_fwd) = upload_table(r);
+        }
     }
     // ---- ModDown / rescale constants
     {

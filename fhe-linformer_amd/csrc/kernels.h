@@ -33,6 +33,10 @@ struct DeviceTables {
     const u64* barrett;    // [n_limbs][2]  (r0, r1) of floor(2^128/q)
     const u64* tw_fwd;     // [n_limbs][2N]  (w, w') pairs, bit-reversed powers of psi
     const u64* tw_inv;     // [n_limbs][2N]  same for psi^{-1}
+    // the per-thread twiddles of the row pass's last (forward) / first (inverse) four stages, transposed so that one load
+    // instruction of a wave reads 64 consecutive 16-byte pairs: [n_limbs][N/4096 tiles][15 slots][256 threads][2]
+    const u64* tw_rows_fwd;
+    const u64* tw_rows_inv;
     const u64* ninv;       // [n_limbs][8]   N^{-1}, shoup, ipsi_br[1]*N^{-1}, shoup, lazy shift, lazy ratio, 0, 0
 };
 

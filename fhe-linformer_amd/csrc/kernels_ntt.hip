@@ -37,6 +37,7 @@ struct NttArgs {
     u64* data;
     const u64* src;     // input of this pass (== data when in place)
     const u64* tw;      // [n_limbs][2N]
+    const u64* tw_rows; // [n_limbs][N/4096][15][256][2]  row-pass layout of the per-thread stages
     const u64* moduli;  // [n_limbs]
     const u64* ninv;    // [n_limbs][8]: N^-1 constants (4), lazy-reduction shift and ratio (2), spare (2)
     const int* limb_tab;
@@ -104,6 +105,12 @@ __device__ __forceinline__ void load_round_tw(RoundTw& r, const u64x2* __restric
 #pragma unroll
         for (int j = 0; j < (8 >> kb); ++j) r.t[(8 >> kb) - 1 + j] = tw[tbase + j];
     }
+}
+
+// the per-thread twiddles of the row pass (global stage bits 0..3) from the transposed table: lanes read consecutive pairs
+__device__ __forceinline__ void load_round_tw_rows(RoundTw& r, const u64x2* __restrict__ trows, int tau) {
+#pragma unroll
+    for (int s = 0; s < 15; ++s) r.t[s] = trows[s * 256 + tau];
 }
 
 template <int KB, bool LAZY>
@@ -315,6 +322,7 @@ template <bool INVERSE, bool LAZY>
 __device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, int tile, int limb, const LimbConst& c) {
     const int log_n = a.log_n;
     const u64x2* tw = reinterpret_cast<const u64x2*>(a.tw) + ((size_t)limb << log_n);
+    const u64x2* trows = reinterpret_cast<const u64x2*>(a.tw_rows) + (((size_t)limb << (log_n - 12)) + tile) * (15 * 256);
     u64* base = a.data + ((size_t)vec << log_n) + ((size_t)tile << 12);
     const u64* sbase = a.src + src_offset(a, vec, log_n) + ((size_t)tile << 12);
     const int tau = threadIdx.x;
@@ -326,7 +334,7 @@ __device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, i
         RoundTw rt, rn;
         load_round_tw<0, 4>(rt, tw, log_n, 4, (tile << 4) | (tau >> 4));
         fwd_round<0, 4, LAZY>(x, rt, c);
-        load_round_tw<0, 4>(rn, tw, log_n, 0, (tile << 8) | tau);   // per-thread twiddles of the last four stages
+        load_round_tw_rows(rn, trows, tau);                          // per-thread twiddles of the last four stages
         exchange(x, lds, tau, 4, 0, false);
         fwd_round<0, 4, LAZY>(x, rn, c);
 #pragma unroll
@@ -342,7 +350,7 @@ __device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, i
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = sbase[tile_index(tau, k, 8)];
         RoundTw rt, rn;
-        load_round_tw<0, 4>(rt, tw, log_n, 0, (tile << 8) | tau);   // per-thread twiddles of the first four stages
+        load_round_tw_rows(rt, trows, tau);                          // per-thread twiddles of the first four stages
         exchange(x, lds, tau, 8, 0, false);
         inv_round<0, 4, false, LAZY, 0, 1>(x, rt, c, nullptr);
         load_round_tw<0, 4>(rn, tw, log_n, 4, (tile << 4) | (tau >> 4));
@@ -405,6 +413,7 @@ void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStre
     a.src_group = b.src ? b.src_group : 0;
     a.src_group_stride = b.src_group_stride;
     a.tw = inverse ? t.tw_inv : t.tw_fwd;
+    a.tw_rows = inverse ? t.tw_rows_inv : t.tw_rows_fwd;
     a.moduli = t.moduli;
     a.ninv = t.ninv;
     a.limb_tab = b.limb_tab;
