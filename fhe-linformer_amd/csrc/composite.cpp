@@ -48,15 +48,16 @@ static std::string mkey(const char* kind, long a, long b, double v) {
     return key;
 }
 
-CtPtr Composite::mask_block(const CtPtr& c, int from, int to, double val) {
+PtPtr Composite::block_mask(int from, int to, double val) {
     const std::string key = mkey("block", from, to, val);
     if (!mask_cache_.count(key)) {
         std::vector<double> m(num_slots(), 0.0);
         for (int i = std::max(from, 0); i < to && i < num_slots(); ++i) m[i] = val;
         mask_plain(key, m);
     }
-    return ev_.mult_plain(c, mask_cache_[key]);
+    return mask_cache_[key];
 }
+CtPtr Composite::mask_block(const CtPtr& c, int from, int to, double val) { return ev_.mult_plain(c, block_mask(from, to, val)); }
 
 CtPtr Composite::mask_heads(const CtPtr& c, double val) {
     const std::string key = mkey("mod", 64, 0, val);
@@ -78,7 +79,7 @@ CtPtr Composite::mask_heads_128(const CtPtr& c, double val) {
     return ev_.mult_plain(c, mask_cache_[key]);
 }
 
-CtPtr Composite::mask_mod_n(const CtPtr& c, int n, int padding) {
+PtPtr Composite::mod_n_mask(int n, int padding) {
     if (n <= 0) throw Error(FHELIN_ERR_ARG, "mask_mod_n: n must be positive");
     const std::string key = mkey("mod", n, padding, 1.0);
     if (!mask_cache_.count(key)) {
@@ -87,8 +88,9 @@ CtPtr Composite::mask_mod_n(const CtPtr& c, int n, int padding) {
             if (i % n == padding) m[i] = 1.0;
         mask_plain(key, m);
     }
-    return ev_.mult_plain(c, mask_cache_[key]);
+    return mask_cache_[key];
 }
+CtPtr Composite::mask_mod_n(const CtPtr& c, int n, int padding) { return ev_.mult_plain(c, mod_n_mask(n, padding)); }
 
 PtPtr Composite::first_n_mask(int n, double val) {
     const std::string key = mkey("first", n, 0, val);
@@ -162,7 +164,12 @@ CtPtr Composite::add_many(const CtVec& v) {
     CtVec cur = v;
     while (cur.size() > 1) {  // binary tree like EvalAddMany
         CtVec nxt;
-        for (size_t i = 0; i + 1 < cur.size(); i += 2) nxt.push_back(ev_.add(cur[i], cur[i + 1]));
+        CtVec lhs, rhs;
+        for (size_t i = 0; i + 1 < cur.size(); i += 2) {
+            lhs.push_back(cur[i]);
+            rhs.push_back(cur[i + 1]);
+        }
+        nxt = ev_.add_batch(lhs, rhs);  // one launch per 32 pairs
         if (cur.size() & 1) nxt.push_back(cur.back());
         cur.swap(nxt);
     }
@@ -173,8 +180,7 @@ CtVec Composite::matmul_pt(const CtVec& rows, const PtPtr& w, const PtPtr& bias,
     // rows are independent (reference loop :872,:888,:985): the same operation sequence, interchanged so that
     // every rotate-and-sum step runs over all rows at once
     CtVec out = rotsum_batch(ev_.mult_plain_batch(rows, w), slots, padding);
-    if (bias)
-        for (auto& m : out) m = ev_.add_plain(m, bias);
+    if (bias) out = ev_.add_plain_batch(out, bias);
     return out;
 }
 
@@ -196,25 +202,36 @@ CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& we
         } else {
             res = ev_.rotate_batch(res, -64);
             res = ev_.rotate_batch(res, -64);
-            for (size_t i = 0; i < inputs.size(); ++i) res[i] = ev_.add(res[i], masked[i]);
+            res = ev_.add_batch(res, masked);
         }
     }
-    if (bias)
-        for (auto& r : res) r = ev_.add_plain(r, bias);
+    if (bias) res = ev_.add_plain_batch(res, bias);
     return res;
 }
 
 CtVec Composite::matmulCRlarge(const std::vector<CtVec>& rows, const std::vector<PtPtr>& weights, const PtPtr& bias) {
-    CtVec sums;
+    // per row (:1005-1014) sum_j r[j] * W_j: the 4 products of every row in one batched launch sequence, then the
+    // same pairwise sums as EvalAddMany ((p0 + p1) + (p2 + p3)) over all rows at once
+    CtVec flat;
+    std::vector<PtPtr> wflat;
     for (const CtVec& r : rows) {
         if (r.size() < 4 || weights.size() < 4) throw Error(FHELIN_ERR_ARG, "matmulCRlarge: need 4 blocks");
-        CtVec parts;
-        for (int j = 0; j < 4; ++j) parts.push_back(ev_.mult_plain(r[j], weights[j]));
-        sums.push_back(add_many(parts));
+        for (int j = 0; j < 4; ++j) {
+            flat.push_back(r[j]);
+            wflat.push_back(weights[j]);
+        }
     }
+    CtVec prod = ev_.mult_plain_each(flat, wflat);
+    CtVec l0, r0, l1, r1;
+    for (size_t i = 0; i + 3 < prod.size(); i += 4) {
+        l0.push_back(prod[i]);
+        r0.push_back(prod[i + 1]);
+        l1.push_back(prod[i + 2]);
+        r1.push_back(prod[i + 3]);
+    }
+    CtVec sums = ev_.add_batch(ev_.add_batch(l0, r0), ev_.add_batch(l1, r1));
     CtVec out = rotsum_batch(sums, 128, 1);
-    if (bias)
-        for (auto& m : out) m = ev_.add_plain(m, bias);
+    if (bias) out = ev_.add_plain_batch(out, bias);
     return out;
 }
 
@@ -229,8 +246,10 @@ CtPtr Composite::shift_sum(const CtVec& terms, int step) {
         CtVec odd;
         for (size_t j = 1; j < cur.size(); j += 2) odd.push_back(cur[j]);
         CtVec rot = ev_.rotate_batch(odd, step * (1 << level));
-        CtVec nxt;
-        for (size_t j = 0; j < cur.size(); j += 2) nxt.push_back(j + 1 < cur.size() ? ev_.add(cur[j], rot[j / 2]) : cur[j]);
+        CtVec even;
+        for (size_t j = 0; j + 1 < cur.size(); j += 2) even.push_back(cur[j]);
+        CtVec nxt = ev_.add_batch(even, rot);
+        if (cur.size() & 1) nxt.push_back(cur.back());
         cur.swap(nxt);
     }
     return cur[0];
@@ -262,37 +281,28 @@ CtPtr Composite::matmulScores(const CtVec& queries, const CtPtr& key) {
 }
 
 CtPtr Composite::wrapUpRepeated(const CtVec& v) {
-    CtVec masked;
-    for (size_t i = 0; i < v.size(); ++i) masked.push_back(mask_block(v[i], 128 * (int)i, 128 * ((int)i + 1), 1));
-    return add_many(masked);
+    std::vector<PtPtr> masks;
+    for (size_t i = 0; i < v.size(); ++i) masks.push_back(block_mask(128 * (int)i, 128 * ((int)i + 1), 1));
+    return add_many(ev_.mult_plain_each(v, masks));
 }
 
 CtPtr Composite::wrapUpExpanded(const CtVec& v) {
     if (v.empty()) throw Error(FHELIN_ERR_ARG, "wrapUpExpanded: empty vector");
     // :1072-1084 rotate-by(-1)-and-add chain == sum_i rot(mask(v_i), -i)
-    CtVec masked;
-    for (const auto& x : v) masked.push_back(mask_mod_n(x, 128, 0));
-    return shift_sum(masked, -1);
+    return shift_sum(ev_.mult_plain_batch(v, mod_n_mask(128, 0)), -1);
 }
 
 CtVec Composite::unwrapExpanded(CtPtr c, int n) {
     // :1089-1097 masks rot(c, i) for i = 0..n-1 (there: n-1 dependent rotations by 1); the `repeat` of every extracted
     // token is independent
-    CtVec masked;
-    for (const auto& r : shift_fan(c, n, 1)) masked.push_back(mask_mod_n(r, 128, 0));
-    return repeat_batch(masked, 128, 1);
+    return repeat_batch(ev_.mult_plain_batch(shift_fan(c, n, 1), mod_n_mask(128, 0)), 128, 1);
 }
 
 CtVec Composite::unwrapScoresExpanded(CtPtr c, int n) {
-    CtVec ma, mb;
-    for (const auto& r : shift_fan(c, n, 1)) {
-        ma.push_back(mask_mod_n(r, 128, 0));
-        mb.push_back(mask_mod_n(r, 128, 64));
-    }
-    CtVec a = repeat_batch(ma, 64, 1), b = repeat_batch(mb, 64, 1);
-    CtVec result;
-    for (int i = 0; i < n; ++i) result.push_back(ev_.add(a[i], b[i]));
-    return result;
+    const CtVec fan = shift_fan(c, n, 1);
+    CtVec a = repeat_batch(ev_.mult_plain_batch(fan, mod_n_mask(128, 0)), 64, 1);
+    CtVec b = repeat_batch(ev_.mult_plain_batch(fan, mod_n_mask(128, 64)), 64, 1);
+    return ev_.add_batch(a, b);
 }
 
 CtVec Composite::unwrap_512_in_4_128(const CtPtr& c, int index) {
@@ -314,11 +324,15 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
     }
     // unwrap_512_in_4_128 (:1142-1162) for every (container, token): mask the four 128-slot blocks, then one batched
     // repeat(128, -128) over all of them
-    CtVec masked;
+    CtVec src;
+    std::vector<PtPtr> masks;
     for (size_t i = 0; i < containers.size() && i < quantities.size(); ++i)
         for (int j = 0; j < quantities[i]; ++j)
-            for (int k = 0; k < 4; ++k) masked.push_back(mask_block(containers[i], j * 512 + 128 * k, j * 512 + 128 * (k + 1), 1));
-    CtVec rep = repeat_batch(masked, 128, -128);
+            for (int k = 0; k < 4; ++k) {
+                src.push_back(containers[i]);
+                masks.push_back(block_mask(j * 512 + 128 * k, j * 512 + 128 * (k + 1), 1));
+            }
+    CtVec rep = repeat_batch(ev_.mult_plain_each(src, masks), 128, -128);
     std::vector<CtVec> out;
     for (size_t i = 0; i + 3 < rep.size(); i += 4) out.push_back(CtVec(rep.begin() + i, rep.begin() + i + 4));
     return out;
@@ -349,9 +363,9 @@ CtVec Composite::generate_containers(const CtVec& inputs, const PtPtr& bias) {
         }
         std::reverse(sliced.begin(), sliced.end());
         CtPtr part = wrap_containers(sliced, quantity);
-        if (bias) part = ev_.add_plain(part, bias);
         containers.push_back(part);
     }
+    if (bias) containers = ev_.add_plain_batch(containers, bias);
     return containers;
 }
 

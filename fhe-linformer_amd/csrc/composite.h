@@ -29,7 +29,9 @@ public:
     CtPtr mask_heads_128(const CtPtr& c, double v);
     CtPtr mask_mod_n(const CtPtr& c, int n, int padding);
     CtPtr mask_first_n(const CtPtr& c, int n, double v);
-    PtPtr first_n_mask(int n, double v);   // the cached mask plaintext itself (batched callers)
+    PtPtr first_n_mask(int n, double v);   // the cached mask plaintexts themselves (batched callers)
+    PtPtr block_mask(int from, int to, double v);
+    PtPtr mod_n_mask(int n, int padding);
 
     // log-tree reductions                                                                     :829-867
     CtPtr rotsum(const CtPtr& in, int slots, int padding);

@@ -19,6 +19,14 @@ DevicePool::~DevicePool() {
 void* DevicePool::alloc(size_t bytes) {
     if (bytes == 0) bytes = 256;
     bytes = (bytes + 255) & ~size_t(255);
+    // size classes 2^k x {1, 1.25, 1.5, 1.75} above 1 MiB: batches of slightly different row counts share blocks instead
+    // of each parking its own exact size in the idle lists (<= 25 % slack)
+    if (bytes > (size_t(1) << 20)) {
+        size_t p2 = size_t(1) << 20;
+        while (p2 * 2 <= bytes) p2 *= 2;
+        const size_t step = p2 / 4;
+        bytes = (bytes + step - 1) / step * step;
+    }
     auto& idle = idle_[cur_lane];
     auto it = idle.find(bytes);
     void* p = nullptr;
@@ -28,6 +36,7 @@ void* DevicePool::alloc(size_t bytes) {
     } else {
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
+            (void)hipGetLastError();  // the failure is handled here; do not leave it for the next launch check
             trim();
             hip_check(hipMalloc(&p, bytes), "hipMalloc");
         }

@@ -1,4 +1,5 @@
 #include "evaluator.h"
+#include <map>
 #include <hip/hip_runtime.h>
 #include <cmath>
 
@@ -389,37 +390,118 @@ std::vector<CtPtr> Evaluator::rescale_batch(const std::vector<CtPtr>& vin) {
 }
 
 std::vector<CtPtr> Evaluator::mult_plain_batch(const std::vector<CtPtr>& vin, const PtPtr& p) {
+    return mult_plain_each(vin, std::vector<PtPtr>(vin.size(), p));
+}
+
+namespace {
+// consecutive runs of operands with the same (components, limbs): one output block and one launch per <= 32 of them
+template <class SameShape, class Emit>
+void for_runs(size_t n, SameShape same, Emit emit) {
+    size_t lo = 0;
+    while (lo < n) {
+        size_t hi = lo + 1;
+        while (hi < n && hi - lo < (size_t)EwItems::MAX_ITEMS && same(lo, hi)) ++hi;
+        emit(lo, hi);
+        lo = hi;
+    }
+}
+}  // namespace
+
+std::vector<CtPtr> Evaluator::mult_plain_each(const std::vector<CtPtr>& vin, const std::vector<PtPtr>& p) {
+    if (vin.size() != p.size()) throw Error(FHELIN_ERR_ARG, "mult_plain_each: one plaintext per ciphertext");
     if (vin.empty()) return {};
     std::vector<CtPtr> x = vin;
     {
+        // degree-2 operands are rescaled first (as in mult_plain); the same ciphertext may occur many times (one
+        // container masked 128 ways): rescale every distinct one once
         std::vector<CtPtr> need;
-        std::vector<size_t> pos;
+        std::map<const Ciphertext*, size_t> slot;
         for (size_t i = 0; i < vin.size(); ++i)
-            if (vin[i]->deg >= 2) {
+            if (vin[i]->deg >= 2 && !slot.count(vin[i].get())) {
+                slot[vin[i].get()] = need.size();
                 need.push_back(vin[i]);
-                pos.push_back(i);
             }
         if (!need.empty()) {
             std::vector<CtPtr> r = rescale_batch(need);
-            for (size_t k = 0; k < pos.size(); ++k) x[pos[k]] = r[k];
+            for (size_t i = 0; i < vin.size(); ++i)
+                if (vin[i]->deg >= 2) x[i] = r[slot[vin[i].get()]];
         }
     }
-    bool uniform = true;
-    for (const CtPtr& c : x) uniform = uniform && c->npoly == 2 && c->ell == x[0]->ell && c->deg == x[0]->deg;
-    if (!uniform) {
-        std::vector<CtPtr> out;
-        for (const CtPtr& c : vin) out.push_back(mult_plain(c, p));
-        return out;
+    std::vector<CtPtr> out(x.size());
+    for_runs(x.size(), [&](size_t a, size_t b) { return x[a]->npoly == x[b]->npoly && x[a]->ell == x[b]->ell && x[a]->deg == x[b]->deg; },
+             [&](size_t lo, size_t hi) {
+                 const CtPtr& f = x[lo];
+                 std::vector<CtPtr> o = new_ct_batch((int)(hi - lo), f->npoly, f->ell, f->deg + 1, f->scale, f->slots);
+                 EwItems it;
+                 it.n = (int)(hi - lo);
+                 it.vecs = f->npoly * f->ell;
+                 it.b_vecs = f->ell;
+                 for (size_t i = lo; i < hi; ++i) {
+                     auto enc = p[i]->at(x[i]->ell, c_.sf_real[x[i]->level()]);
+                     o[i - lo]->scale = x[i]->scale * enc->scale;
+                     it.out[i - lo] = o[i - lo]->d;
+                     it.a[i - lo] = x[i]->d;
+                     it.b[i - lo] = enc->d;
+                     out[i] = o[i - lo];
+                 }
+                 launch_ew_items(c_.dt, it, 0, f->ell, c_.stream);
+                 c_.stats.ct_pt_mult += (u64)(hi - lo);
+             });
+    launch_ok("mult_plain_each");
+    return out;
+}
+
+std::vector<CtPtr> Evaluator::add_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) {
+    if (a.size() != b.size()) throw Error(FHELIN_ERR_ARG, "add_batch: operand count mismatch");
+    std::vector<CtPtr> x(a.size()), y(a.size()), out(a.size());
+    for (size_t i = 0; i < a.size(); ++i) {
+        if (a[i]->npoly != b[i]->npoly) throw Error(FHELIN_ERR_STATE, "add: component count mismatch");
+        match(a[i], b[i], x[i], y[i]);
     }
-    auto enc = p->at(x[0]->ell, c_.sf_real[x[0]->level()]);
-    std::vector<CtPtr> o = new_ct_batch((int)x.size(), 2, x[0]->ell, x[0]->deg + 1, x[0]->scale * enc->scale, x[0]->slots);
-    for (size_t i = 0; i < x.size(); ++i) {
-        o[i]->scale = x[i]->scale * enc->scale;
-        launch_ew_mul(c_.dt, o[i]->d, x[i]->d, enc->d, 2 * x[i]->ell, x[i]->ell, 0, x[i]->ell, c_.stream);
-    }
-    c_.stats.ct_pt_mult += x.size();
-    launch_ok("mult_plain_batch");
-    return o;
+    for_runs(x.size(), [&](size_t p, size_t q) { return x[p]->npoly == x[q]->npoly && x[p]->ell == x[q]->ell; },
+             [&](size_t lo, size_t hi) {
+                 const CtPtr& f = x[lo];
+                 std::vector<CtPtr> o = new_ct_batch((int)(hi - lo), f->npoly, f->ell, f->deg, f->scale, f->slots);
+                 EwItems it;
+                 it.n = (int)(hi - lo);
+                 it.vecs = it.b_vecs = f->npoly * f->ell;
+                 for (size_t i = lo; i < hi; ++i) {
+                     o[i - lo]->deg = x[i]->deg;
+                     o[i - lo]->scale = x[i]->scale;
+                     it.out[i - lo] = o[i - lo]->d;
+                     it.a[i - lo] = x[i]->d;
+                     it.b[i - lo] = y[i]->d;
+                     out[i] = o[i - lo];
+                 }
+                 launch_ew_items(c_.dt, it, 1, f->ell, c_.stream);
+             });
+    launch_ok("add_batch");
+    return out;
+}
+
+std::vector<CtPtr> Evaluator::add_plain_batch(const std::vector<CtPtr>& v, const PtPtr& p) {
+    std::vector<CtPtr> out(v.size());
+    for_runs(v.size(), [&](size_t a, size_t b) { return v[a]->npoly == v[b]->npoly && v[a]->ell == v[b]->ell; },
+             [&](size_t lo, size_t hi) {
+                 const CtPtr& f = v[lo];
+                 std::vector<CtPtr> o = new_ct_batch((int)(hi - lo), f->npoly, f->ell, f->deg, f->scale, f->slots);
+                 EwItems it;
+                 it.n = (int)(hi - lo);
+                 it.vecs = f->npoly * f->ell;
+                 it.b_vecs = f->ell;
+                 for (size_t i = lo; i < hi; ++i) {
+                     auto enc = p->at(v[i]->ell, v[i]->scale);
+                     o[i - lo]->deg = v[i]->deg;
+                     o[i - lo]->scale = v[i]->scale;
+                     it.out[i - lo] = o[i - lo]->d;
+                     it.a[i - lo] = v[i]->d;
+                     it.b[i - lo] = enc->d;
+                     out[i] = o[i - lo];
+                 }
+                 launch_ew_items(c_.dt, it, 3, f->ell, c_.stream);
+             });
+    launch_ok("add_plain_batch");
+    return out;
 }
 
 CtPtr Evaluator::rotate_add(const CtPtr& a, int index) {

@@ -114,6 +114,11 @@ public:
     std::vector<CtPtr> rotate_batch(const std::vector<CtPtr>& v, int index);
     std::vector<CtPtr> rotate_batch_impl(const std::vector<CtPtr>& v, int index, bool accumulate);
     std::vector<CtPtr> mult_plain_batch(const std::vector<CtPtr>& v, const PtPtr& p);
+    // element-wise ops over many independent ciphertexts, one launch per 32 operands of identical shape; the
+    // bookkeeping (rescale before a product, level/scale matching before a sum) is exactly that of the single ops
+    std::vector<CtPtr> mult_plain_each(const std::vector<CtPtr>& v, const std::vector<PtPtr>& p);  // v[i] * p[i]
+    std::vector<CtPtr> add_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b);        // a[i] + b[i]
+    std::vector<CtPtr> add_plain_batch(const std::vector<CtPtr>& v, const PtPtr& p);
     std::vector<CtPtr> rescale_batch(const std::vector<CtPtr>& v);
 
     // ---- leveled ops (functional: inputs are never modified)

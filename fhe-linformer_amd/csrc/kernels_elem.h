@@ -27,6 +27,20 @@ void launch_modraise(const DeviceTables& t, u64* out, const u64* src, int npoly,
 void launch_reduce_i128(const DeviceTables& t, u64* out, const u64* coeffs, int limb_first, int nlimbs, hipStream_t s);
 
 // ---- hybrid key switching (K6-K8)
+// Element-wise op over up to MAX_ITEMS independent operands of identical shape in ONE launch (grid.y = items x vectors):
+//   out_i[v] = a_i[v] (op) b_i[v % b_vecs]     op 0 mul, 1 add, 2 sub;   op 3: add for v < b_vecs, copy otherwise
+// (op 3 = ciphertext + plaintext: only component 0 changes).  Pointers travel in the kernel arguments.
+struct EwItems {
+    static constexpr int MAX_ITEMS = 32;
+    int n = 0;
+    int vecs = 0;
+    int b_vecs = 0;
+    u64* out[MAX_ITEMS];
+    const u64* a[MAX_ITEMS];
+    const u64* b[MAX_ITEMS];
+};
+void launch_ew_items(const DeviceTables& t, const EwItems& it, int op, int limb_count, hipStream_t s);
+
 struct KsShape {
     int ell;     // live Q limbs
     int k;       // special limbs

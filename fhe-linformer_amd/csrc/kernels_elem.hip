@@ -52,6 +52,33 @@ __global__ __launch_bounds__(256) void ew_binary_kernel(DeviceTables t, u64* out
     reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
 }
 
+template <int OP>
+__global__ __launch_bounds__(256) void ew_items_kernel(DeviceTables t, EwItems it, int limb_count) {
+    const int item = blockIdx.y / it.vecs, v = blockIdx.y % it.vecs;
+    const int limb = v % limb_count;
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const u64x2 x = reinterpret_cast<const u64x2*>(it.a[item])[(size_t)v * row + n2];
+    u64x2 r = x;
+    if (OP != 3 || v < it.b_vecs) {
+        const u64x2 y = reinterpret_cast<const u64x2*>(it.b[item])[(size_t)(v % it.b_vecs) * row + n2];
+        if (OP == 0) {
+            const Barrett br = load_barrett(t, limb);
+            r.x = mul_mod(x.x, y.x, br);
+            r.y = mul_mod(x.y, y.y, br);
+        } else if (OP == 2) {
+            const u64 q = t.moduli[limb];
+            r.x = sub_mod(x.x, y.x, q);
+            r.y = sub_mod(x.y, y.y, q);
+        } else {
+            const u64 q = t.moduli[limb];
+            r.x = add_mod(x.x, y.x, q);
+            r.y = add_mod(x.y, y.y, q);
+        }
+    }
+    reinterpret_cast<u64x2*>(it.out[item])[(size_t)v * row + n2] = r;
+}
+
 // out[v] = acc[v] + a[v] * b[v % b_mod]
 __global__ __launch_bounds__(256) void ew_muladd_kernel(DeviceTables t, u64* out, const u64* acc, const u64* a, const u64* b,
                                                         int b_mod, int limb_first, int limb_count) {
@@ -230,6 +257,16 @@ inline dim3 grid2(int log_n, int nvec) { return dim3((1u << log_n) / 512, (unsig
 
 }  // namespace
 
+void launch_ew_items(const DeviceTables& t, const EwItems& it, int op, int limb_count, hipStream_t s) {
+    if (it.n <= 0 || it.vecs <= 0) return;
+    const dim3 g = grid2(t.log_n, it.n * it.vecs);
+    switch (op) {
+        case 0: hipLaunchKernelGGL((ew_items_kernel<0>), g, dim3(256), 0, s, t, it, limb_count); break;
+        case 1: hipLaunchKernelGGL((ew_items_kernel<1>), g, dim3(256), 0, s, t, it, limb_count); break;
+        case 2: hipLaunchKernelGGL((ew_items_kernel<2>), g, dim3(256), 0, s, t, it, limb_count); break;
+        default: hipLaunchKernelGGL((ew_items_kernel<3>), g, dim3(256), 0, s, t, it, limb_count); break;
+    }
+}
 void launch_ew_mul(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s) {
     if (nvec <= 0) return;
     hipLaunchKernelGGL((ew_binary_kernel<0>), grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, b, b_mod, limb_first, limb_count);
