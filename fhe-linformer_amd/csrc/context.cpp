@@ -131,6 +131,7 @@ Context::Context(const Params& p) : prm(p) {
         }
         hip_check(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming), "hipEventCreate(fork)");
         if (const char* e = std::getenv("FHELIN_ASYNC")) async_lanes = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FHELIN_FUSE_MODDOWN")) fuse_moddown = std::atoi(e) != 0;
     }
     hip_check(hipEventCreate(&ev_start), "hipEventCreate");
     stage_words = (size_t)2 << p.log_n;
@@ -339,20 +340,41 @@ u64 Context::galois_element(int r) const {
     return g;
 }
 
-const u32* Context::automorph_map(u64 g) {
-    require_device();
-    auto it = automorph_maps.find(g);
-    if (it != automorph_maps.end()) return it->second;
-    const int ln = prm.log_n;
+static std::vector<u32> build_automorph_map(u64 g, size_t N, int ln) {
     const u64 M = 2ull * N;
     std::vector<u32> m(N);
     for (u32 j = 0; j < (u32)N; ++j) {
         u64 e = (2ull * bitrev32(j, ln) + 1) * g % M;  // odd exponent of the evaluation point that feeds slot j
         m[j] = bitrev32((u32)((e - 1) >> 1), ln);
     }
-    const u32* d = upload_table(m);
+    return m;
+}
+
+const u32* Context::automorph_map(u64 g) {
+    require_device();
+    auto it = automorph_maps.find(g);
+    if (it != automorph_maps.end()) return it->second;
+    const u64 M = 2ull * N;
+    u64 gi = g;  // g^-1 mod 2N (g odd, 2N a power of two): Newton steps double the number of correct bits
+    for (int i = 0; i < 6; ++i) gi = gi * (2 - g * gi % M + M) % M;
+    const u32* d = upload_table(build_automorph_map(g, N, prm.log_n));
     automorph_maps[g] = d;
+    const u32* di = d;
+    if (gi != g) {
+        auto iit = automorph_maps.find(gi);
+        di = iit != automorph_maps.end() ? iit->second : upload_table(build_automorph_map(gi, N, prm.log_n));
+        automorph_maps[gi] = di;
+    }
+    automorph_inverse[d] = di;
+    automorph_inverse[di] = d;
     return d;
+}
+
+const u32* Context::automorph_inverse_of(const u32* map) {
+    if (!map) return nullptr;
+    auto it = automorph_inverse.find(map);
+    if (it == automorph_inverse.end()) throw Error(FHELIN_ERR_INTERNAL, "automorphism map without a registered inverse");
+    return it->second;
 }
 
 }  // namespace fhelin

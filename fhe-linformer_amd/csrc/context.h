@@ -160,11 +160,21 @@ struct Context {
     int digits_at(int ell) const { return (ell + alpha - 1) / alpha; }
     u64 galois_element(int rot_index) const;       // 5^r mod 2N (r may be negative)
     const u32* automorph_map(u64 galois);          // device map for the NTT-domain permutation
+    const u32* automorph_inverse_of(const u32* map);  // the map of the inverse automorphism (built together with `map`)
+    std::map<const u32*, const u32*> automorph_inverse;
+    // FHELIN_FUSE_MODDOWN=1: K8b as an epilogue of NTT(conv)'s row pass instead of its own kernel.  Bit-identical, one
+    // memory pass fewer — and measured SLOWER end to end (1615 vs 1574 ms/sample): the epilogue's ~25 instructions per
+    // residue land in the VALU-bound NTT, while the separate kernel is bandwidth-bound and overlaps with it.  Off.
+    bool fuse_moddown = false;
     void sync();
     // K1 launch + accounting (active = vectors actually transformed, for tables with skipped entries)
     void ntt(const LimbBatch& b, bool inverse, int active = -1) {
         stats.limb_ntt += (u64)(active >= 0 ? active : b.nvec);
         launch_ntt(dt, b, inverse, stream);
+    }
+    void ntt_moddown(const LimbBatch& b, const NttModDown& md) {
+        stats.limb_ntt += (u64)b.nvec;
+        launch_ntt_moddown(dt, b, md, stream);
     }
 };
 

@@ -164,8 +164,31 @@ void Evaluator::keyswitch_impl(int B, const KsRows* rows, const u64* c_ntt, size
     c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
     u64* conv = c_.dalloc<u64>((size_t)B * 2 * ell * N);
     launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
-    c_.ntt(LimbBatch{conv, B * 2 * ell, nullptr, 0, ell}, false);
-    launch_moddown_finish(c_.dt, sh, out, accQ, conv, c_.d_pinv, add0, add1, map, post, s);
+    if (c_.fuse_moddown) {
+        // K8b rides in the row pass of NTT(conv): (accQ - NTT(conv)) * P^-1 + add (+ post) is formed in registers and
+        // written through the inverse automorphism map — NTT(conv) never goes to memory
+        NttModDown md;
+        md.accQ = accQ;
+        md.out = out;
+        md.add0 = add0;
+        md.add1 = add1;
+        md.post = post;
+        md.pinv = c_.d_pinv;
+        md.ell = ell;
+        md.out_stride = out_stride;
+        md.add_stride = add_stride;
+        md.post_stride = post_stride;
+        if (rows) {
+            md.per_row = 1;
+            for (int b = 0; b < B; ++b) md.invmap_row[b] = c_.automorph_inverse_of(rows->maps[b]);
+        } else {
+            md.invmap = c_.automorph_inverse_of(map);
+        }
+        c_.ntt_moddown(LimbBatch{conv, B * 2 * ell, nullptr, 0, ell}, md);
+    } else {
+        c_.ntt(LimbBatch{conv, B * 2 * ell, nullptr, 0, ell}, false);
+        launch_moddown_finish(c_.dt, sh, out, accQ, conv, c_.d_pinv, add0, add1, map, post, s);
+    }
     launch_ok("keyswitch");
     c_.pool.free(cc);
     c_.pool.free(ext);

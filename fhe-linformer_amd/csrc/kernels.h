@@ -40,9 +40,31 @@ struct DeviceTables {
     const u64* ninv;       // [n_limbs][8]   N^{-1}, shoup, ipsi_br[1]*N^{-1}, shoup, lazy shift, lazy ratio, 0, 0
 };
 
+// Optional epilogue of the FORWARD transform's row pass: instead of storing NTT(conv), finish the ModDown of hybrid key
+// switching in registers (K8b, see kernels_elem.h launch_moddown_finish):
+//   out[bi][c][t][j] = (accQ[v][m] - NTT(conv)[v][m]) * P^-1 + add_c[bi][t][m] (+ post[bi][c][t][j]),   j = invmap[m]
+// for vector v = (bi*2 + c)*ell + t.  invmap is the INVERSE automorphism map (position m lands at j), so a wave still
+// writes whole 128-byte lines: the map permutes lines and the 16 residues inside a line.
+struct NttModDown {
+    static constexpr int MAX_ROWS = 16;
+    const u64* accQ = nullptr;
+    u64* out = nullptr;
+    const u64* add0 = nullptr;
+    const u64* add1 = nullptr;
+    const u64* post = nullptr;
+    const u32* invmap = nullptr;
+    const u64* pinv = nullptr;   // [L+1][2] P^-1 mod q_t, shoup
+    int ell = 0;
+    size_t out_stride = 0, add_stride = 0, post_stride = 0;
+    int per_row = 0;
+    const u32* invmap_row[MAX_ROWS] = {};
+};
+
 // K1: negacyclic NTT (natural -> bit-reversed) / INTT (bit-reversed -> natural, scaled by N^{-1}).
 // In place, canonical [0,q) in and out.
 void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStream_t s);
+// forward NTT of b (conv, [batch][2][ell][N]) whose row pass ends in the ModDown epilogue; b.data is scratch afterwards
+void launch_ntt_moddown(const DeviceTables& t, const LimbBatch& b, const NttModDown& md, hipStream_t s);
 
 // micro-benchmark kernels used by bench.py --micro to calibrate the integer-multiply ceiling
 void launch_mulbench(u64* out, int iters, int variant, int blocks, hipStream_t s);

@@ -300,7 +300,7 @@ __device__ __forceinline__ void cols_body(const NttArgs& a, u64* lds, int vec, i
 }
 
 template <int A, bool INVERSE>
-__global__ __launch_bounds__(256) void ntt_cols_kernel(NttArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ntt_cols_kernel(NttArgs a) {
     constexpr int LOGTILES = A - 4;
     __shared__ u64 lds[LDS_WORDS];
     const int vec = blockIdx.x >> LOGTILES;
@@ -318,8 +318,9 @@ __global__ __launch_bounds__(256) void ntt_cols_kernel(NttArgs a) {
 // pass B: row transforms over the low 8 bits of the index.  Tile = 16 consecutive rows of 256
 // (4096 contiguous residues); tile-local index e == global index - tile*4096.
 // ------------------------------------------------------------------------------------------------
-template <bool INVERSE, bool LAZY>
-__device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, int tile, int limb, const LimbConst& c) {
+template <bool INVERSE, bool LAZY, bool MODDOWN>
+__device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, int tile, int limb, const LimbConst& c,
+                                          const NttModDown* md) {
     const int log_n = a.log_n;
     const u64x2* tw = reinterpret_cast<const u64x2*>(a.tw) + ((size_t)limb << log_n);
     const u64x2* trows = reinterpret_cast<const u64x2*>(a.tw_rows) + (((size_t)limb << (log_n - 12)) + tile) * (15 * 256);
@@ -343,8 +344,31 @@ __device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, i
         // window at bit 0 leaves 16 consecutive residues per thread (128-byte lane stride); one more LDS exchange
         // to the bit-8 window makes every store instruction a contiguous 512-byte wave access
         exchange(x, lds, tau, 0, 8, true);
+        if constexpr (MODDOWN) {
+            const int ell = md->ell;
+            const int bi = vec / (2 * ell), comp = (vec / ell) & 1, t = vec % ell;
+            const size_t n = (size_t)1 << log_n;
+            const u64 pw = md->pinv[2 * t], pws = md->pinv[2 * t + 1];
+            const u64* aq = md->accQ + ((size_t)vec << log_n) + ((size_t)tile << 12);
+            const u64* add = comp == 0 ? md->add0 : md->add1;
+            if (add) add += (size_t)bi * md->add_stride + (size_t)t * n + ((size_t)tile << 12);
+            const u32* im = md->per_row ? md->invmap_row[bi] : md->invmap;
+            const u64* post = md->post ? md->post + (size_t)bi * md->post_stride + (size_t)(comp * ell + t) * n : nullptr;
+            u64* out = md->out + (size_t)bi * md->out_stride + (size_t)(comp * ell + t) * n;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) base[tile_index(tau, k, 8)] = x[k];
+            for (int k = 0; k < 16; ++k) {
+                const int e = tile_index(tau, k, 8);
+                u64 r = mul_shoup(sub_mod(aq[e], x[k], c.q), pw, pws, c.q);
+                if (add) r = add_mod(r, add[e], c.q);
+                const size_t m = ((size_t)tile << 12) + e;
+                const size_t j = im ? (size_t)im[m] : m;
+                if (post) r = add_mod(r, post[j], c.q);
+                out[j] = r;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) base[tile_index(tau, k, 8)] = x[k];
+        }
     } else {
         // coalesced load through the bit-8 window, then an LDS exchange to the bit-0 window of the first GS round
 #pragma unroll
@@ -365,8 +389,8 @@ __device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, i
     }
 }
 
-template <bool INVERSE>
-__global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
+template <bool INVERSE, bool MODDOWN = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ntt_rows_kernel(NttArgs a, NttModDown md) {
     __shared__ u64 lds[LDS_WORDS];
     const int logtiles = a.log_n - 12;
     // Block -> (vector, tile) map.  A row tile needs its own 4 KiB twiddle slice per (limb, tile); vectors of the same
@@ -390,9 +414,9 @@ __global__ __launch_bounds__(256) void ntt_rows_kernel(NttArgs a) {
     if (limb < 0) return;
     const LimbConst c = limb_const(a, limb);
     if (lazy_prime(c.q))
-        rows_body<INVERSE, true>(a, lds, vec, tile, limb, c);
+        rows_body<INVERSE, true, MODDOWN>(a, lds, vec, tile, limb, c, &md);
     else
-        rows_body<INVERSE, false>(a, lds, vec, tile, limb, c);
+        rows_body<INVERSE, false, MODDOWN>(a, lds, vec, tile, limb, c, &md);
 }
 
 template <int A>
@@ -405,7 +429,14 @@ void launch_cols(const NttArgs& a, bool inverse, int blocks, hipStream_t s) {
 
 }  // namespace
 
-void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStream_t s) {
+static void launch_ntt_impl(const DeviceTables& t, const LimbBatch& b, bool inverse, const NttModDown* md, hipStream_t s);
+
+void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStream_t s) { launch_ntt_impl(t, b, inverse, nullptr, s); }
+void launch_ntt_moddown(const DeviceTables& t, const LimbBatch& b, const NttModDown& md, hipStream_t s) {
+    launch_ntt_impl(t, b, false, &md, s);
+}
+
+static void launch_ntt_impl(const DeviceTables& t, const LimbBatch& b, bool inverse, const NttModDown* md, hipStream_t s) {
     if (b.nvec <= 0) return;
     NttArgs a;
     a.data = b.data;
@@ -442,9 +473,12 @@ void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStre
         cols();
         a.src = a.data;
         a.src_group = 0;
-        hipLaunchKernelGGL((ntt_rows_kernel<false>), dim3(blocks), dim3(256), 0, s, a);
+        if (md)
+            hipLaunchKernelGGL((ntt_rows_kernel<false, true>), dim3(blocks), dim3(256), 0, s, a, *md);
+        else
+            hipLaunchKernelGGL((ntt_rows_kernel<false, false>), dim3(blocks), dim3(256), 0, s, a, NttModDown());
     } else {
-        hipLaunchKernelGGL((ntt_rows_kernel<true>), dim3(blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((ntt_rows_kernel<true, false>), dim3(blocks), dim3(256), 0, s, a, NttModDown());
         a.src = a.data;
         a.src_group = 0;
         cols();
