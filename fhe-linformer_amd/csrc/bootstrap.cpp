@@ -291,12 +291,14 @@ CtPtr Bootstrapper::mod_raise(const CtPtr& ct, long double& rho) {
     return up;
 }
 
-CtPtr Bootstrapper::eval_mod(const CtPtr& x) {
-    CtPtr u = ev_.eval_chebyshev(x, cheb_, -1.0, 1.0);
+// EvalMod of the real and the imaginary half together: both go through the same Chebyshev fit and double-angle steps,
+// so every multiplication is one batched relinearisation over the pair
+std::vector<CtPtr> Bootstrapper::eval_mod(const std::vector<CtPtr>& xs) {
+    std::vector<CtPtr> u = ev_.eval_chebyshev_many(xs, cheb_, -1.0, 1.0);
     for (int i = 0; i < R; ++i) {
-        CtPtr t = ev_.mult(u, u);
-        t = ev_.add(t, t);
-        u = ev_.add_real(t, -1.0);
+        std::vector<CtPtr> t = ev_.mult_batch(u, u);
+        t = ev_.add_batch(t, t);
+        for (size_t k = 0; k < t.size(); ++k) u[k] = ev_.add_real(t[k], -1.0);
     }
     return u;
 }
@@ -311,10 +313,9 @@ CtPtr Bootstrapper::run(const CtPtr& ct, int stop_after) {
     CtPtr a = ev_.add(w, wc);                    // real parts  t_k       / (q0 K)   (1/2 folded into the DFT constants)
     if (stop_after == 2) return a;
     CtPtr b = mult_i(ev_.sub(wc, w));            // imaginary   t_{k+n}   / (q0 K)
-    CtPtr a2 = eval_mod(a);
-    if (stop_after == 3) return a2;
-    CtPtr b2 = eval_mod(b);
-    CtPtr v = ev_.add(a2, mult_i(b2));
+    if (stop_after == 3) return eval_mod({a})[0];
+    std::vector<CtPtr> ab = eval_mod({a, b});
+    CtPtr v = ev_.add(ab[0], mult_i(ab[1]));
     for (const auto& st : s2c_) v = apply(st, v);
     // slots now hold m * rho / 2^correction: undo the correction exactly and absorb rho in the scale
     v = ev_.mult_int(v, 1ull << correction, false, v->scale);

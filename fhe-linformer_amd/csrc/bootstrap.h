@@ -56,7 +56,7 @@ private:
     CtPtr apply(const LinStage& st, const CtPtr& x);
     CtPtr mult_i(const CtPtr& x);
     CtPtr mod_raise(const CtPtr& ct, long double& rho);
-    CtPtr eval_mod(const CtPtr& x);
+    std::vector<CtPtr> eval_mod(const std::vector<CtPtr>& xs);
     CtPtr run(const CtPtr& ct, int stop_after);
 };
 

@@ -474,7 +474,10 @@ std::vector<CtPtr> Evaluator::mult_plain_each(const std::vector<CtPtr>& vin, con
     return out;
 }
 
-std::vector<CtPtr> Evaluator::add_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) {
+std::vector<CtPtr> Evaluator::add_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 1); }
+std::vector<CtPtr> Evaluator::sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 2); }
+
+std::vector<CtPtr> Evaluator::add_sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b, int op) {
     if (a.size() != b.size()) throw Error(FHELIN_ERR_ARG, "add_batch: operand count mismatch");
     std::vector<CtPtr> x(a.size()), y(a.size()), out(a.size());
     for (size_t i = 0; i < a.size(); ++i) {
@@ -496,9 +499,52 @@ std::vector<CtPtr> Evaluator::add_batch(const std::vector<CtPtr>& a, const std::
                      it.b[i - lo] = y[i]->d;
                      out[i] = o[i - lo];
                  }
-                 launch_ew_items(c_.dt, it, 1, f->ell, c_.stream);
+                 launch_ew_items(c_.dt, it, op, f->ell, c_.stream);
              });
     launch_ok("add_batch");
+    return out;
+}
+
+std::vector<CtPtr> Evaluator::mult_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) {
+    if (a.size() != b.size()) throw Error(FHELIN_ERR_ARG, "mult_batch: operand count mismatch");
+    if (!relin_key) throw Error(FHELIN_ERR_KEY, "no relinearisation key (EvalMultKeyGen not called)");
+    const size_t n = a.size();
+    // operands of degree 2 are rescaled first (every distinct ciphertext once), then brought to a common level per pair
+    std::vector<CtPtr> in;
+    std::map<const Ciphertext*, size_t> slot;
+    for (const auto* side : {&a, &b})
+        for (const CtPtr& c : *side) {
+            if (c->npoly != 2) throw Error(FHELIN_ERR_STATE, "mult: operands must have 2 components");
+            if (c->deg >= 2 && !slot.count(c.get())) {
+                slot[c.get()] = in.size();
+                in.push_back(c);
+            }
+        }
+    std::vector<CtPtr> resc = in.empty() ? std::vector<CtPtr>() : rescale_batch(in);
+    auto ready = [&](const CtPtr& c) { return c->deg >= 2 ? resc[slot[c.get()]] : c; };
+    std::vector<CtPtr> x(n), y(n), out(n);
+    for (size_t i = 0; i < n; ++i) match(ready(a[i]), ready(b[i]), x[i], y[i]);
+    std::vector<char> done(n, 0);
+    for (size_t first = 0; first < n; ++first) {
+        if (done[first]) continue;
+        std::vector<size_t> idx;
+        for (size_t i = first; i < n && (int)idx.size() < batch_limit; ++i)
+            if (!done[i] && x[i]->ell == x[first]->ell) idx.push_back(i);
+        const int B = (int)idx.size(), ell = x[first]->ell;
+        const size_t pn = (size_t)ell * c_.N;
+        std::vector<CtPtr> d = new_ct_batch(B, 3, ell, 2, 0, x[first]->slots);   // tensor products, contiguous [B][3][ell][N]
+        for (int k = 0; k < B; ++k) launch_tensor(c_.dt, d[k]->d, x[idx[k]]->d, y[idx[k]]->d, ell, c_.stream);
+        std::vector<CtPtr> o = new_ct_batch(B, 2, ell, 2, 0, x[first]->slots);
+        keyswitch_batch(B, d[0]->d + 2 * pn, 3 * pn, ell, *relin_key, o[0]->d, 2 * pn, d[0]->d, d[0]->d + pn, 3 * pn, nullptr, nullptr, 0);
+        for (int k = 0; k < B; ++k) {
+            const size_t i = idx[k];
+            o[k]->deg = x[i]->deg + y[i]->deg;
+            o[k]->scale = x[i]->scale * y[i]->scale;
+            out[i] = o[k];
+            done[i] = 1;
+        }
+    }
+    launch_ok("mult_batch");
     return out;
 }
 

@@ -119,6 +119,12 @@ public:
     std::vector<CtPtr> mult_plain_each(const std::vector<CtPtr>& v, const std::vector<PtPtr>& p);  // v[i] * p[i]
     std::vector<CtPtr> add_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b);        // a[i] + b[i]
     std::vector<CtPtr> add_plain_batch(const std::vector<CtPtr>& v, const PtPtr& p);
+    std::vector<CtPtr> sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b);        // a[i] - b[i]
+    // a[i] * b[i] with relinearisation: one batched key switch (shared relin key) per chunk of rows
+    std::vector<CtPtr> mult_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b);
+    // the same Chebyshev series on several ciphertexts at once: every product of the evaluation runs as mult_batch over
+    // all ciphertexts AND all independent nodes of the same depth (baby powers of one doubling round)
+    std::vector<CtPtr> eval_chebyshev_many(const std::vector<CtPtr>& xs, const std::vector<double>& coeffs, double a, double b);
     std::vector<CtPtr> rescale_batch(const std::vector<CtPtr>& v);
 
     // ---- leveled ops (functional: inputs are never modified)
@@ -155,7 +161,9 @@ private:
     void keyswitch_impl(int batch, const KsRows* rows, const u64* c_ntt, size_t c_stride, int ell, const EvalKey* key, u64* out,
                         size_t out_stride, const u64* add0, const u64* add1, size_t add_stride, const u32* map, const u64* post,
                         size_t post_stride);
-    CtPtr cheb_recurse(const std::vector<double>& c, const std::vector<CtPtr>& T, const std::map<int, CtPtr>& G, int baby);
+    typedef std::vector<CtPtr> CtRow;  // one value per input ciphertext
+    CtRow cheb_recurse(const std::vector<double>& c, const std::vector<CtRow>& T, const std::map<int, CtRow>& G, int baby);
+    std::vector<CtPtr> add_sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b, int op);
     void match(const CtPtr& a, const CtPtr& b, CtPtr& ao, CtPtr& bo);
 };
 

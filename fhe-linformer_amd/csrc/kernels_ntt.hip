@@ -211,12 +211,13 @@ __device__ __forceinline__ LimbConst limb_const(const NttArgs& a, int limb) {
     c.rr = (u32)a.ninv[8 * limb + 5];
     return c;
 }
-// primes below 2^53 (the 52-bit scaling primes: most limbs) take the lazy path, the 55-bit first prime and the 60-bit
-// special primes the semi-lazy path (one conditional subtraction per butterfly); the choice is uniform per workgroup
+// the 52-bit scaling primes (most limbs) take the lazy path, the 60-bit special primes the semi-lazy path (one
+// conditional subtraction per butterfly), the 55-bit first prime lazy forward / semi-lazy inverse; uniform per workgroup
 #if defined(FHELIN_NTT_FORCE_PATH)  // ISA inspection builds only (tools/isa_count.py): 1 = lazy, 0 = classic
-__device__ __forceinline__ bool lazy_prime(u64) { return FHELIN_NTT_FORCE_PATH; }
+template <bool INVERSE> __device__ __forceinline__ bool lazy_prime(u64) { return FHELIN_NTT_FORCE_PATH; }
 #else
-__device__ __forceinline__ bool lazy_prime(u64 q) { return q < (1ull << 53); }
+// forward: bound 86q must fit 64 bits -> q < 2^57 (covers the 55-bit first prime too); inverse: 1280q -> q < 2^53
+template <bool INVERSE> __device__ __forceinline__ bool lazy_prime(u64 q) { return q < (1ull << (INVERSE ? 53 : 57)); }
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
     const int limb = limb_of(a, vec);
     if (limb < 0) return;
     const LimbConst c = limb_const(a, limb);
-    if (lazy_prime(c.q))
+    if (lazy_prime<INVERSE>(c.q))
         cols_body<A, INVERSE, true>(a, lds, vec, tile, limb, c);
     else
         cols_body<A, INVERSE, false>(a, lds, vec, tile, limb, c);
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
     const int limb = limb_of(a, vec);
     if (limb < 0) return;
     const LimbConst c = limb_const(a, limb);
-    if (lazy_prime(c.q))
+    if (lazy_prime<INVERSE>(c.q))
         rows_body<INVERSE, true, MODDOWN>(a, lds, vec, tile, limb, c, &md);
     else
         rows_body<INVERSE, false, MODDOWN>(a, lds, vec, tile, limb, c, &md);

@@ -97,20 +97,28 @@ CtPtr Evaluator::eval_poly(const CtPtr& x, const std::vector<double>& coeffs) {
     return coeffs[0] != 0.0 ? add_real(acc, coeffs[0]) : acc;
 }
 
-CtPtr Evaluator::cheb_recurse(const std::vector<double>& c, const std::vector<CtPtr>& T, const std::map<int, CtPtr>& G, int baby) {
+// Chebyshev evaluation over a ROW of ciphertexts (one value per input): every op below acts on all inputs at once, the
+// products through mult_batch (one batched relinearisation).
+Evaluator::CtRow Evaluator::cheb_recurse(const std::vector<double>& c, const std::vector<CtRow>& T, const std::map<int, CtRow>& G,
+                                         int baby) {
     int n = (int)c.size() - 1;
     while (n > 0 && c[n] == 0.0) --n;
+    const size_t rows = T[1].size();
     if (n < baby) {
-        CtPtr acc;
+        CtRow acc;
         for (int k = 1; k <= n; ++k) {
             if (c[k] == 0.0) continue;
-            CtPtr t = mult_real(T[k], c[k]);
-            acc = acc ? add(acc, t) : t;
+            CtRow t(rows);
+            for (size_t i = 0; i < rows; ++i) t[i] = mult_real(T[k][i], c[k]);
+            acc = acc.empty() ? t : add_batch(acc, t);
         }
-        if (!acc) {  // constant polynomial: c0 as an encryption-free shift of 0 * T_1
-            acc = mult_real(T[1], 0.0);
+        if (acc.empty()) {  // constant polynomial: c0 as an encryption-free shift of 0 * T_1
+            acc.resize(rows);
+            for (size_t i = 0; i < rows; ++i) acc[i] = mult_real(T[1][i], 0.0);
         }
-        return c[0] != 0.0 ? add_real(acc, c[0]) : acc;
+        if (c[0] != 0.0)
+            for (size_t i = 0; i < rows; ++i) acc[i] = add_real(acc[i], c[0]);
+        return acc;
     }
     int m = baby;
     while (m * 2 <= n) m *= 2;
@@ -121,56 +129,94 @@ CtPtr Evaluator::cheb_recurse(const std::vector<double>& c, const std::vector<Ct
         q[i - m] = 2 * c[i];
         r[2 * m - i] -= c[i];
     }
-    CtPtr qv = cheb_recurse(q, T, G, baby);
-    CtPtr res = mult(qv, G.at(m));
+    CtRow qv = cheb_recurse(q, T, G, baby);
+    CtRow res = mult_batch(qv, G.at(m));
     bool r_zero = true;
     for (double v : r) r_zero = r_zero && v == 0.0;
     if (r_zero) return res;
-    return add(res, cheb_recurse(r, T, G, baby));
+    return add_batch(res, cheb_recurse(r, T, G, baby));
 }
 
 CtPtr Evaluator::eval_chebyshev(const CtPtr& x, const std::vector<double>& coeffs_in, double a, double b) {
+    return eval_chebyshev_many(std::vector<CtPtr>{x}, coeffs_in, a, b)[0];
+}
+
+std::vector<CtPtr> Evaluator::eval_chebyshev_many(const std::vector<CtPtr>& xs, const std::vector<double>& coeffs_in, double a, double b) {
+    if (xs.empty()) return {};
     std::vector<double> c = coeffs_in;
     int n = (int)c.size() - 1;
     while (n > 0 && c[n] == 0.0) --n;
     c.resize(n + 1);
     if (n < 1) throw Error(FHELIN_ERR_ARG, "eval_chebyshev: need degree >= 1");
     c[0] *= 0.5;  // series convention: c0/2 + sum_{k>=1} c_k T_k  (OpenFHE EvalChebyshevSeries)
+    const size_t rows = xs.size();
     // affine map of [a,b] onto [-1,1]
-    CtPtr u = x;
-    if (!(a == -1.0 && b == 1.0)) {
-        u = mult_real(x, 2.0 / (b - a));
-        u = add_real(u, -(a + b) / (b - a));
+    CtRow u(rows);
+    for (size_t i = 0; i < rows; ++i) {
+        u[i] = xs[i];
+        if (!(a == -1.0 && b == 1.0)) {
+            u[i] = mult_real(xs[i], 2.0 / (b - a));
+            u[i] = add_real(u[i], -(a + b) / (b - a));
+        }
+        if (u[i]->deg >= 2) u[i] = rescale(u[i]);
     }
-    if (u->deg >= 2) u = rescale(u);
     int l = 0;
     while ((1 << (2 * l)) < n + 1) ++l;  // baby = 2^ceil(log2(n+1)/2)
-    int baby = std::max(2, 1 << l);
-    std::vector<CtPtr> T(baby + 1);
+    const int baby = std::max(2, 1 << l);
+    std::vector<CtRow> T(baby + 1);
     T[1] = u;
-    for (int k = 2; k <= baby; ++k) {
-        CtPtr t;
-        if (k % 2 == 0) {
-            t = mult(T[k / 2], T[k / 2]);
-            t = add(t, t);
-            t = add_real(t, -1.0);
-        } else {
-            t = mult(T[k / 2], T[k / 2 + 1]);
-            t = add(t, t);
-            t = sub(t, T[1]);
+    // T_k = 2 T_floor(k/2) T_ceil(k/2) - T_(k mod 2): the powers h < k <= 2h only need powers <= h, so each doubling round
+    // is ONE batched multiplication over all its k and all inputs
+    for (int h = 1; h < baby; h *= 2) {
+        const int k_hi = std::min(2 * h, baby);
+        CtRow lhs, rhs;
+        for (int k = h + 1; k <= k_hi; ++k)
+            for (size_t i = 0; i < rows; ++i) {
+                lhs.push_back(T[k / 2][i]);
+                rhs.push_back(T[k - k / 2][i]);
+            }
+        CtRow t = mult_batch(lhs, rhs);
+        t = add_batch(t, t);
+        CtRow odd_a, odd_b;
+        std::vector<size_t> odd_pos;
+        size_t p = 0;
+        for (int k = h + 1; k <= k_hi; ++k)
+            for (size_t i = 0; i < rows; ++i, ++p) {
+                if (k % 2 == 0) {
+                    t[p] = add_real(t[p], -1.0);
+                } else {
+                    odd_a.push_back(t[p]);
+                    odd_b.push_back(T[1][i]);
+                    odd_pos.push_back(p);
+                }
+            }
+        if (!odd_a.empty()) {
+            CtRow d = sub_batch(odd_a, odd_b);
+            for (size_t j = 0; j < odd_pos.size(); ++j) t[odd_pos[j]] = d[j];
         }
-        T[k] = rescale(t);
+        t = rescale_batch(t);
+        p = 0;
+        for (int k = h + 1; k <= k_hi; ++k) {
+            T[k].resize(rows);
+            for (size_t i = 0; i < rows; ++i, ++p) T[k][i] = t[p];
+        }
     }
-    std::map<int, CtPtr> G;
+    std::map<int, CtRow> G;
     G[baby] = T[baby];
     for (int m = baby; m * 2 <= n; m *= 2) {
-        CtPtr t = mult(G[m], G[m]);
-        t = add(t, t);
-        t = add_real(t, -1.0);
-        G[2 * m] = rescale(t);
+        CtRow t = mult_batch(G[m], G[m]);
+        t = add_batch(t, t);
+        for (size_t i = 0; i < rows; ++i) t[i] = add_real(t[i], -1.0);
+        G[2 * m] = rescale_batch(t);
     }
-    std::vector<CtPtr> babies(T.begin(), T.begin() + baby);  // T[0] unused, T[1..baby-1]
-    align_deg1(*this, babies, 1);
+    // per input: bring the baby powers to one common (level, degree 1)
+    std::vector<CtRow> babies(baby, CtRow(rows));  // index 0 unused
+    for (size_t i = 0; i < rows; ++i) {
+        std::vector<CtPtr> col(baby);
+        for (int k = 1; k < baby; ++k) col[k] = T[k][i];
+        align_deg1(*this, col, 1);
+        for (int k = 1; k < baby; ++k) babies[k][i] = col[k];
+    }
     return cheb_recurse(c, babies, G, baby);
 }
 
