@@ -111,9 +111,17 @@ static int log_steps(int slots) {
     return n;
 }
 
+// A degree-2 input (a fresh product) is rescaled BEFORE the rotations instead of lazily before its next multiplication:
+// the same single rescale, but the key switches of the tree then run with one limb fewer (EvalRotate and ModReduce
+// commute up to rounding noise; FHELIN_EARLY_RESCALE=0 restores the reference's order).
+static bool early_rescale() {
+    static const bool v = [] { const char* e = std::getenv("FHELIN_EARLY_RESCALE"); return !e || std::atoi(e) != 0; }();
+    return v;
+}
+
 CtPtr Composite::rotsum(const CtPtr& in, int slots, int padding) {
-    CtPtr r = in;  // handles are immutable: no Clone() needed before the first step
     const int n = log_steps(slots);
+    CtPtr r = (n && early_rescale() && in->deg >= 2 && in->ell >= 2) ? ev_.rescale(in) : in;  // immutable handles: no Clone()
     for (int i = 0; i < n; ++i) r = ev_.rotate_add(r, padding * (1 << i));
     return n ? r : ev_.clone(in);
 }
@@ -121,16 +129,30 @@ CtPtr Composite::rotsum(const CtPtr& in, int slots, int padding) {
 CtPtr Composite::rotsum_padded(const CtPtr& in, int slots) { return rotsum(in, slots, slots); }
 
 CtPtr Composite::repeat(const CtPtr& in, int slots, int padding) {
-    CtPtr r = in;
     const int n = log_steps(slots);
+    CtPtr r = (n && early_rescale() && in->deg >= 2 && in->ell >= 2) ? ev_.rescale(in) : in;
     for (int i = 0; i < n; ++i) r = ev_.rotate_add(r, padding * -(1 << i));
     return n ? r : ev_.clone(in);
 }
 
 // log-tree rotate-and-add over independent rows.  Rows are cut into chunks of `batch_limit`; every chunk runs its
 // whole chain (one batched key switch per step) on its own lane, so chunks overlap on the GPU.
-CtVec Composite::tree_batch(const CtVec& in, int slots, int step_sign, int padding) {
+CtVec Composite::tree_batch(const CtVec& in_raw, int slots, int step_sign, int padding) {
     const int n = log_steps(slots);
+    CtVec in = in_raw;
+    if (n && early_rescale()) {  // see rotsum(): one limb fewer for every key switch of the tree
+        CtVec need;
+        std::vector<size_t> pos;
+        for (size_t i = 0; i < in.size(); ++i)
+            if (in[i]->deg >= 2 && in[i]->ell >= 2) {
+                need.push_back(in[i]);
+                pos.push_back(i);
+            }
+        if (!need.empty()) {
+            CtVec r = ev_.rescale_batch(need);
+            for (size_t k = 0; k < pos.size(); ++k) in[pos[k]] = r[k];
+        }
+    }
     CtVec out(in.size());
     if (!n) {
         for (size_t i = 0; i < in.size(); ++i) out[i] = ev_.clone(in[i]);

@@ -22,7 +22,11 @@ def _read(path):
     return np.array([float(v) for v in open(path).read().strip().split(",")])
 
 
-def test_shim_driver_matches_slot_model(tmp_path):
+@pytest.mark.parametrize("early_rescale", ["1", "0"])
+def test_shim_driver_matches_slot_model(tmp_path, early_rescale):
+    """early_rescale=0 keeps OpenFHE's lazy order (a product stays at its level until its next multiplication), so
+    GetLevel() reads exactly what the reference would print; the default rescales a product before its rotation tree
+    (same values, one limb fewer per key switch) and GetLevel() of such a product reads one higher."""
     from oracle import slotsim as sim
     assert os.path.exists(BIN), "tests/shim/shim_driver missing: run __graft_entry__.build()"
     rng = np.random.default_rng(2024)
@@ -33,7 +37,8 @@ def test_shim_driver_matches_slot_model(tmp_path):
         _write(tmp_path / f"input_{i}.txt", x)
     _write(tmp_path / "W_T.txt", W)          # one row per line, like extract_parameters_numeric.py:28
     _write(tmp_path / "bias.txt", bias)
-    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fhe-linformer_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fhe-linformer_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""),
+               FHELIN_EARLY_RESCALE=early_rescale)
     r = subprocess.run([BIN, str(tmp_path)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "Could not find" in r.stderr          # load_ciphertext of a missing file: message + null handle
@@ -54,4 +59,4 @@ def test_shim_driver_matches_slot_model(tmp_path):
     cr = sim.matmul([Q[0]], wv, None, 128, 1)[0]
     assert np.max(np.abs(_read(tmp_path / "cr.out") - cr)) < 1e-6
     lv = open(tmp_path / "levels.out").read().strip().split(",")
-    assert lv[0] == "0" and lv[3] == "1" and int(lv[1]) >= 1 and int(lv[2]) > int(lv[1])
+    assert lv[0] == ("1" if early_rescale == "1" else "0") and lv[3] == "1" and int(lv[1]) >= 1 and int(lv[2]) > int(lv[1])
