@@ -182,6 +182,10 @@ class Engine:
         if rc != 0:
             raise FhelinError(rc, self.lib.fhelin_last_error().decode())
         self.h = h
+        if self.params.n_p < 0:      # derived by the library (OpenFHE's sizeP rule): read the resolved parameters back
+            rc = self.lib.fhelin_ctx_info(self.h, C.byref(self.params), None, None)
+            if rc != 0:
+                raise FhelinError(rc, self.lib.fhelin_last_error().decode())
         self.log_n, self.N = self.params.log_n, 1 << self.params.log_n
         self.n_q, self.n_p = self.params.n_q, self.params.n_p
         nl = self.n_q + self.n_p

@@ -84,7 +84,21 @@ static u64 prod_mod(const std::vector<u64>& ms, int skip, u64 t) {
     return r;
 }
 
-Context::Context(const Params& p) : prm(p) {
+// n_p < 0: the number of special primes OpenFHE's HYBRID parameter generation picks — enough primes of special_bits
+// to cover the widest digit:  sizeP = ceil(max_j bits(prod of digit j) / auxBits)  (29 limbs, dnum 4: 55 + 7*52 = 419 -> 7;
+// the reference's 28 limbs: 55 + 6*52 = 367 -> 7)
+static Params resolve_params(Params p) {
+    if (p.n_p < 0 && p.n_q >= 1 && p.dnum >= 1 && p.special_bits >= 1) {
+        const int a = (p.n_q + p.dnum - 1) / p.dnum;
+        const int first = p.first_bits + (std::min(a, p.n_q) - 1) * p.scale_bits;   // the digit that holds q0
+        const int other = p.n_q > a ? std::min(a, p.n_q - a) * p.scale_bits : 0;
+        p.n_p = (std::max(first, other) + p.special_bits - 1) / p.special_bits;
+    }
+    return p;
+}
+
+Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
+    const Params& p = prm;
     if (p.log_n < 12 || p.log_n > 17) throw Error(FHELIN_ERR_ARG, "log_n must be in [12,17]");
     if (p.n_q < 1 || p.n_q > 64 || p.n_p < 0 || p.n_p > 16) throw Error(FHELIN_ERR_ARG, "bad limb counts");
     if (p.dnum < 1) throw Error(FHELIN_ERR_ARG, "dnum must be >= 1");

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
 __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape sh, u64* __restrict__ accQ, u64* __restrict__ accP, const u64* __restrict__ ext,
                                                        const u64* __restrict__ evk, const u64* __restrict__ c_ntt) {
     const int nt = sh.ell + sh.k;
-    const int bi = blockIdx.y / nt, tt = blockIdx.y % nt;
+    // batch row fastest: the blocks of one target limb's key slice (shared by all rows) are dispatched back to back and
+    // find it in L2 instead of streaming the key once per row
+    const int bi = blockIdx.y % sh.batch, tt = blockIdx.y / sh.batch;
     const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
     if (!sh.shared_input) {
         ext += (size_t)bi * sh.beta * nt * ((size_t)1 << t.log_n);

@@ -169,7 +169,7 @@ public:
 
     /* Context generating/loading (reference :3-235).  The reference's parameters are N=2^15, depth 27 = 28 Q limbs,
      * dnum 4 (:6-35).  This engine's bootstrap consumes 15 levels where OpenFHE's consumes 14, so the chain gets one more
-     * limb (29 Q + 8 special limbs) while `circuit_depth` keeps the reference's value; FHELIN_PRESET=bench selects
+     * limb (29 Q + 7 special limbs) while `circuit_depth` keeps the reference's value; FHELIN_PRESET=bench selects
      * BASELINE.json's ring N=2^16. */
     void generate_context(bool serialize = false, bool secure = false) {
         (void)secure;  // parsed but ignored by the reference as well (:3,:10)
@@ -687,7 +687,7 @@ private:
         p.n_q = 29;
         p.first_bits = 55;
         p.scale_bits = 52;
-        p.n_p = 8;
+        p.n_p = -1;  // OpenFHE's sizeP rule: 7 special limbs for this chain (419-bit digit / 60)
         p.special_bits = 60;
         p.dnum = 4;
         p.log_slots = 14;

@@ -46,7 +46,8 @@ typedef struct fhelin_params {
     int32_t n_q;           /* multiplicative depth + 1               :31-35 */
     int32_t first_bits;    /* SetFirstModSize(55)                    :25    */
     int32_t scale_bits;    /* SetScalingModSize(52), FLEXIBLEAUTO    :18-24 */
-    int32_t n_p;           /* special primes of HYBRID key switching (OpenFHE-internal) */
+    int32_t n_p;           /* special primes of HYBRID key switching (OpenFHE-internal); < 0: OpenFHE's rule
+                              ceil(bits of the widest digit / special_bits), read it back with fhelin_ctx_info */
     int32_t special_bits;  /* 60                                                       */
     int32_t dnum;          /* SetNumLargeDigits(4)                   :11    */
     int32_t log_slots;     /* SetBatchSize(1 << 14)                  :6,14  */

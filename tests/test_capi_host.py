@@ -74,3 +74,19 @@ def test_bad_parameters_are_rejected(fa):
         with pytest.raises(fa.FhelinError) as ei:
             fa.Engine("toy", device=-1, **kw)
         assert ei.value.code == 1
+
+
+@pytest.mark.parametrize("n_q,dnum,want", [(29, 4, 7), (28, 4, 7), (30, 4, 7), (24, 4, 6), (6, 3, 2)])
+def test_special_prime_count_follows_openfhe_rule(fa, n_q, dnum, want):
+    """n_p < 0: ceil(bits of the widest digit / special_bits) special primes, the count OpenFHE's HYBRID parameter
+    generation picks (reference parameters: 28 limbs, dnum 4 -> 55 + 6*52 = 367 bits -> 7; this engine's 29-limb chain:
+    419 bits -> 7).  The product of the special primes must cover every digit."""
+    e = fa.Engine("reference", device=-1, n_q=n_q, dnum=dnum, n_p=-1)
+    try:
+        assert e.n_p == want and len(e.p) == want
+        alpha = -(-n_q // dnum)
+        digits = [e.q[i:i + alpha] for i in range(0, n_q, alpha)]
+        widest = max(sum(np.log2(d.astype(np.float64))) for d in digits)
+        assert sum(np.log2(e.p.astype(np.float64))) >= widest
+    finally:
+        e.close()

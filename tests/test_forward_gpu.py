@@ -1,6 +1,6 @@
 """End-to-end: one encrypted Linformer-d128 forward pass (driver fhe-linformer_amd/linformer.py, the call
 sequence of reference src/main.cpp:145-475 incl. 8 bootstraps) on the GPU at the reference's parameters
-(N=2^15, 16384 slots, dnum 4, 29+8 limbs: depth 27 + 1 because this engine's bootstrap uses 15 levels instead
+(N=2^15, 16384 slots, dnum 4, 29+7 limbs: depth 27 + 1 because this engine's bootstrap uses 15 levels instead
 of OpenFHE's 14), compared by decryption with the SAME operation sequence executed in the clear
 (oracle/circuit_sim.py).  Tolerances (stated): intermediates before the first bootstrap 1e-8; after
 bootstrapping 1e-4 (bootstrap precision ~2e-5); the degree-300 tanh amplifies that to <= 5e-3 on the logits.
@@ -26,7 +26,7 @@ def test_encrypted_forward_matches_plaintext_circuit(fa, variant, preset, n_q):
     sim, st = cs.SlotSimController(), {}
     ref = lf.forward(sim, w, x_in, X_E, X_F, st, variant)
 
-    eng = fa.Engine(preset, seed=11, n_q=n_q, n_p=8)
+    eng = fa.Engine(preset, seed=11, n_q=n_q, n_p=-1)
     try:
         eng.keygen()
         eng.gen_relin_key()
@@ -35,7 +35,10 @@ def test_encrypted_forward_matches_plaintext_circuit(fa, variant, preset, n_q):
         ctl, tr = lf.GpuController(eng), {}
         out = lf.forward(ctl, w, x_in, X_E, X_F, tr, variant)
         assert ctl.n_boot == sim.n_boot == 8                   # 2 (affine-1) + 5 (GELU containers) + 1 (pooler)
-        tol = {"scores": 1e-8, "exp": 1e-8, "self_attention": 1e-8, "affine1_0": 1e-8, "encoder_out": 1e-4, "pooled": 5e-3}
+        # before the first bootstrap only CKKS noise separates the two: with OpenFHE's count of special primes (P barely
+        # above the widest digit) hybrid key switching leaves ~2^-37 relative noise per rotation, ~2e-8 after the thousands
+        # of rotations up to `self_attention`; after bootstrapping its 2.5e-5 precision dominates
+        tol = {"scores": 5e-8, "exp": 5e-8, "self_attention": 5e-8, "affine1_0": 5e-8, "encoder_out": 1e-4, "pooled": 5e-3}
         for k, t in tol.items():
             err = np.max(np.abs(eng.decrypt(tr[k]) - st[k]))
             assert err < t, (k, err)

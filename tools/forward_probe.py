@@ -14,7 +14,7 @@ w = pf.synthetic_model(1234); x = pf.synthetic_tokens(S, 4321)
 x_in, X_E, X_F = pf.client_inputs(w, x)
 sim = cs.SlotSimController(); st = {}
 ref = lf.forward(sim, w, x_in, X_E, X_F, st, variant)
-n_p = -(-n_q // 4)
+n_p = -1   # library rule (OpenFHE sizeP): 7 special limbs for 29-30 Q limbs
 e = fa.Engine(preset, seed=11, n_q=n_q, n_p=n_p)
 t0 = time.time(); e.keygen(); e.gen_relin_key()
 e.gen_rotation_keys(sorted(set([2 ** i for i in range(14)] + [-(2 ** i) for i in range(14)])))
