@@ -11,7 +11,7 @@ bootstrap, FFN 128->512 + Chebyshev GELU + bootstrap, FFN 512->128, affine-2, po
 classifier; 8 bootstraps, ~17k key-switched rotations) over one sample of S=129 tokens + CLS, on synthetic
 weights/tokens (oracle/plain_forward.py, seeds 1234/4321).  Input ciphertexts are encrypted before the timed
 region (resident in HBM); the timed region is pure server-side evaluation plus the final decrypt of the logits.
-Ring: N=2^16, 16384 slots, dnum 4, 29+7 limbs (55-bit q0, 52-bit scaling, 60-bit special) — the reference's
+Ring: N=2^16, 16384 slots, dnum 4, 28+7 limbs (55-bit q0, 52-bit scaling, 60-bit special) — the reference's
 depth 27 (+1: this engine's bootstrap consumes 15 levels where OpenFHE's consumes 14).
 Sharding: independent samples, one per GPU per step (weak scaling), keys replicated, no data-path collective;
 one RCCL all_gather of the logits at the end.
@@ -42,8 +42,8 @@ def parse():
     ap.add_argument("--workload", choices=["forward", "ntt"], default="forward")
     ap.add_argument("--tokens", type=int, default=129, help="tokens per sample (S); S+1 rows incl. CLS, 128 < S+1 <= 256")
     ap.add_argument("--log-n", type=int, default=16)
-    ap.add_argument("--n-q", type=int, default=29)
-    ap.add_argument("--n-p", type=int, default=0, help="special limbs (0: OpenFHE's rule ceil(widest digit bits / 60) = 7 for 29 limbs)")
+    ap.add_argument("--n-q", type=int, default=28)
+    ap.add_argument("--n-p", type=int, default=0, help="special limbs (0: OpenFHE's rule ceil(widest digit bits / 60) = 7 for 28 limbs)")
     ap.add_argument("--ntt-batch", type=int, default=8, help="ciphertexts per NTT step per GPU")
     ap.add_argument("--ntt-steps", type=int, default=30)
     ap.add_argument("--micro", action="store_true", help="instruction-rate probes instead of the benchmark")

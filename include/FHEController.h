@@ -167,10 +167,9 @@ public:
     FHEController(const FHEController&) = delete;
     FHEController& operator=(const FHEController&) = delete;
 
-    /* Context generating/loading (reference :3-235).  The reference's parameters are N=2^15, depth 27 = 28 Q limbs,
-     * dnum 4 (:6-35).  This engine's bootstrap consumes 15 levels where OpenFHE's consumes 14, so the chain gets one more
-     * limb (29 Q + 7 special limbs) while `circuit_depth` keeps the reference's value; FHELIN_PRESET=bench selects
-     * BASELINE.json's ring N=2^16. */
+    /* Context generating/loading (reference :3-235).  The reference's parameters: N=2^15, depth 27 = 28 Q limbs, dnum 4
+     * (:6-35), hence 7 special limbs by OpenFHE's rule — used as they are; FHELIN_PRESET=bench selects BASELINE.json's
+     * ring N=2^16. */
     void generate_context(bool serialize = false, bool secure = false) {
         (void)secure;  // parsed but ignored by the reference as well (:3,:10)
         num_slots = 1 << 14;
@@ -684,10 +683,10 @@ private:
         const char* preset = std::getenv("FHELIN_PRESET");
         const bool bench = preset && string(preset) == "bench";
         p.log_n = bench ? 16 : 15;
-        p.n_q = 29;
+        p.n_q = 28;  // circuit_depth 27 + 1, the reference's chain (:27-31)
         p.first_bits = 55;
         p.scale_bits = 52;
-        p.n_p = -1;  // OpenFHE's sizeP rule: 7 special limbs for this chain (419-bit digit / 60)
+        p.n_p = -1;  // OpenFHE's sizeP rule: 7 special limbs for this chain (367-bit digit / 60)
         p.special_bits = 60;
         p.dnum = 4;
         p.log_slots = 14;

@@ -7,7 +7,7 @@ from fhe_linformer_amd import linformer as lf
 from oracle import plain_forward as pf, circuit_sim as cs
 
 preset = sys.argv[1] if len(sys.argv) > 1 else "reference"
-n_q = int(sys.argv[2]) if len(sys.argv) > 2 else 29
+n_q = int(sys.argv[2]) if len(sys.argv) > 2 else 28
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 129
 variant = sys.argv[4] if len(sys.argv) > 4 else "main"
 w = pf.synthetic_model(1234); x = pf.synthetic_tokens(S, 4321)

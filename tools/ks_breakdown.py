@@ -10,7 +10,7 @@ from oracle import plain_forward as pf
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 129
 w = pf.synthetic_model(1234); x = pf.synthetic_tokens(S, 4321)
 x_in, X_E, X_F = pf.client_inputs(w, x)
-e = fa.Engine("bench", seed=11, n_q=29, n_p=-1)
+e = fa.Engine("bench", seed=11, n_q=28, n_p=-1)
 e.keygen(); e.gen_relin_key()
 e.gen_rotation_keys(sorted(set([2 ** i for i in range(14)] + [-(2 ** i) for i in range(14)])))
 e.bootstrap_setup(3, 3, 16384)
