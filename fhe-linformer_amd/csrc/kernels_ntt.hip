@@ -75,7 +75,7 @@ typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 
 // Per-limb constants of a block.
 struct LimbConst {
-    u64 q, q2;
+    u64 q;
     u64 nq;   // 2^64 - q
     u64 q5;   // 5q   (lazy path: upper bound of mul_shoup_lazy5)
     u32 sh;   // lazy path: reduce_lazy_2q shift and ratio
@@ -204,7 +204,6 @@ __device__ __forceinline__ void exchange(u64 (&x)[16], u64* lds, int tau, int p_
 __device__ __forceinline__ LimbConst limb_const(const NttArgs& a, int limb) {
     LimbConst c;
     c.q = a.moduli[limb];
-    c.q2 = c.q << 1;
     c.nq = 0 - c.q;
     c.q5 = 5 * c.q;
     c.sh = (u32)a.ninv[8 * limb + 4];
