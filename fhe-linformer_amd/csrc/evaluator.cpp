@@ -157,6 +157,7 @@ void Evaluator::keyswitch_impl(int B, const KsRows* rows, const u64* c_ntt, size
     launch_modup_conv(c_.dt, shu, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod, s);
     LimbBatch eb{ext, Bu * lt.beta * nt, lt.ext_limb_tab, 0, 1};
     eb.tab_len = lt.beta * nt;
+    eb.lazy_out = true;  // only K7 reads the digits: it takes any residue below 2^60
     c_.ntt(eb, false, Bu * (lt.beta * nt - ell));
     u64* accQ = c_.dalloc<u64>((size_t)B * 2 * ell * N);
     u64* accP = c_.dalloc<u64>((size_t)B * 2 * K * N);

@@ -23,6 +23,10 @@ struct LimbBatch {
     // strided out-of-place input: vector v is read from src + (v / src_group) * src_group_stride + (v % src_group) * N
     int src_group = 0;         // 0 = src is dense like data
     size_t src_group_stride = 0;
+    // forward only: limbs on the lazy butterfly path (q < 2^53) may leave the transform unreduced, in [0, 86q) < 2^60,
+    // when the consumer takes any value below 2^60 (the evaluation-key inner product K7 splits its operands in 30-bit
+    // halves and reduces the 128-bit sums once).  Saves the final reduction of the row pass.
+    bool lazy_out = false;
 };
 
 // Device-resident per-context tables.

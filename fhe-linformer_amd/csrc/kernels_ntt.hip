@@ -47,6 +47,7 @@ struct NttArgs {
     int log_n;
     int nvec;
     int period;  // > 0: vectors v and v + period use the same limb (twiddles); used to co-schedule them
+    int lazy_out;             // forward: lazy-path limbs below 2^53 skip the final reduction (LimbBatch::lazy_out)
     int src_group;            // > 0: strided first-pass input (see LimbBatch)
     size_t src_group_stride;
 };
@@ -338,9 +339,11 @@ __device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, i
         load_round_tw_rows(rn, trows, tau);                          // per-thread twiddles of the last four stages
         exchange(x, lds, tau, 4, 0, false);
         fwd_round<0, 4, LAZY>(x, rn, c);
+        if (!(LAZY && !MODDOWN && a.lazy_out && c.q < (1ull << 53))) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            x[k] = csub_mask(reduce_lazy_2q(x[k], c.q, c.sh, c.rr), c.q);   // from < 86q (lazy) or < 10q (semi-lazy)
+            for (int k = 0; k < 16; ++k)
+                x[k] = csub_mask(reduce_lazy_2q(x[k], c.q, c.sh, c.rr), c.q);   // from < 86q (lazy) or < 10q (semi-lazy)
+        }
         // window at bit 0 leaves 16 consecutive residues per thread (128-byte lane stride); one more LDS exchange
         // to the bit-8 window makes every store instruction a contiguous 512-byte wave access
         exchange(x, lds, tau, 0, 8, true);
@@ -443,6 +446,7 @@ static void launch_ntt_impl(const DeviceTables& t, const LimbBatch& b, bool inve
     a.src = b.src ? b.src : b.data;
     a.src_group = b.src ? b.src_group : 0;
     a.src_group_stride = b.src_group_stride;
+    a.lazy_out = (!inverse && b.lazy_out) ? 1 : 0;
     a.tw = inverse ? t.tw_inv : t.tw_fwd;
     a.tw_rows = inverse ? t.tw_rows_inv : t.tw_rows_fwd;
     a.moduli = t.moduli;
