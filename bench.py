@@ -8,11 +8,11 @@ driver launches it under torch.distributed.run, one rank per GPU (RCCL over xGMI
 Workload "forward" (default).  A *step* = one encrypted Linformer-d128 forward pass (the call sequence of
 reference src/main.cpp:145-475: Q/K/V matmuls, scores, Taylor^8 exp, Chebyshev 1/x, attention, W_O, affine-1,
 bootstrap, FFN 128->512 + Chebyshev GELU + bootstrap, FFN 512->128, affine-2, pooler with Chebyshev tanh,
-classifier; 8 bootstraps, ~17k key-switched rotations) over one sample of S=129 tokens + CLS, on synthetic
+classifier; 8 bootstraps, ~14.8k key switches) over one sample of S=129 tokens + CLS, on synthetic
 weights/tokens (oracle/plain_forward.py, seeds 1234/4321).  Input ciphertexts are encrypted before the timed
 region (resident in HBM); the timed region is pure server-side evaluation plus the final decrypt of the logits.
-Ring: N=2^16, 16384 slots, dnum 4, 28+7 limbs (55-bit q0, 52-bit scaling, 60-bit special) — the reference's
-depth 27 (+1: this engine's bootstrap consumes 15 levels where OpenFHE's consumes 14).
+Ring: N=2^16, 16384 slots, dnum 4, 28+7 limbs (55-bit q0, 52-bit scaling, 60-bit special) — the reference's own
+chain: depth 27 = 28 Q limbs, and the 7 special limbs OpenFHE's HYBRID rule gives for it.
 Sharding: independent samples, one per GPU per step (weak scaling), keys replicated, no data-path collective;
 one RCCL all_gather of the logits at the end.
 
