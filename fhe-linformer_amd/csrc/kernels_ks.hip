@@ -29,23 +29,18 @@ __device__ __forceinline__ Barrett load_barrett(const DeviceTables& t, int limb)
 
 constexpr int TCH = 16; // targets per block: every z-chunk re-reads the digit's source limbs, so fewer/larger chunks cut traffic
 
-// grid (N/256, beta, ceil((ell+k)/TCH))
-template <int MAXA>
-__global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape sh, u64* __restrict__ ext, const u64* __restrict__ cc, const u64* __restrict__ c_ntt,
-                                                         const u64* __restrict__ hatinv, const u64* __restrict__ hatmod) {
-    const int bi = blockIdx.y / sh.beta, j = blockIdx.y % sh.beta;
+// grid (N/256, beta, ceil((ell+k)/TCH)).  MAXA = digit size alpha (exact for alpha <= 8): full digits run the FULL body, whose
+// loops carry no per-source conditions (the scalar branches otherwise cost about as much as the multiply-accumulates
+// they guard); the shorter last digit takes the guarded body.
+template <int MAXA, bool FULL>
+__device__ __forceinline__ void modup_body(const DeviceTables& t, const KsShape& sh, u64* __restrict__ ext, const u64* __restrict__ cc,
+                                           const u64* __restrict__ hatinv, const u64* __restrict__ hatmod, int j, int lo, int cnt, size_t n) {
     const size_t N = (size_t)1 << t.log_n;
-    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int lo = j * sh.alpha;
-    const int cnt = min(sh.alpha, sh.ell - lo);
     const int nt = sh.ell + sh.k;
-    cc += (size_t)bi * sh.ell * N;
-    c_ntt += (size_t)bi * sh.c_stride;
-    ext += (size_t)bi * sh.beta * nt * N;
     u32 y0[MAXA], y1[MAXA];  // y_i = [c_i * (Q_j/q_i)^{-1}]_{q_i}, split in 30-bit halves
 #pragma unroll
     for (int i = 0; i < MAXA; ++i) {
-        if (i < cnt) {
+        if (FULL || i < cnt) {
             const int li = lo + i;
             split30(mul_shoup(cc[(size_t)li * N + n], hatinv[2 * li], hatinv[2 * li + 1], t.moduli[li]), y0[i], y1[i]);
         } else {
@@ -64,7 +59,7 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
             Acc30 acc = {0, 0, 0};
 #pragma unroll
             for (int i = i0; i < i0 + 8 && i < MAXA; ++i)
-                if (i < cnt) {
+                if (FULL || i < cnt) {
                     const u64 h = hatmod[(size_t)(lo + i) * nt + tt];  // pre-split on the host (pack30)
                     mac30(acc, y0[i], y1[i], (u32)h, (u32)(h >> 32));
                 }
@@ -72,6 +67,24 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
         }
         dst[(size_t)tt * N] = barrett_reduce128(slo, shi, br);
     }
+}
+
+template <int MAXA>
+__global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape sh, u64* __restrict__ ext, const u64* __restrict__ cc, const u64* __restrict__ c_ntt,
+                                                         const u64* __restrict__ hatinv, const u64* __restrict__ hatmod) {
+    const int bi = blockIdx.y / sh.beta, j = blockIdx.y % sh.beta;
+    const size_t N = (size_t)1 << t.log_n;
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int lo = j * sh.alpha;
+    const int cnt = min(sh.alpha, sh.ell - lo);
+    const int nt = sh.ell + sh.k;
+    cc += (size_t)bi * sh.ell * N;
+    ext += (size_t)bi * sh.beta * nt * N;
+    (void)c_ntt;
+    if (cnt == MAXA)
+        modup_body<MAXA, true>(t, sh, ext, cc, hatinv, hatmod, j, lo, cnt, n);
+    else
+        modup_body<MAXA, false>(t, sh, ext, cc, hatinv, hatmod, j, lo, cnt, n);
 }
 
 // grid (N/512, ell + k)
@@ -138,19 +151,15 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
     }
 }
 
-// grid (N/256, 2, ceil(ell/TCH))
-template <int MAXK>
-__global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsShape sh, u64* __restrict__ conv, const u64* __restrict__ accP, const u64* __restrict__ phatinv,
-                                                           const u64* __restrict__ phatmod) {
-    const int bi = blockIdx.y >> 1, c = blockIdx.y & 1;
+// grid (N/256, 2, ceil(ell/TCH)).  MAXK = number of special limbs (exact for k <= 8, then FULL: no per-source conditions)
+template <int MAXK, bool FULL>
+__device__ __forceinline__ void moddown_body(const DeviceTables& t, const KsShape& sh, u64* __restrict__ conv, const u64* __restrict__ accP,
+                                             const u64* __restrict__ phatinv, const u64* __restrict__ phatmod, int c, size_t n) {
     const size_t N = (size_t)1 << t.log_n;
-    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
-    accP += (size_t)bi * 2 * sh.k * N;
-    conv += (size_t)bi * 2 * sh.ell * N;
     u32 z0[MAXK], z1[MAXK];
 #pragma unroll
     for (int p = 0; p < MAXK; ++p) {
-        if (p < sh.k) {
+        if (FULL || p < sh.k) {
             split30(mul_shoup(accP[((size_t)c * sh.k + p) * N + n], phatinv[2 * p], phatinv[2 * p + 1], t.moduli[sh.L1 + p]), z0[p], z1[p]);
         } else {
             z0[p] = z1[p] = 0;
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsSha
             Acc30 acc = {0, 0, 0};
 #pragma unroll
             for (int p = p0; p < p0 + 8 && p < MAXK; ++p)
-                if (p < sh.k) {
+                if (FULL || p < sh.k) {
                     const u64 h = phatmod[(size_t)p * sh.L1 + tt];  // pre-split on the host (pack30)
                     mac30(acc, z0[p], z1[p], (u32)h, (u32)(h >> 32));
                 }
@@ -174,6 +183,20 @@ __global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsSha
         }
         dst[(size_t)tt * N] = barrett_reduce128(slo, shi, br);
     }
+}
+
+template <int MAXK>
+__global__ __launch_bounds__(256) void moddown_conv_kernel(DeviceTables t, KsShape sh, u64* __restrict__ conv, const u64* __restrict__ accP, const u64* __restrict__ phatinv,
+                                                           const u64* __restrict__ phatmod) {
+    const int bi = blockIdx.y >> 1, c = blockIdx.y & 1;
+    const size_t N = (size_t)1 << t.log_n;
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    accP += (size_t)bi * 2 * sh.k * N;
+    conv += (size_t)bi * 2 * sh.ell * N;
+    if (sh.k == MAXK)
+        moddown_body<MAXK, true>(t, sh, conv, accP, phatinv, phatmod, c, n);
+    else
+        moddown_body<MAXK, false>(t, sh, conv, accP, phatinv, phatmod, c, n);
 }
 
 // grid (N/512, 2*ell)
@@ -226,12 +249,13 @@ __global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsS
 void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const u64* cc, const u64* c_ntt, const u64* hatinv,
                        const u64* hatmod, hipStream_t s) {
     dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * sh.beta), (unsigned)((sh.ell + sh.k + TCH - 1) / TCH));
-    if (sh.alpha <= 4)
-        hipLaunchKernelGGL((modup_conv_kernel<4>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod);
-    else if (sh.alpha <= 8)
-        hipLaunchKernelGGL((modup_conv_kernel<8>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod);
-    else
-        hipLaunchKernelGGL((modup_conv_kernel<16>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod);
+#define FHELIN_MODUP_CASE(A) case A: hipLaunchKernelGGL((modup_conv_kernel<A>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod); break;
+    switch (sh.alpha) {
+        FHELIN_MODUP_CASE(1) FHELIN_MODUP_CASE(2) FHELIN_MODUP_CASE(3) FHELIN_MODUP_CASE(4)
+        FHELIN_MODUP_CASE(5) FHELIN_MODUP_CASE(6) FHELIN_MODUP_CASE(7) FHELIN_MODUP_CASE(8)
+        default: hipLaunchKernelGGL((modup_conv_kernel<16>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod); break;
+    }
+#undef FHELIN_MODUP_CASE
 }
 void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* evk, const u64* c_ntt,
                      hipStream_t s) {
@@ -241,10 +265,13 @@ void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* a
 void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
                          hipStream_t s) {
     dim3 g((1u << t.log_n) / 256, (unsigned)(2 * sh.batch), (unsigned)((sh.ell + TCH - 1) / TCH));
-    if (sh.k <= 8)
-        hipLaunchKernelGGL((moddown_conv_kernel<8>), g, dim3(256), 0, s, t, sh, conv, accP, phatinv, phatmod);
-    else
-        hipLaunchKernelGGL((moddown_conv_kernel<16>), g, dim3(256), 0, s, t, sh, conv, accP, phatinv, phatmod);
+#define FHELIN_MODDOWN_CASE(K) case K: hipLaunchKernelGGL((moddown_conv_kernel<K>), g, dim3(256), 0, s, t, sh, conv, accP, phatinv, phatmod); break;
+    switch (sh.k) {
+        FHELIN_MODDOWN_CASE(1) FHELIN_MODDOWN_CASE(2) FHELIN_MODDOWN_CASE(3) FHELIN_MODDOWN_CASE(4)
+        FHELIN_MODDOWN_CASE(5) FHELIN_MODDOWN_CASE(6) FHELIN_MODDOWN_CASE(7) FHELIN_MODDOWN_CASE(8)
+        default: hipLaunchKernelGGL((moddown_conv_kernel<16>), g, dim3(256), 0, s, t, sh, conv, accP, phatinv, phatmod); break;
+    }
+#undef FHELIN_MODDOWN_CASE
 }
 void launch_moddown_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* pinv,
                            const u64* add0, const u64* add1, const u32* map, const u64* post, hipStream_t s) {
