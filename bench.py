@@ -31,7 +31,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-POW2_ROTS = sorted(set([2 ** i for i in range(14)] + [-(2 ** i) for i in range(14)]))
 
 
 def parse():
@@ -199,7 +198,7 @@ def main():
     if args.workload == "forward":
         eng.keygen()
         eng.gen_relin_key()
-        eng.gen_rotation_keys(POW2_ROTS)
+        eng.gen_rotation_keys(fa.circuit_rotation_indices())   # +-2^i and +-3*2^i (merged tree steps)
         eng.bootstrap_setup(3, 3, 16384)
         w = pf.synthetic_model(1234)
         S = args.tokens

@@ -6,5 +6,5 @@ There is no CPU fallback: importing works without a GPU (so the C-ABI can be ins
 evaluation call fails loudly when the library or a HIP device is missing.
 """
 from .capi import (  # noqa: F401
-    FhelinError, Params, Engine, load_library, library_path, PRESETS,
+    FhelinError, Params, Engine, load_library, library_path, PRESETS, circuit_rotation_indices,
 )

@@ -35,6 +35,18 @@ PRESETS = {
 }
 
 
+def circuit_rotation_indices():
+    """The rotation keys a client generates for the Linformer circuit: the +-2^i set the reference's composites rotate by
+    (the shim's generate_rotation_keys extends main.cpp's list to it, quirk Q3), plus +-3*2^i, with which two steps of a
+    rotate-and-sum tree run as one merged key switch (Evaluator::rotate_sum_batch)."""
+    r = set()
+    for i in range(14):
+        r.update((1 << i, -(1 << i)))
+    for i in range(13):
+        r.update((3 << i, -(3 << i)))
+    return sorted(r)
+
+
 def library_path():
     return os.path.join(_HERE, "libfhelin_amd.so")
 
@@ -96,6 +108,7 @@ def load_library():
         "fhelin_rotate": (i32, [vp, vp, i32, C.POINTER(vp)]),
         "fhelin_rotate_many": (i32, [vp, vp, C.POINTER(i32), i32, C.POINTER(vp)]),
         "fhelin_rotate_each": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(vp)]),
+        "fhelin_rotate_sum": (i32, [vp, C.POINTER(vp), i32, C.POINTER(i32), i32, C.POINTER(vp)]),
         "fhelin_rescale": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_level_reduce": (i32, [vp, vp, i32, C.POINTER(vp)]),
         "fhelin_raw_rescale": (i32, [vp, vp, C.POINTER(vp)]),
@@ -351,6 +364,13 @@ class Engine:
         idx = (C.c_int32 * len(indices))(*indices)
         outs = self._outs(len(v))
         self._ck(self.lib.fhelin_rotate_each(self.h, self._harr(v), idx, len(v), outs))
+        return self._cts(outs, len(v))
+
+    def rotate_sum(self, v, indices):
+        """v[i] + sum_r rot(v[i], indices[r]): one ModUp and one ModDown per row"""
+        idx = (C.c_int32 * len(indices))(*indices)
+        outs = self._outs(len(v))
+        self._ck(self.lib.fhelin_rotate_sum(self.h, self._harr(v), len(v), idx, len(indices), outs))
         return self._cts(outs, len(v))
 
     def rescale(self, a):

@@ -198,6 +198,18 @@ int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* 
     for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
     FHELIN_CATCH
 }
+int fhelin_rotate_sum(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const int32_t* indices, int32_t n_rot, fhelin_ct** outs) {
+    NEED(c && v && indices && outs && n >= 0 && n_rot >= 1);
+    FHELIN_TRY
+    std::vector<CtPtr> in;
+    for (int i = 0; i < n; ++i) {
+        if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext in array");
+        in.push_back(ct_in(c, v[i]));
+    }
+    std::vector<CtPtr> r = c->ev.rotate_sum_batch(in, std::vector<int>(indices, indices + n_rot));
+    for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
+    FHELIN_CATCH
+}
 int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY

@@ -6,7 +6,14 @@
 
 namespace fhelin {
 
+static bool env_flag(const char* name) {  // unset or non-zero = on
+    const char* e = std::getenv(name);
+    return !e || std::atoi(e) != 0;
+}
+
 Composite::Composite(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {
+    early_rescale_ = env_flag("FHELIN_EARLY_RESCALE");  // read per context, so that one process can hold both kinds
+    merge_rot_ = env_flag("FHELIN_MERGE_ROT");
     if (const char* b = std::getenv("FHELIN_BATCH")) {
         int v = std::atoi(b);
         if (v >= 1 && v <= 256) ev_.batch_limit = v;
@@ -114,25 +121,41 @@ static int log_steps(int slots) {
 // A degree-2 input (a fresh product) is rescaled BEFORE the rotations instead of lazily before its next multiplication:
 // the same single rescale, but the key switches of the tree then run with one limb fewer (EvalRotate and ModReduce
 // commute up to rounding noise; FHELIN_EARLY_RESCALE=0 restores the reference's order).
-static bool early_rescale() {
-    static const bool v = [] { const char* e = std::getenv("FHELIN_EARLY_RESCALE"); return !e || std::atoi(e) != 0; }();
-    return v;
+
+
+// Two consecutive steps of a rotate-and-sum tree, x += rot(x, s); x += rot(x, 2s), equal x + rot(x,s) + rot(x,2s) +
+// rot(x,3s): with the key for 3s they run as ONE merged key switch (one ModUp, three gathered inner products
+// accumulated in the extended basis, one ModDown: half the NTTs of two key switches).  The key set a client generates
+// through this library contains the 3*2^i rotations for that purpose; without them the tree falls back to single steps.
+// FHELIN_MERGE_ROT=0 disables.
+
+CtVec Composite::tree_steps(CtVec r, int n, int unit) {
+    int i = 0;
+    while (i < n) {
+        const int s = unit * (1 << i);
+        if (i + 1 < n && merge_rot_ && ev_.have_rotation_keys({s, 2 * s, 3 * s}, r[0]->slots)) {
+            r = ev_.rotate_sum_batch(r, {s, 2 * s, 3 * s});
+            i += 2;
+        } else {
+            r = ev_.rotate_add_batch(r, s);
+            i += 1;
+        }
+    }
+    return r;
 }
 
 CtPtr Composite::rotsum(const CtPtr& in, int slots, int padding) {
     const int n = log_steps(slots);
-    CtPtr r = (n && early_rescale() && in->deg >= 2 && in->ell >= 2) ? ev_.rescale(in) : in;  // immutable handles: no Clone()
-    for (int i = 0; i < n; ++i) r = ev_.rotate_add(r, padding * (1 << i));
-    return n ? r : ev_.clone(in);
+    CtPtr r = (n && early_rescale_ && in->deg >= 2 && in->ell >= 2) ? ev_.rescale(in) : in;  // immutable handles: no Clone()
+    return n ? tree_steps(CtVec{r}, n, padding)[0] : ev_.clone(in);
 }
 
 CtPtr Composite::rotsum_padded(const CtPtr& in, int slots) { return rotsum(in, slots, slots); }
 
 CtPtr Composite::repeat(const CtPtr& in, int slots, int padding) {
     const int n = log_steps(slots);
-    CtPtr r = (n && early_rescale() && in->deg >= 2 && in->ell >= 2) ? ev_.rescale(in) : in;
-    for (int i = 0; i < n; ++i) r = ev_.rotate_add(r, padding * -(1 << i));
-    return n ? r : ev_.clone(in);
+    CtPtr r = (n && early_rescale_ && in->deg >= 2 && in->ell >= 2) ? ev_.rescale(in) : in;
+    return n ? tree_steps(CtVec{r}, n, -padding)[0] : ev_.clone(in);
 }
 
 // log-tree rotate-and-add over independent rows.  Rows are cut into chunks of `batch_limit`; every chunk runs its
@@ -140,7 +163,7 @@ CtPtr Composite::repeat(const CtPtr& in, int slots, int padding) {
 CtVec Composite::tree_batch(const CtVec& in_raw, int slots, int step_sign, int padding) {
     const int n = log_steps(slots);
     CtVec in = in_raw;
-    if (n && early_rescale()) {  // see rotsum(): one limb fewer for every key switch of the tree
+    if (n && early_rescale_) {  // see rotsum(): one limb fewer for every key switch of the tree
         CtVec need;
         std::vector<size_t> pos;
         for (size_t i = 0; i < in.size(); ++i)
@@ -168,9 +191,9 @@ CtVec Composite::tree_batch(const CtVec& in_raw, int slots, int step_sign, int p
         CtVec r(in.begin() + lo, in.begin() + hi);
         if (lanes) {
             Context::LaneScope scope(c, 1 + k % c.n_lanes);
-            for (int i = 0; i < n; ++i) r = ev_.rotate_add_batch(r, padding * step_sign * (1 << i));
+            r = tree_steps(r, n, padding * step_sign);
         } else {
-            for (int i = 0; i < n; ++i) r = ev_.rotate_add_batch(r, padding * step_sign * (1 << i));
+            r = tree_steps(r, n, padding * step_sign);
         }
         std::copy(r.begin(), r.end(), out.begin() + lo);
     }

@@ -43,6 +43,7 @@ public:
     CtVec rotsum_batch(const CtVec& in, int slots, int padding);
     CtVec repeat_batch(const CtVec& in, int slots, int padding);
     CtVec tree_batch(const CtVec& in, int slots, int step_sign, int padding);
+    CtVec tree_steps(CtVec r, int n, int unit);   // n doubling steps x += rot(x, unit * 2^i), merged in pairs when the 3s key exists
 
     // matmuls                                                                                 :869-1058
     CtVec matmul_pt(const CtVec& rows, const PtPtr& w, const PtPtr& bias, int slots, int padding);   // RE / CR with plaintext weight
@@ -69,6 +70,8 @@ private:
     Evaluator& ev_;
     Client& cl_;
     std::map<std::string, PtPtr> mask_cache_;
+    bool early_rescale_ = true;   // FHELIN_EARLY_RESCALE: rescale a fresh product before its rotation tree
+    bool merge_rot_ = true;       // FHELIN_MERGE_ROT: two tree steps as one merged key switch when the 3s key exists
     PtPtr mask_plain(const std::string& key, const std::vector<double>& v);
 };
 

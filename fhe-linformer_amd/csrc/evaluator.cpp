@@ -198,6 +198,106 @@ void Evaluator::keyswitch_impl(int B, const KsRows* rows, const u64* c_ntt, size
     c_.pool.free(conv);
 }
 
+bool Evaluator::have_rotation_keys(const std::vector<int>& indices, int slots) const {
+    const int ns = slots > 0 ? slots : (1 << c_.prm.log_slots);
+    for (int r : indices) {
+        if (r % ns == 0) return false;
+        if (!rot_keys.count(c_.galois_element(r))) return false;
+    }
+    return !indices.empty();
+}
+
+std::vector<CtPtr> Evaluator::rotate_sum_batch(const std::vector<CtPtr>& vin, const std::vector<int>& indices) {
+    if (vin.empty()) return {};
+    const int R = (int)indices.size();
+    if (R < 1 || R > KsShape::MAX_ROT) throw Error(FHELIN_ERR_ARG, "rotate_sum_batch: 1..7 rotations");
+    if (!have_rotation_keys(indices, vin[0]->slots)) throw Error(FHELIN_ERR_KEY, "rotate_sum_batch: missing rotation key");
+    if (c_.K < 1) throw Error(FHELIN_ERR_STATE, "hybrid key switching needs at least one special prime");
+    std::vector<const EvalKey*> keys;
+    std::vector<const u32*> maps;
+    for (int r : indices) {
+        const u64 g = c_.galois_element(r);
+        keys.push_back(rot_keys.at(g).get());
+        maps.push_back(c_.automorph_map(g));
+    }
+    const size_t N = c_.N;
+    const int K = c_.K, L1 = c_.L + 1;
+    hipStream_t s = c_.stream;
+    std::vector<CtPtr> out(vin.size());
+    std::vector<char> done(vin.size(), 0);
+    for (size_t first = 0; first < vin.size(); ++first) {
+        if (done[first]) continue;
+        if (vin[first]->npoly != 2) throw Error(FHELIN_ERR_STATE, "rotate: ciphertext must have 2 components");
+        std::vector<size_t> idx;
+        for (size_t i = first; i < vin.size() && (int)idx.size() < batch_limit; ++i) {
+            const CtPtr &a = vin[first], &b = vin[i];
+            if (!done[i] && b->npoly == 2 && b->ell == a->ell && b->deg == a->deg && fabsl(b->scale / a->scale - 1.0L) < 1e-9L)
+                idx.push_back(i);
+        }
+        std::vector<CtPtr> chunk;
+        for (size_t i : idx) chunk.push_back(vin[i]);
+        chunk = make_contiguous(chunk);
+        const int B = (int)chunk.size(), ell = chunk[0]->ell;
+        const size_t pn = (size_t)ell * N, ctw = 2 * pn;
+        const LevelTables& lt = c_.lvl[ell];
+        const int nt = ell + K;
+        std::vector<CtPtr> o = new_ct_batch(B, 2, ell, chunk[0]->deg, chunk[0]->scale, chunk[0]->slots);
+        const u64* base = chunk[0]->d;
+        KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, ctw, ctw, pn, ctw};
+        sh.n_rot = R;
+        for (int r = 0; r < R; ++r) {
+            sh.evk_rot[r] = keys[r]->d;
+            sh.map_rot[r] = maps[r];
+        }
+        // accounting in units of the reference's rotations: R = 2^k - 1 merged terms stand for k tree steps
+        int steps = 0;
+        while ((1 << steps) < R + 1) ++steps;
+        c_.stats.keyswitch += (u64)B * steps;
+        c_.stats.keyswitch_limbs += (u64)B * steps * ell;
+        // ModUp of c1, once for all rotations
+        u64* cc = c_.dalloc<u64>((size_t)B * ell * N);
+        {
+            LimbBatch ib{cc, B * ell, nullptr, 0, ell, base + pn};
+            if (B > 1) {
+                ib.src_group = ell;
+                ib.src_group_stride = ctw;
+            }
+            c_.ntt(ib, true);
+        }
+        u64* ext = c_.dalloc<u64>((size_t)B * lt.beta * nt * N);
+        launch_modup_conv(c_.dt, sh, ext, cc, base + pn, lt.up_hatinv, lt.up_hatmod, s);
+        LimbBatch eb{ext, B * lt.beta * nt, lt.ext_limb_tab, 0, 1};
+        eb.tab_len = lt.beta * nt;
+        eb.lazy_out = true;
+        c_.ntt(eb, false, B * (lt.beta * nt - ell));
+        // all rotated inner products, gathered and accumulated in the extended basis; the c0 parts likewise
+        u64* accQ = c_.dalloc<u64>((size_t)B * 2 * ell * N);
+        u64* accP = c_.dalloc<u64>((size_t)B * 2 * K * N);
+        launch_ks_inner_multi(c_.dt, sh, accQ, accP, ext, base + pn, s);
+        u64* c0sum = c_.dalloc<u64>((size_t)B * ell * N);
+        launch_gather_sum(c_.dt, sh, c0sum, base, ctw, s);
+        // one ModDown; the epilogue adds the gathered c0 parts and the unrotated input
+        c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
+        u64* conv = c_.dalloc<u64>((size_t)B * 2 * ell * N);
+        launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
+        c_.ntt(LimbBatch{conv, B * 2 * ell, nullptr, 0, ell}, false);
+        launch_moddown_finish(c_.dt, sh, o[0]->d, accQ, conv, c_.d_pinv, c0sum, nullptr, nullptr, base, s);
+        launch_ok("rotate_sum_batch");
+        c_.pool.free(cc);
+        c_.pool.free(ext);
+        c_.pool.free(accQ);
+        c_.pool.free(accP);
+        c_.pool.free(c0sum);
+        c_.pool.free(conv);
+        for (int b = 0; b < B; ++b) {
+            o[b]->scale = vin[idx[b]]->scale;
+            out[idx[b]] = o[b];
+            done[idx[b]] = 1;
+        }
+    }
+    return out;
+}
+
 // hoisted rotations of one ciphertext.  A rotation here is KeySwitch_{s -> sigma^-1(s)}(c1) + c0 followed by the NTT-domain
 // automorphism gather in the ModDown epilogue, so the ModUp of c1 does not depend on the rotation index: it is computed
 // once and every index runs only its own inner product + ModDown.  Bit-identical to rotate(a, i).

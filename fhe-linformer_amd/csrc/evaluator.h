@@ -105,6 +105,11 @@ public:
     };
     void keyswitch_rows(const KsRows& rows, const u64* c_ntt, size_t c_stride, int ell, u64* out, size_t out_stride, const u64* add0,
                         size_t add_stride);
+    // v[i] + sum_r rot(v[i], indices[r]) with ONE ModUp and ONE ModDown per row: the rotated terms are accumulated in the
+    // extended basis (kernels_elem.h launch_ks_inner_multi).  Two steps of a rotate-and-sum tree, x += rot(x, s);
+    // x += rot(x, 2s), are the call {s, 2s, 3s}.  All keys must exist (have_rotation_keys).
+    std::vector<CtPtr> rotate_sum_batch(const std::vector<CtPtr>& v, const std::vector<int>& indices);
+    bool have_rotation_keys(const std::vector<int>& indices, int slots) const;
     // hoisted rotations: rot(a, i) for every i in `indices` with ONE ModUp of a (results identical to rotate(a, i))
     std::vector<CtPtr> rotate_many(const CtPtr& a, const std::vector<int>& indices);
     // rot(v[i], indices[i]) for ciphertexts of identical shape, one batched key switch per chunk of rows

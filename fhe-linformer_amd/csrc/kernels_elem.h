@@ -61,6 +61,11 @@ struct KsShape {
     int shared_input = 0;
     const u64* evk_row[MAX_ROWS] = {};
     const u32* map_row[MAX_ROWS] = {};
+    // merged rotations (launch_ks_inner_multi): n_rot <= MAX_ROT rotations of every row are accumulated before ONE ModDown
+    static constexpr int MAX_ROT = 7;
+    int n_rot = 0;
+    const u64* evk_rot[MAX_ROT] = {};
+    const u32* map_rot[MAX_ROT] = {};
 };
 // K6: cc [ell][N] coefficient form, c_ntt [ell][N] NTT form -> ext [beta][ell+k][N]
 //     (own-digit slots stay unused — K7 reads c_ntt there; the others get the fast-basis-extended values, coefficient form)
@@ -69,6 +74,13 @@ void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const
 // K7: accQ [2][ell][N], accP [2][k][N] <- sum_j ext[j][t] * evk[j][comp][limb(t)]
 void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* evk, const u64* c_ntt,
                      hipStream_t s);
+// K7 for a sum of rotations: acc_c[t][n] = sum_r sum_j d_j[t][m_r(n)] * evk_{r,j,c}[t][m_r(n)],  m_r = map_rot[r]: the
+// automorphism of every term is applied while gathering (the maps move whole 128-byte lines), all terms are
+// accumulated in 128 bits and reduced once; ONE ModDown then serves the whole sum.
+void launch_ks_inner_multi(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* c_ntt,
+                           hipStream_t s);
+// out[v][n] = sum_r in[v][map_rot[r][n]]  for v in [0, nvec) (the c0 parts of the rotated copies), per batch row
+void launch_gather_sum(const DeviceTables& t, const KsShape& sh, u64* out, const u64* in, size_t in_stride, hipStream_t s);
 // K8a: accP coefficient form [2][k][N] -> conv [2][ell][N] (coefficient form)
 void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
                          hipStream_t s);

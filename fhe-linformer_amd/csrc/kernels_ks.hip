@@ -151,6 +151,70 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
     }
 }
 
+// grid (N/256, batch*(ell + k)): one coefficient per thread (the gathered positions of neighbours are not adjacent)
+__global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsShape sh, u64* __restrict__ accQ, u64* __restrict__ accP,
+                                                             const u64* __restrict__ ext, const u64* __restrict__ c_ntt) {
+    const int nt = sh.ell + sh.k;
+    const int bi = blockIdx.y % sh.batch, tt = blockIdx.y / sh.batch;
+    const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
+    const size_t N = (size_t)1 << t.log_n;
+    ext += (size_t)bi * sh.beta * nt * N;
+    c_ntt += (size_t)bi * sh.c_stride;
+    const int own = tt < sh.ell ? tt / sh.alpha : -1;
+    accQ += (size_t)bi * 2 * sh.ell * N;
+    accP += (size_t)bi * 2 * sh.k * N;
+    const Barrett br = load_barrett(t, limb);
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t kstride = (size_t)(sh.L1 + sh.k) * N;  // one evk component
+    u64 lo[2] = {0, 0}, hi[2] = {0, 0};                 // b, a
+    Acc30 b = {0, 0, 0}, a = {0, 0, 0};
+    int pending = 0;
+    for (int r = 0; r < sh.n_rot; ++r) {
+        const size_t m = sh.map_rot[r][n];
+        const u64* __restrict__ K = sh.evk_rot[r] + (size_t)limb * N + m;
+        for (int j = 0; j < sh.beta; ++j) {
+            const u64 d = j == own ? c_ntt[(size_t)tt * N + m] : ext[((size_t)j * nt + tt) * N + m];
+            u32 d0, d1, k0, k1;
+            split30(d, d0, d1);
+            split30(K[(size_t)(2 * j) * kstride], k0, k1);
+            mac30(b, d0, d1, k0, k1);
+            split30(K[(size_t)(2 * j + 1) * kstride], k0, k1);
+            mac30(a, d0, d1, k0, k1);
+            if (++pending == 8) {  // at most 8 products of 60-bit halves fit the 64-bit columns
+                acc30_flush(b, lo[0], hi[0]);
+                acc30_flush(a, lo[1], hi[1]);
+                b = Acc30{0, 0, 0};
+                a = Acc30{0, 0, 0};
+                pending = 0;
+            }
+        }
+    }
+    acc30_flush(b, lo[0], hi[0]);
+    acc30_flush(a, lo[1], hi[1]);
+    const u64 rb = barrett_reduce128(lo[0], hi[0], br), ra = barrett_reduce128(lo[1], hi[1], br);
+    if (tt < sh.ell) {
+        accQ[(size_t)tt * N + n] = rb;
+        accQ[(size_t)(sh.ell + tt) * N + n] = ra;
+    } else {
+        const int pj = tt - sh.ell;
+        accP[(size_t)pj * N + n] = rb;
+        accP[(size_t)(sh.k + pj) * N + n] = ra;
+    }
+}
+
+// grid (N/256, batch*ell)
+__global__ __launch_bounds__(256) void gather_sum_kernel(DeviceTables t, KsShape sh, u64* __restrict__ out, const u64* __restrict__ in,
+                                                         size_t in_stride) {
+    const int bi = blockIdx.y / sh.ell, tt = blockIdx.y % sh.ell;
+    const size_t N = (size_t)1 << t.log_n;
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u64 q = t.moduli[tt];
+    const u64* src = in + (size_t)bi * in_stride + (size_t)tt * N;
+    u64 acc = 0;
+    for (int r = 0; r < sh.n_rot; ++r) acc = add_mod(acc, src[sh.map_rot[r][n]], q);
+    out[((size_t)bi * sh.ell + tt) * N + n] = acc;
+}
+
 // grid (N/256, 2, ceil(ell/TCH)).  MAXK = number of special limbs (exact for k <= 8, then FULL: no per-source conditions)
 template <int MAXK, bool FULL>
 __device__ __forceinline__ void moddown_body(const DeviceTables& t, const KsShape& sh, u64* __restrict__ conv, const u64* __restrict__ accP,
@@ -261,6 +325,15 @@ void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* a
                      hipStream_t s) {
     dim3 g((1u << t.log_n) / 512, (unsigned)(sh.batch * (sh.ell + sh.k)));
     hipLaunchKernelGGL(ks_inner_kernel, g, dim3(256), 0, s, t, sh, accQ, accP, ext, evk, c_ntt);
+}
+void launch_ks_inner_multi(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* c_ntt,
+                           hipStream_t s) {
+    dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * (sh.ell + sh.k)));
+    hipLaunchKernelGGL(ks_inner_multi_kernel, g, dim3(256), 0, s, t, sh, accQ, accP, ext, c_ntt);
+}
+void launch_gather_sum(const DeviceTables& t, const KsShape& sh, u64* out, const u64* in, size_t in_stride, hipStream_t s) {
+    dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * sh.ell));
+    hipLaunchKernelGGL(gather_sum_kernel, g, dim3(256), 0, s, t, sh, out, in, in_stride);
 }
 void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
                          hipStream_t s) {

@@ -242,11 +242,16 @@ public:
             cout << "Filename cannot be empty when serializing rotation keys." << endl;
             return;
         }
-        // the reference's list (src/main.cpp:84) omits indices the circuit uses (quirk Q3): generate the union
+        // the reference's list (src/main.cpp:84) omits indices the circuit uses (quirk Q3): generate the union, plus the
+        // 3*2^i rotations that let the engine run two steps of a rotate-and-sum tree as one merged key switch
         vector<int32_t> all(rotations.begin(), rotations.end());
         for (int i = 0; i < 14; i++) {
             all.push_back(1 << i);
             all.push_back(-(1 << i));
+        }
+        for (int i = 0; i < 13; i++) {
+            all.push_back(3 << i);
+            all.push_back(-(3 << i));
         }
         fhelin_shim::check(fhelin_gen_rotation_keys(context, all.data(), (int32_t)all.size()), "EvalRotateKeyGen");
         if (serialize) {

@@ -130,6 +130,10 @@ int fhelin_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** 
 int fhelin_rotate_many(fhelin_ctx* c, const fhelin_ct* a, const int32_t* indices, int32_t n, fhelin_ct** outs);
 /* outs[i] = EvalRotate(v[i], indices[i]): rows of identical (level, degree, scale) share one batched key switch */
 int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* indices, int32_t n, fhelin_ct** outs);
+/* outs[i] = v[i] + sum_r EvalRotate(v[i], indices[r]) (1 <= n_rot <= 7) with one decomposition and ONE ModDown per
+ * row: the rotated terms are accumulated in the extended basis QP.  Two steps of the reference's rotsum loop (:829-837),
+ * x += rot(x, s); x += rot(x, 2s), are the call {s, 2s, 3s}.  Needs the rotation keys of all indices. */
+int fhelin_rotate_sum(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const int32_t* indices, int32_t n_rot, fhelin_ct** outs);
 int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);                          /* ModReduce (implicit in :427/:431) */
 int fhelin_level_reduce(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhelin_ct** out);
 

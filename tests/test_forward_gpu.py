@@ -29,7 +29,7 @@ def test_encrypted_forward_matches_plaintext_circuit(fa, variant, preset, n_q):
     try:
         eng.keygen()
         eng.gen_relin_key()
-        eng.gen_rotation_keys(sorted(set([2 ** i for i in range(14)] + [-(2 ** i) for i in range(14)])))
+        eng.gen_rotation_keys(fa.circuit_rotation_indices())
         eng.bootstrap_setup(3, 3, 16384)
         ctl, tr = lf.GpuController(eng), {}
         out = lf.forward(ctl, w, x_in, X_E, X_F, tr, variant)

@@ -125,3 +125,29 @@ def test_rotsum_pattern(keyed):
         c = eng.add(c, eng.rotate(c, s))
     want = np.tile(x.reshape(-1, 128).sum(axis=0), n // 128)
     assert np.max(np.abs(eng.decrypt(c) - want)) < 1e-6
+
+
+@pytest.mark.parametrize("preset", ["toy13", "bench"])
+def test_merged_rotation_sum(keyed, preset):
+    """x + rot(x, 1) + rot(x, 2) + rot(x, 3) with one ModUp and one ModDown (rotated inner products accumulated in the
+    extended basis) — two steps of a rotate-and-sum tree — for a batch of rows, at a full and a partial-digit level,
+    also on a degree-2 input.  Tolerance: CKKS noise, 1e-7."""
+    eng = keyed[preset]
+    ns = 1 << eng.params.log_slots
+    for level in (0, eng.n_q - 3):
+        xs = [_vec(eng, 50 + i) for i in range(3)]
+        cts = [eng.encrypt(x, level=level) for x in xs]
+        outs = eng.rotate_sum(cts, [1, 2, 3])
+        for x, o in zip(xs, outs):
+            want = x + np.roll(x, -1) + np.roll(x, -2) + np.roll(x, -3)
+            assert o.info()["ell"] == eng.n_q - level
+            assert np.max(np.abs(eng.decrypt(o) - want)) < 1e-7, (preset, level)
+    x = _vec(eng, 77)
+    m = np.zeros(ns)
+    m[::2] = 0.5
+    prod = eng.mult(eng.encrypt(x), eng.encode(m, 0))          # degree 2
+    got = eng.decrypt(eng.rotate_sum([prod], [128, -64])[0])
+    y = x * m
+    assert np.max(np.abs(got - (y + np.roll(y, -128) + np.roll(y, 64)))) < 1e-7
+    with pytest.raises(Exception):
+        eng.rotate_sum([prod], [5])                            # no key for rotation 5

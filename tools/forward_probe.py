@@ -17,7 +17,7 @@ ref = lf.forward(sim, w, x_in, X_E, X_F, st, variant)
 n_p = -1   # library rule (OpenFHE sizeP): 7 special limbs for 29-30 Q limbs
 e = fa.Engine(preset, seed=11, n_q=n_q, n_p=n_p)
 t0 = time.time(); e.keygen(); e.gen_relin_key()
-e.gen_rotation_keys(sorted(set([2 ** i for i in range(14)] + [-(2 ** i) for i in range(14)])))
+e.gen_rotation_keys(fa.circuit_rotation_indices())
 e.bootstrap_setup(3, 3, 16384); print("keys+setup s", round(time.time() - t0, 2), flush=True)
 
 

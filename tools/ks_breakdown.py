@@ -12,7 +12,7 @@ w = pf.synthetic_model(1234); x = pf.synthetic_tokens(S, 4321)
 x_in, X_E, X_F = pf.client_inputs(w, x)
 e = fa.Engine("bench", seed=11, n_q=28, n_p=-1)
 e.keygen(); e.gen_relin_key()
-e.gen_rotation_keys(sorted(set([2 ** i for i in range(14)] + [-(2 ** i) for i in range(14)])))
+e.gen_rotation_keys(fa.circuit_rotation_indices())
 e.bootstrap_setup(3, 3, 16384)
 agg = collections.defaultdict(lambda: [0, 0, 0, 0.0])
 depth = [0]
