@@ -245,8 +245,13 @@ CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& we
         if (j == (int)weights.size() - 1) {
             res = masked;
         } else {
-            res = ev_.rotate_batch(res, -64);
-            res = ev_.rotate_batch(res, -64);
+            // the reference rotates by -64 twice (:934-935); one rotation by -128 moves the same slots
+            if (merge_rot_ && ev_.have_rotation_keys({-128}, res[0]->slots)) {
+                res = ev_.rotate_batch(res, -128);
+            } else {
+                res = ev_.rotate_batch(res, -64);
+                res = ev_.rotate_batch(res, -64);
+            }
             res = ev_.add_batch(res, masked);
         }
     }
