@@ -241,17 +241,15 @@ CtPtr Bootstrapper::apply(const LinStage& st, const CtPtr& xin) {
     }
     std::map<int, CtPtr> inner;
     for (auto& g : groups) inner[g.first] = g.second[0];
-    // giant steps: different inputs, different keys, same shape -> one batched key switch with per-row keys
+    // giant steps: different inputs, different keys, same shape
     std::vector<CtPtr> gin;
     std::vector<int> gidx;
     for (auto& g : inner) {
         gin.push_back(g.second);
         gidx.push_back(g.first);
     }
-    std::vector<CtPtr> grot = ev_.rotate_each(gin, gidx);
-    CtPtr out;
-    for (auto& v : grot) out = out ? ev_.add(out, v) : v;
-    return out;
+    // sum_g rot(inner_g, g): own ModUp per term, ONE shared ModDown (Evaluator::rotate_each_sum)
+    return ev_.rotate_each_sum(gin, gidx);
 }
 
 CtPtr Bootstrapper::mod_raise(const CtPtr& ct, long double& rho) {

@@ -298,6 +298,92 @@ std::vector<CtPtr> Evaluator::rotate_sum_batch(const std::vector<CtPtr>& vin, co
     return out;
 }
 
+CtPtr Evaluator::rotate_each_sum(const std::vector<CtPtr>& vin, const std::vector<int>& indices) {
+    if (vin.empty() || vin.size() != indices.size()) throw Error(FHELIN_ERR_ARG, "rotate_each_sum: one index per ciphertext");
+    const int ns = vin[0]->slots > 0 ? vin[0]->slots : (1 << c_.prm.log_slots);
+    // unrotated terms are plain additions; the rest go through the merged key switch in groups of <= 7
+    std::vector<CtPtr> rot;
+    std::vector<int> ridx;
+    CtPtr acc;
+    for (size_t i = 0; i < vin.size(); ++i) {
+        if (indices[i] % ns == 0) acc = acc ? add(acc, vin[i]) : vin[i];
+        else {
+            rot.push_back(vin[i]);
+            ridx.push_back(indices[i]);
+        }
+    }
+    for (size_t first = 0; first < rot.size(); first += KsShape::MAX_ROT) {
+        const int R = (int)std::min(rot.size() - first, (size_t)KsShape::MAX_ROT);
+        std::vector<CtPtr> chunk(rot.begin() + first, rot.begin() + first + R);
+        bool uniform = have_rotation_keys(std::vector<int>(ridx.begin() + first, ridx.begin() + first + R), ns) && c_.K >= 1;
+        for (const CtPtr& c : chunk)
+            uniform = uniform && c->npoly == 2 && c->ell == chunk[0]->ell && c->deg == chunk[0]->deg &&
+                      fabsl(c->scale / chunk[0]->scale - 1.0L) < 1e-9L;
+        if (!uniform || R < 2) {  // fall back to separate rotations
+            for (int r = 0; r < R; ++r) {
+                CtPtr t = rotate(chunk[r], ridx[first + r]);
+                acc = acc ? add(acc, t) : t;
+            }
+            continue;
+        }
+        chunk = make_contiguous(chunk);
+        const size_t N = c_.N;
+        const int K = c_.K, L1 = c_.L + 1, ell = chunk[0]->ell;
+        const size_t pn = (size_t)ell * N, ctw = 2 * pn;
+        const LevelTables& lt = c_.lvl[ell];
+        const int nt = ell + K;
+        hipStream_t s = c_.stream;
+        const u64* base = chunk[0]->d;
+        // ModUp of the R inputs as one batch
+        KsShape up{ell, K, c_.alpha, lt.beta, L1, R, ctw, 0, 0, 0};
+        u64* cc = c_.dalloc<u64>((size_t)R * ell * N);
+        {
+            LimbBatch ib{cc, R * ell, nullptr, 0, ell, base + pn};
+            ib.src_group = ell;
+            ib.src_group_stride = ctw;
+            c_.ntt(ib, true);
+        }
+        u64* ext = c_.dalloc<u64>((size_t)R * lt.beta * nt * N);
+        launch_modup_conv(c_.dt, up, ext, cc, base + pn, lt.up_hatinv, lt.up_hatmod, s);
+        LimbBatch eb{ext, R * lt.beta * nt, lt.ext_limb_tab, 0, 1};
+        eb.tab_len = lt.beta * nt;
+        eb.lazy_out = true;
+        c_.ntt(eb, false, R * (lt.beta * nt - ell));
+        // one accumulator for all R rotated inner products, one ModDown
+        KsShape sh{ell, K, c_.alpha, lt.beta, L1, 1, 0, ctw, pn, 0};
+        sh.n_rot = R;
+        sh.rot_ext_stride = (size_t)lt.beta * nt * N;
+        sh.rot_input_stride = ctw;
+        for (int r = 0; r < R; ++r) {
+            const u64 g = c_.galois_element(ridx[first + r]);
+            sh.evk_rot[r] = rot_keys.at(g)->d;
+            sh.map_rot[r] = c_.automorph_map(g);
+        }
+        c_.stats.keyswitch += (u64)R;
+        c_.stats.keyswitch_limbs += (u64)R * ell;
+        u64* accQ = c_.dalloc<u64>((size_t)2 * ell * N);
+        u64* accP = c_.dalloc<u64>((size_t)2 * K * N);
+        launch_ks_inner_multi(c_.dt, sh, accQ, accP, ext, base + pn, s);
+        u64* c0sum = c_.dalloc<u64>((size_t)ell * N);
+        launch_gather_sum(c_.dt, sh, c0sum, base, 0, s);
+        c_.ntt(LimbBatch{accP, 2 * K, nullptr, L1, K}, true);
+        u64* conv = c_.dalloc<u64>((size_t)2 * ell * N);
+        launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
+        c_.ntt(LimbBatch{conv, 2 * ell, nullptr, 0, ell}, false);
+        CtPtr o = new_ct(2, ell, chunk[0]->deg, chunk[0]->scale, chunk[0]->slots);
+        launch_moddown_finish(c_.dt, sh, o->d, accQ, conv, c_.d_pinv, c0sum, nullptr, nullptr, nullptr, s);
+        launch_ok("rotate_each_sum");
+        c_.pool.free(cc);
+        c_.pool.free(ext);
+        c_.pool.free(accQ);
+        c_.pool.free(accP);
+        c_.pool.free(c0sum);
+        c_.pool.free(conv);
+        acc = acc ? add(acc, o) : o;
+    }
+    return acc;
+}
+
 // hoisted rotations of one ciphertext.  A rotation here is KeySwitch_{s -> sigma^-1(s)}(c1) + c0 followed by the NTT-domain
 // automorphism gather in the ModDown epilogue, so the ModUp of c1 does not depend on the rotation index: it is computed
 // once and every index runs only its own inner product + ModDown.  Bit-identical to rotate(a, i).

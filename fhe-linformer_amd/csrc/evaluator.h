@@ -110,6 +110,9 @@ public:
     // x += rot(x, 2s), are the call {s, 2s, 3s}.  All keys must exist (have_rotation_keys).
     std::vector<CtPtr> rotate_sum_batch(const std::vector<CtPtr>& v, const std::vector<int>& indices);
     bool have_rotation_keys(const std::vector<int>& indices, int slots) const;
+    // sum_i rot(v[i], indices[i]) for up to 7 ciphertexts of identical shape (index 0 = unrotated term allowed): every
+    // term has its own ModUp and key, the inner products are accumulated in QP and share ONE ModDown (giant steps)
+    CtPtr rotate_each_sum(const std::vector<CtPtr>& v, const std::vector<int>& indices);
     // hoisted rotations: rot(a, i) for every i in `indices` with ONE ModUp of a (results identical to rotate(a, i))
     std::vector<CtPtr> rotate_many(const CtPtr& a, const std::vector<int>& indices);
     // rot(v[i], indices[i]) for ciphertexts of identical shape, one batched key switch per chunk of rows

@@ -66,6 +66,10 @@ struct KsShape {
     int n_rot = 0;
     const u64* evk_rot[MAX_ROT] = {};
     const u32* map_rot[MAX_ROT] = {};
+    // rot_input_stride > 0: rotation r acts on its OWN input (digits at ext + r * rot_ext_stride, polynomial at c + r *
+    // rot_input_stride): a sum of rotations of different ciphertexts (giant steps) shares the one ModDown
+    size_t rot_ext_stride = 0;
+    size_t rot_input_stride = 0;
 };
 // K6: cc [ell][N] coefficient form, c_ntt [ell][N] NTT form -> ext [beta][ell+k][N]
 //     (own-digit slots stay unused — K7 reads c_ntt there; the others get the fast-basis-extended values, coefficient form)

@@ -170,10 +170,12 @@ __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsS
     Acc30 b = {0, 0, 0}, a = {0, 0, 0};
     int pending = 0;
     for (int r = 0; r < sh.n_rot; ++r) {
-        const size_t m = sh.map_rot[r][n];
+        const size_t m = sh.map_rot[r] ? (size_t)sh.map_rot[r][n] : n;
         const u64* __restrict__ K = sh.evk_rot[r] + (size_t)limb * N + m;
+        const u64* __restrict__ er = ext + (size_t)r * sh.rot_ext_stride;
+        const u64* __restrict__ cr = c_ntt + (size_t)r * sh.rot_input_stride;
         for (int j = 0; j < sh.beta; ++j) {
-            const u64 d = j == own ? c_ntt[(size_t)tt * N + m] : ext[((size_t)j * nt + tt) * N + m];
+            const u64 d = j == own ? cr[(size_t)tt * N + m] : er[((size_t)j * nt + tt) * N + m];
             u32 d0, d1, k0, k1;
             split30(d, d0, d1);
             split30(K[(size_t)(2 * j) * kstride], k0, k1);
@@ -211,7 +213,10 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(DeviceTables t, KsShape
     const u64 q = t.moduli[tt];
     const u64* src = in + (size_t)bi * in_stride + (size_t)tt * N;
     u64 acc = 0;
-    for (int r = 0; r < sh.n_rot; ++r) acc = add_mod(acc, src[sh.map_rot[r][n]], q);
+    for (int r = 0; r < sh.n_rot; ++r) {
+        const u64* sr = src + (size_t)r * sh.rot_input_stride;
+        acc = add_mod(acc, sr[sh.map_rot[r] ? (size_t)sh.map_rot[r][n] : n], q);
+    }
     out[((size_t)bi * sh.ell + tt) * N + n] = acc;
 }
 
