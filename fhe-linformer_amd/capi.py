@@ -66,6 +66,9 @@ def load_library():
         "fhelin_last_error": (C.c_char_p, []),
         "fhelin_version": (C.c_char_p, []),
         "fhelin_ctx_create": (i32, [C.POINTER(Params), C.POINTER(vp)]),
+        "fhelin_ctx_create_seeded": (i32, [C.POINTER(Params), vp, C.POINTER(vp)]),
+        "fhelin_ctx_secret_seed": (i32, [vp, vp]),
+        "fhelin_prng_block": (i32, [vp, C.c_uint64, C.c_uint64, vp]),
         "fhelin_ctx_destroy": (None, [vp]),
         "fhelin_ctx_info": (i32, [vp, C.POINTER(Params), C.POINTER(i32), C.POINTER(i32)]),
         "fhelin_ctx_moduli": (i32, [vp, u64p, i32]),
@@ -92,6 +95,10 @@ def load_library():
         "fhelin_key_import": (i32, [vp, i32, i32, vp, C.c_size_t]),
         "fhelin_encode": (i32, [vp, C.POINTER(C.c_double), i32, i32, i32, C.POINTER(vp)]),
         "fhelin_pt_free": (None, [vp]),
+        "fhelin_pt_export": (i32, [vp, vp, i32, C.c_double, C.c_double, vp, C.c_size_t]),
+        "fhelin_rotate_each_sum": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(vp)]),
+        "fhelin_raw_modraise": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "fhelin_raw_phase": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_encrypt": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_decrypt": (i32, [vp, vp, C.POINTER(C.c_double), i32]),
         "fhelin_ct_import": (i32, [vp, vp, i32, i32, i32, C.c_double, i32, C.POINTER(vp)]),
@@ -185,13 +192,20 @@ class DevBuf:
 class Engine:
     """One fhelin context (one GPU, one stream)."""
 
-    def __init__(self, preset="bench", device=0, seed=1, **overrides):
+    def __init__(self, preset="bench", device=0, seed=0, seed_bytes=None, **overrides):
+        """seed=0 (default): keys from 256 bits of OS entropy.  seed != 0: deterministic TEST seed.  seed_bytes: an explicit
+        32-byte secret seed (re-creating a client's keys)."""
         self.lib = load_library()
         cfg = dict(PRESETS[preset]) if isinstance(preset, str) else dict(preset)
         cfg.update(overrides)
         self.params = Params(device=device, seed=seed, **cfg)
         h = C.c_void_p()
-        rc = self.lib.fhelin_ctx_create(C.byref(self.params), C.byref(h))
+        if seed_bytes is not None:
+            assert len(seed_bytes) == 32
+            sb = (C.c_uint8 * 32)(*bytes(seed_bytes))
+            rc = self.lib.fhelin_ctx_create_seeded(C.byref(self.params), sb, C.byref(h))
+        else:
+            rc = self.lib.fhelin_ctx_create(C.byref(self.params), C.byref(h))
         if rc != 0:
             raise FhelinError(rc, self.lib.fhelin_last_error().decode())
         self.h = h
@@ -219,6 +233,11 @@ class Engine:
     def _ck(self, rc):
         if rc != 0:
             raise FhelinError(rc, self.lib.fhelin_last_error().decode())
+
+    def secret_seed(self):
+        out = (C.c_uint8 * 32)()
+        self._ck(self.lib.fhelin_ctx_secret_seed(self.h, out))
+        return bytes(out)
 
     def close(self):
         if getattr(self, "h", None):
@@ -372,6 +391,28 @@ class Engine:
         outs = self._outs(len(v))
         self._ck(self.lib.fhelin_rotate_sum(self.h, self._harr(v), len(v), idx, len(indices), outs))
         return self._cts(outs, len(v))
+
+    def rotate_each_sum(self, v, indices):
+        """sum_i rot(v[i], indices[i]): own ModUp per term, one shared ModDown per <= 7 terms"""
+        idx = (C.c_int32 * len(indices))(*indices)
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_rotate_each_sum(self.h, self._harr(v), idx, len(v), C.byref(h)))
+        return Ct(self, h)
+
+    def raw_modraise(self, a, new_ell):
+        return self._un(self.lib.fhelin_raw_modraise, a, new_ell)
+
+    def raw_phase(self, a):
+        return self._un(self.lib.fhelin_raw_phase, a)
+
+    def pt_export(self, pt, ell, scale=0.0):
+        """[ell][N] residues of the plaintext's encoding at (ell limbs, scale); scale 0 = Delta of that level.  `scale`
+        may be a numpy longdouble: it travels exactly as hi + lo doubles."""
+        out = np.empty((ell, self.N), dtype=np.uint64)
+        hi = float(scale)
+        lo = float(np.longdouble(scale) - np.longdouble(hi))
+        self._ck(self.lib.fhelin_pt_export(self.h, pt.h, ell, hi, lo, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
 
     def rescale(self, a):
         return self._un(self.lib.fhelin_rescale, a)

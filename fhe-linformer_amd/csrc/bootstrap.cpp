@@ -266,18 +266,11 @@ CtPtr Bootstrapper::mod_raise(const CtPtr& ct, long double& rho) {
     x = ev_.rescale(x);  // one limb (q0), scale ~ q0 / 2^correction
     rho = x->scale * (long double)(1ull << correction) / q0;
 
-    const size_t N = c.N;
-    const int L1 = c.L + 1;
-    hipStream_t s = c.stream;
-    u64* coef = c.dalloc<u64>(2 * N);
-    hip_check(hipMemcpyAsync(coef, x->d, 2 * N * 8, hipMemcpyDeviceToDevice, s), "modraise copy");
     c.stats.bootstrap += 1;
-    c.ntt(LimbBatch{coef, 2, nullptr, 0, 1}, true);
-    CtPtr up = ev_.new_ct(2, L1, 1, c.sf_real[0], slots_);
-    launch_modraise(c.dt, up->d, coef, 2, 0, L1, s);
-    c.ntt(LimbBatch{up->d, 2 * L1, nullptr, 0, L1}, false);
-    hip_check(hipGetLastError(), "modraise");
-    c.pool.free(coef);
+    CtPtr up = ev_.raw_modraise(x, c.L + 1);
+    up->deg = 1;
+    up->scale = c.sf_real[0];
+    up->slots = slots_;
     // SubSum: project onto the subring of X^{N/(2 slots)} (sparse packing)
     const int gapN = (c.N / 2) / slots_;
     for (int j = 1; j < gapN; j <<= 1) {

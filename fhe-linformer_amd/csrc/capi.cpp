@@ -22,10 +22,14 @@ extern "C" {
 const char* fhelin_last_error(void) { return g_last_error.c_str(); }
 const char* fhelin_version(void) { return "fhelin_amd 0.1 (gfx950)"; }
 
-int fhelin_ctx_create(const fhelin_params* p, fhelin_ctx** out) {
+static int ctx_create(const fhelin_params* p, const uint8_t* seed32, fhelin_ctx** out) {
     if (!p || !out) return capi_fail(FHELIN_ERR_ARG, "null argument");
     FHELIN_TRY
     Params q;
+    if (seed32) {
+        std::memcpy(q.seed_bytes, seed32, 32);
+        q.have_seed_bytes = true;
+    }
     q.log_n = p->log_n;
     q.n_q = p->n_q;
     q.first_bits = p->first_bits;
@@ -40,6 +44,21 @@ int fhelin_ctx_create(const fhelin_params* p, fhelin_ctx** out) {
     auto* c = new fhelin_ctx(q);
     *out = c;
     FHELIN_CATCH
+}
+int fhelin_ctx_create(const fhelin_params* p, fhelin_ctx** out) { return ctx_create(p, nullptr, out); }
+int fhelin_ctx_create_seeded(const fhelin_params* p, const uint8_t* seed32, fhelin_ctx** out) {
+    if (!seed32) return capi_fail(FHELIN_ERR_ARG, "null seed");
+    return ctx_create(p, seed32, out);
+}
+int fhelin_ctx_secret_seed(const fhelin_ctx* c, uint8_t* out32) {
+    if (!c || !out32) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    std::memcpy(out32, c->ctx.prm.seed_bytes, 32);
+    return FHELIN_OK;
+}
+int fhelin_prng_block(const uint8_t* seed32, uint64_t counter, uint64_t stream, uint8_t* out64) {
+    if (!seed32 || !out64) return capi_fail(FHELIN_ERR_ARG, "null argument");
+    Prng::block(seed32, counter, stream, out64);
+    return FHELIN_OK;
 }
 
 void fhelin_ctx_destroy(fhelin_ctx* c) { delete c; }

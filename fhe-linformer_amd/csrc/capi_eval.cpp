@@ -92,6 +92,18 @@ int fhelin_encode(fhelin_ctx* c, const double* vals, int32_t n, int32_t level, i
     FHELIN_CATCH
 }
 void fhelin_pt_free(fhelin_pt* p) { delete p; }
+int fhelin_pt_export(fhelin_ctx* c, const fhelin_pt* p, int32_t ell, double scale_hi, double scale_lo, uint64_t* out, size_t cap) {
+    NEED(c && p && out);
+    FHELIN_TRY
+    Context& x = c->ctx;
+    x.require_device();
+    if (ell < 1 || ell > x.L + 1) throw Error(FHELIN_ERR_ARG, "pt_export: bad limb count");
+    if (cap < (size_t)ell * x.N) throw Error(FHELIN_ERR_ARG, "buffer too small");
+    auto enc = p->p->at(ell, scale_hi > 0 ? (long double)scale_hi + (long double)scale_lo : x.sf_real[x.L + 1 - ell]);
+    hip_check(hipMemcpyAsync(out, enc->d, (size_t)ell * x.N * 8, hipMemcpyDeviceToHost, x.stream), "pt export");
+    x.sync();
+    FHELIN_CATCH
+}
 
 int fhelin_encrypt(fhelin_ctx* c, const fhelin_pt* p, fhelin_ct** out) {
     NEED(c && p && out);
@@ -208,6 +220,29 @@ int fhelin_rotate_sum(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const
     }
     std::vector<CtPtr> r = c->ev.rotate_sum_batch(in, std::vector<int>(indices, indices + n_rot));
     for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
+    FHELIN_CATCH
+}
+int fhelin_rotate_each_sum(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* indices, int32_t n, fhelin_ct** out) {
+    NEED(c && v && indices && out && n >= 1);
+    FHELIN_TRY
+    std::vector<CtPtr> in;
+    for (int i = 0; i < n; ++i) {
+        if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext in array");
+        in.push_back(ct_in(c, v[i]));
+    }
+    *out = wrap(c->ev.rotate_each_sum(in, std::vector<int>(indices, indices + n)));
+    FHELIN_CATCH
+}
+int fhelin_raw_modraise(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->ev.raw_modraise(ct_in(c, a), new_ell));
+    FHELIN_CATCH
+}
+int fhelin_raw_phase(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c->cl.phase(ct_in(c, a), a->p->ell));
     FHELIN_CATCH
 }
 int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {

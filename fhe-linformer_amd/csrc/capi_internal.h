@@ -15,7 +15,7 @@ struct fhelin_ctx {
     fhelin::Client cl;
     fhelin::Composite comp;
     fhelin::Bootstrapper boot;
-    explicit fhelin_ctx(const fhelin::Params& p) : ctx(p), ev(ctx), cl(ev, p.seed), comp(ev, cl), boot(ev, cl) {}
+    explicit fhelin_ctx(const fhelin::Params& p) : ctx(p), ev(ctx), cl(ev, ctx.prm.seed_bytes), comp(ev, cl), boot(ev, cl) {}
 };
 struct fhelin_ct {
     fhelin::CtPtr p;

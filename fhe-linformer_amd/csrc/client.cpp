@@ -9,34 +9,77 @@
 namespace fhelin {
 
 // ------------------------------------------------------------------------------------------------ PRNG
-static u64 splitmix(u64& x) {
-    u64 z = (x += 0x9E3779B97F4A7C15ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
+// ChaCha20 over GCC vector types: lane j of every state word belongs to block (counter + j), so one pass of the
+// 20 rounds yields LANES blocks (lowered to SSE2/AVX2 by the compiler; no intrinsics).
+namespace {
+typedef u32 vw __attribute__((vector_size(4 * Prng::LANES)));
+inline vw rotl_v(vw x, int k) { return (x << k) | (x >> (32 - k)); }
+inline void quarter(vw& a, vw& b, vw& c, vw& d) {
+    a += b; d ^= a; d = rotl_v(d, 16);
+    c += d; b ^= c; b = rotl_v(b, 12);
+    a += b; d ^= a; d = rotl_v(d, 8);
+    c += d; b ^= c; b = rotl_v(b, 7);
 }
-Prng::Prng(u64 seed) {
-    for (auto& w : s) w = splitmix(seed);
+void chacha20_blocks(const u32 key[8], u64 counter, u64 stream, u32* out /* [LANES][16] */) {
+    static const u32 sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};  // "expand 32-byte k"
+    vw init[16], x[16];
+    for (int i = 0; i < 4; ++i) init[i] = vw{} + sigma[i];
+    for (int i = 0; i < 8; ++i) init[4 + i] = vw{} + key[i];
+    for (int j = 0; j < Prng::LANES; ++j) {
+        const u64 c = counter + (u64)j;
+        init[12][j] = (u32)c;
+        init[13][j] = (u32)(c >> 32);
+    }
+    init[14] = vw{} + (u32)stream;
+    init[15] = vw{} + (u32)(stream >> 32);
+    for (int i = 0; i < 16; ++i) x[i] = init[i];
+    for (int r = 0; r < 10; ++r) {
+        quarter(x[0], x[4], x[8], x[12]);
+        quarter(x[1], x[5], x[9], x[13]);
+        quarter(x[2], x[6], x[10], x[14]);
+        quarter(x[3], x[7], x[11], x[15]);
+        quarter(x[0], x[5], x[10], x[15]);
+        quarter(x[1], x[6], x[11], x[12]);
+        quarter(x[2], x[7], x[8], x[13]);
+        quarter(x[3], x[4], x[9], x[14]);
+    }
+    for (int i = 0; i < 16; ++i) {
+        x[i] += init[i];
+        for (int j = 0; j < Prng::LANES; ++j) out[j * 16 + i] = x[i][j];
+    }
 }
-static inline u64 rotl(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
-u64 Prng::next() {  // xoshiro256**
-    const u64 r = rotl(s[1] * 5, 7) * 9;
-    const u64 t = s[1] << 17;
-    s[2] ^= s[0];
-    s[3] ^= s[1];
-    s[1] ^= s[2];
-    s[0] ^= s[3];
-    s[2] ^= t;
-    s[3] = rotl(s[3], 45);
+void load_key(const uint8_t seed[32], u32 key[8]) {
+    for (int i = 0; i < 8; ++i)
+        key[i] = (u32)seed[4 * i] | ((u32)seed[4 * i + 1] << 8) | ((u32)seed[4 * i + 2] << 16) | ((u32)seed[4 * i + 3] << 24);
+}
+}  // namespace
+
+Prng::Prng(const uint8_t seed[32], u64 stream) : stream_(stream) { load_key(seed, key_); }
+
+void Prng::refill() {
+    chacha20_blocks(key_, counter_, stream_, buf_);
+    counter_ += LANES;
+    pos_ = 0;
+}
+void Prng::block(const uint8_t seed[32], u64 counter, u64 stream, uint8_t out[64]) {
+    u32 key[8], buf[16 * LANES];
+    load_key(seed, key);
+    chacha20_blocks(key, counter, stream, buf);
+    for (int i = 0; i < 16; ++i)
+        for (int b = 0; b < 4; ++b) out[4 * i + b] = (uint8_t)(buf[i] >> (8 * b));
+}
+u64 Prng::next() {
+    if (pos_ + 2 > 16 * LANES) refill();
+    const u64 r = (u64)buf_[pos_] | ((u64)buf_[pos_ + 1] << 32);
+    pos_ += 2;
     return r;
 }
-u64 Prng::uniform(u64 q) {
-    const u64 lim = ~0ull - (~0ull % q + 1) % q;  // largest multiple of q minus one
-    u64 x;
-    do {
-        x = next();
-    } while (x > lim);
-    return x % q;
+u64 Prng::uniform(u64 q) {  // multiply-shift with rejection of the biased low range (exactly uniform)
+    const u64 thresh = (0 - q) % q;  // 2^64 mod q
+    for (;;) {
+        const u128 m = (u128)next() * q;
+        if ((u64)m >= thresh) return (u64)(m >> 64);
+    }
 }
 double Prng::normal() {
     if (have_spare) {
@@ -199,7 +242,7 @@ std::shared_ptr<Encoding> Plaintext::at(int ell, long double scale) {
 }
 
 // ------------------------------------------------------------------------------------------------ Client
-Client::Client(Evaluator& ev, u64 seed) : ev_(ev), c_(ev.ctx()), rng_(seed) {}
+Client::Client(Evaluator& ev, const uint8_t seed[32]) : ev_(ev), c_(ev.ctx()), rng_(seed) {}
 Client::~Client() {
     try {
         if (s_all) c_.pool.free(s_all);
@@ -381,6 +424,24 @@ CtPtr Client::encrypt(const PtPtr& p) {
     return ct;
 }
 
+CtPtr Client::phase(const CtPtr& ct, int nl) {
+    if (!s_all) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
+    if (nl < 1 || nl > ct->ell || ct->npoly < 2) throw Error(FHELIN_ERR_ARG, "phase: bad limb count / component count");
+    const size_t pn = (size_t)ct->ell * c_.N;
+    CtPtr o = ev_.new_ct(1, nl, ct->deg, ct->scale, ct->slots);
+    u64* m = o->d;
+    // m = c0 + c1 s (+ c2 s^2) on the first nl limbs
+    launch_ew_muladd(c_.dt, m, ct->d, ct->d + pn, s_all, nl, nl, 0, nl, c_.stream);
+    if (ct->npoly == 3) {
+        u64* s2 = c_.dalloc<u64>((size_t)nl * c_.N);
+        launch_ew_mul(c_.dt, s2, s_all, s_all, nl, nl, 0, nl, c_.stream);
+        launch_ew_muladd(c_.dt, m, m, ct->d + 2 * pn, s2, nl, nl, 0, nl, c_.stream);
+        c_.pool.free(s2);
+    }
+    hip_check(hipGetLastError(), "phase kernels");
+    return o;
+}
+
 std::vector<double> Client::decrypt(const CtPtr& cin, int slots) {
     if (!s_all) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
     CtPtr ct = cin;
@@ -388,21 +449,13 @@ std::vector<double> Client::decrypt(const CtPtr& cin, int slots) {
     if (slots <= 0) slots = ct->slots > 0 ? ct->slots : (1 << c_.prm.log_slots);
     const size_t N = c_.N;
     const int ell = ct->ell, nl = std::min(ell, 2);
-    const size_t pn = (size_t)ell * N;
-    u64* m = c_.dalloc<u64>((size_t)nl * N);
-    // m = c0 + c1 s (+ c2 s^2) on the first nl limbs
-    launch_ew_muladd(c_.dt, m, ct->d, ct->d + pn, s_all, nl, nl, 0, nl, c_.stream);
-    if (ct->npoly == 3) {
-        u64* s2 = c_.dalloc<u64>((size_t)nl * N);
-        launch_ew_mul(c_.dt, s2, s_all, s_all, nl, nl, 0, nl, c_.stream);
-        launch_ew_muladd(c_.dt, m, m, ct->d + 2 * pn, s2, nl, nl, 0, nl, c_.stream);
-        c_.pool.free(s2);
-    }
+    CtPtr ph = phase(ct, nl);
+    u64* m = ph->d;
     c_.ntt(LimbBatch{m, nl, nullptr, 0, nl}, true);
     std::vector<u64> h((size_t)nl * N);
     hip_check(hipMemcpyAsync(h.data(), m, h.size() * 8, hipMemcpyDeviceToHost, c_.stream), "decrypt download");
     hip_check(hipStreamSynchronize(c_.stream), "decrypt sync");
-    c_.pool.free(m);
+    ph.reset();
     const u64 q0 = c_.chain.q[0];
     const size_t gap = (N / 2) / slots;
     std::vector<std::pair<double, double>> v(slots);

@@ -8,20 +8,30 @@
 
 namespace fhelin {
 
+// Cryptographic pseudo-random generator: the ChaCha20 stream (RFC 8439 block function, 20 rounds) keyed with a 256-bit
+// secret seed; 64-bit block counter (state words 12-13), 64-bit stream id (words 14-15).  Every secret the client samples
+// (secret key, encryption randomness, key-switching-key noise and masks) comes from this stream.
 struct Prng {
-    u64 s[4];
-    explicit Prng(u64 seed);
+    static constexpr int LANES = 8;                // blocks produced per refill
+    explicit Prng(const uint8_t seed[32], u64 stream = 0);
     u64 next();
     u64 uniform(u64 q);        // unbiased in [0, q)
     double normal();           // standard normal (Box-Muller)
+    // one 64-byte block for the given (counter, stream): known-answer tests against RFC 8439
+    static void block(const uint8_t seed[32], u64 counter, u64 stream, uint8_t out[64]);
 private:
+    u32 key_[8];
+    u64 counter_ = 0, stream_ = 0;
+    u32 buf_[16 * LANES];
+    int pos_ = 16 * LANES;     // u32 words consumed of buf_
+    void refill();
     bool have_spare = false;
     double spare = 0;
 };
 
 class Client {
 public:
-    Client(Evaluator& ev, u64 seed);
+    Client(Evaluator& ev, const uint8_t seed[32]);
     ~Client();
     void keygen();                       // secret (sparse ternary) + public key
     bool has_keys() const { return s_all != nullptr; }
@@ -33,6 +43,7 @@ public:
     PtPtr encode(const double* vals, int n, int level, int slots);
     CtPtr encrypt(const PtPtr& p);
     std::vector<double> decrypt(const CtPtr& c, int slots);
+    CtPtr phase(const CtPtr& c, int nlimbs);   // c0 + c1 s (+ c2 s^2) on the first nlimbs limbs, NTT form, 1 component
 
     // raw import/export of key material (parity tests feed identical arrays to the oracle)
     void export_secret(u64* out);        // [L+1+k][N]

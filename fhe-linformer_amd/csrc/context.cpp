@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <sys/random.h>
 
 namespace fhelin {
 
@@ -87,7 +88,24 @@ static u64 prod_mod(const std::vector<u64>& ms, int skip, u64 t) {
 // n_p < 0: the number of special primes OpenFHE's HYBRID parameter generation picks — enough primes of special_bits
 // to cover the widest digit:  sizeP = ceil(max_j bits(prod of digit j) / auxBits)  (29 limbs, dnum 4: 55 + 7*52 = 419 -> 7;
 // the reference's 28 limbs: 55 + 6*52 = 367 -> 7)
+static void resolve_seed(Params& p) {
+    if (p.have_seed_bytes) return;
+    if (p.seed != 0) {  // deterministic test seed: little-endian in the first 8 key bytes
+        std::memset(p.seed_bytes, 0, sizeof p.seed_bytes);
+        for (int i = 0; i < 8; ++i) p.seed_bytes[i] = (uint8_t)(p.seed >> (8 * i));
+    } else {
+        size_t got = 0;
+        while (got < sizeof p.seed_bytes) {
+            const ssize_t n = getrandom(p.seed_bytes + got, sizeof p.seed_bytes - got, 0);
+            if (n <= 0) throw Error(FHELIN_ERR_INTERNAL, "getrandom failed: no entropy for key generation");
+            got += (size_t)n;
+        }
+    }
+    p.have_seed_bytes = true;
+}
+
 static Params resolve_params(Params p) {
+    resolve_seed(p);
     if (p.n_p < 0 && p.n_q >= 1 && p.dnum >= 1 && p.special_bits >= 1) {
         const int a = (p.n_q + p.dnum - 1) / p.dnum;
         const int first = p.first_bits + (std::min(a, p.n_q) - 1) * p.scale_bits;   // the digit that holds q0
@@ -110,6 +128,9 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
     K = p.n_p;
     alpha = (p.n_q + p.dnum - 1) / p.dnum;
     if (alpha > 16) throw Error(FHELIN_ERR_ARG, "digit size > 16 limbs not supported");
+    // the evaluation-key inner product sums beta <= dnum products in 128 bits before ONE Barrett reduction, which needs
+    // beta * p^2 < p * 2^64 for the 60-bit special primes (kernels_ks.hip ks_inner_kernel)
+    if ((p.n_q + alpha - 1) / alpha > 16) throw Error(FHELIN_ERR_ARG, "more than 16 key-switching digits not supported");
     try {
         chain = make_prime_chain(p.log_n, p.n_q, p.first_bits, p.scale_bits, p.n_p, p.special_bits);
     } catch (const std::exception& e) {

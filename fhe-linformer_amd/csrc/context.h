@@ -27,7 +27,12 @@ struct Params {
     int dnum = 4;
     int log_slots = 14;
     int hamming = 192;     // sparse ternary secret weight
-    uint64_t seed = 1;
+    // secret seed of the client-side generator (client.h Prng).  seed == 0: 32 bytes of OS entropy (getrandom) — the
+    // default and the only secure choice; seed != 0: a deterministic 64-bit TEST seed (tests, reproducible benchmarks);
+    // seed_bytes set explicitly (have_seed_bytes): a stored 256-bit seed (load_context regenerating a client's keys)
+    uint64_t seed = 0;
+    uint8_t seed_bytes[32] = {};
+    bool have_seed_bytes = false;
     int device = 0;        // < 0: host-only context (parameter tables only; every device op fails)
 };
 

@@ -782,6 +782,24 @@ CtPtr Evaluator::raw_mult_relin(const CtPtr& a, const CtPtr& b, const EvalKey& k
     return o;
 }
 
+CtPtr Evaluator::raw_modraise(const CtPtr& a, int new_ell) {
+    if (a->ell != 1) throw Error(FHELIN_ERR_STATE, "modraise: the input must have exactly one limb (q0)");
+    if (new_ell < 1 || new_ell > c_.L + 1) throw Error(FHELIN_ERR_ARG, "modraise: bad target limb count");
+    const size_t N = c_.N;
+    const int P = a->npoly;
+    hipStream_t s = c_.stream;
+    u64* coef = c_.dalloc<u64>((size_t)P * N);
+    // INTT of the q0 limb of every polynomial, out of place (the input is immutable)
+    LimbBatch ib{coef, P, nullptr, 0, 1, a->d};
+    c_.ntt(ib, true);
+    CtPtr up = new_ct(P, new_ell, a->deg, a->scale, a->slots);
+    launch_modraise(c_.dt, up->d, coef, P, 0, new_ell, s);
+    c_.ntt(LimbBatch{up->d, P * new_ell, nullptr, 0, new_ell}, false);
+    launch_ok("modraise");
+    c_.pool.free(coef);
+    return up;
+}
+
 // ------------------------------------------------------------------------------------------------ leveled ops
 CtPtr Evaluator::rescale(const CtPtr& a) {
     CtPtr o = raw_rescale(a);

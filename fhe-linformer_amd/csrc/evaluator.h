@@ -163,6 +163,9 @@ public:
     CtPtr raw_rotate(const CtPtr& a, u64 galois, const EvalKey& key, bool accumulate = false);
     CtPtr rotate_add(const CtPtr& a, int index);            // a + rot(a, index), one fused key switch (rotsum step :833)
     CtPtr raw_mult_relin(const CtPtr& a, const CtPtr& b, const EvalKey& key);
+    // K9 ModRaise (EvalBootstrap's first step): a ciphertext with ONE limb (modulus q0) -> new_ell limbs, every coefficient's
+    // centred representative read modulo each q_t.  Scale / degree / slots are copied; the caller sets what they mean.
+    CtPtr raw_modraise(const CtPtr& a, int new_ell);
 
 private:
     Context& c_;

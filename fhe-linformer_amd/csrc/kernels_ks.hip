@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsS
     const size_t kstride = (size_t)(sh.L1 + sh.k) * N;  // one evk component
     u64 lo[2] = {0, 0}, hi[2] = {0, 0};                 // b, a
     Acc30 b = {0, 0, 0}, a = {0, 0, 0};
-    int pending = 0;
+    int pending = 0, folded = 0;
     for (int r = 0; r < sh.n_rot; ++r) {
         const size_t m = sh.map_rot[r] ? (size_t)sh.map_rot[r][n] : n;
         const u64* __restrict__ K = sh.evk_rot[r] + (size_t)limb * N + m;
@@ -188,6 +188,15 @@ __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsS
                 b = Acc30{0, 0, 0};
                 a = Acc30{0, 0, 0};
                 pending = 0;
+                // barrett_reduce128 needs a sum below q * 2^64: 16 products of operands below 2^60 (special limbs:
+                // canonical digits and keys, 16 p^2 < p * 2^64; scaling limbs: digits below 86q, 16 * 86 q^2 < q * 2^64
+                // for q < 2^53) plus one carried residue.  R * beta can reach 28 (giant steps): fold every 16.
+                if (++folded == 2) {
+                    lo[0] = barrett_reduce128(lo[0], hi[0], br);
+                    lo[1] = barrett_reduce128(lo[1], hi[1], br);
+                    hi[0] = hi[1] = 0;
+                    folded = 0;
+                }
             }
         }
     }

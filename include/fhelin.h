@@ -53,7 +53,8 @@ typedef struct fhelin_params {
     int32_t log_slots;     /* SetBatchSize(1 << 14)                  :6,14  */
     int32_t hamming;       /* SPARSE_TERNARY secret weight           :8     */
     int32_t device;        /* HIP device ordinal; < 0 = host-only parameter context */
-    uint64_t seed;         /* PRNG seed for key generation / encryption randomness */
+    uint64_t seed;         /* 0: the client-side generator (ChaCha20) is keyed with 256 bits of OS entropy — the default and the
+                              only secure choice; != 0: deterministic 64-bit TEST seed (reproducible tests / benchmarks) */
 } fhelin_params;
 
 const char* fhelin_last_error(void);
@@ -61,6 +62,14 @@ const char* fhelin_version(void);
 
 /* ---- context (GenCryptoContext + Enable(...), FHEController.cpp:37-45) ------------------------ */
 int fhelin_ctx_create(const fhelin_params* p, fhelin_ctx** out);
+/* the same with an explicit 256-bit secret seed (p->seed ignored): a client re-creating its own keys from its secret-key
+ * file, as FHEController::load_context does from ../keys/secret-key.txt (FHEController.cpp:208-214) */
+int fhelin_ctx_create_seeded(const fhelin_params* p, const uint8_t* seed32, fhelin_ctx** out);
+/* the 256-bit secret seed all key material of this context derives from — SECRET: belongs in the client's secret-key
+ * file (FHEController.cpp:80-86 writes secret-key.txt), never next to the public context */
+int fhelin_ctx_secret_seed(const fhelin_ctx* c, uint8_t* out32);
+/* one 64-byte ChaCha20 block of the client-side generator (known-answer test hook, RFC 8439 section 2.3.2) */
+int fhelin_prng_block(const uint8_t* seed32, uint64_t counter, uint64_t stream, uint8_t* out64);
 void fhelin_ctx_destroy(fhelin_ctx* c);
 int fhelin_ctx_info(const fhelin_ctx* c, fhelin_params* out, int32_t* alpha, int32_t* has_device);
 int fhelin_ctx_moduli(const fhelin_ctx* c, uint64_t* out, int32_t cap);          /* Q then P */
@@ -105,6 +114,12 @@ int fhelin_key_import(fhelin_ctx* c, int32_t kind, int32_t index, const uint64_t
 /* ---- plaintexts: context->MakeCKKSPackedPlaintext(vec, 1, level, nullptr, slots)  :353,:368 ---- */
 int fhelin_encode(fhelin_ctx* c, const double* vals, int32_t n, int32_t level, int32_t slots, fhelin_pt** out);
 void fhelin_pt_free(fhelin_pt* p);
+/* the residues [ell][N] (NTT form) this plaintext multiplies / adds with at `ell` live limbs and real scaling factor
+ * scale_hi + scale_lo (the library keeps scales as 80-bit long double: two doubles carry one exactly; scale_hi <= 0:
+ * the context's Delta of that level) — exactly the encoding EvalMult(ct,pt) / EvalAdd(ct,pt) use for a ciphertext of that
+ * shape (parity tests hand them to the oracle's dyadic functions) */
+int fhelin_pt_export(fhelin_ctx* c, const fhelin_pt* p, int32_t ell, double scale_hi, double scale_lo, uint64_t* out,
+                     size_t cap_words);
 
 /* ---- ciphertexts ----------------------------------------------------------------------------- */
 int fhelin_encrypt(fhelin_ctx* c, const fhelin_pt* p, fhelin_ct** out);                 /* context->Encrypt   :380,:384 */
@@ -134,6 +149,9 @@ int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* 
  * row: the rotated terms are accumulated in the extended basis QP.  Two steps of the reference's rotsum loop (:829-837),
  * x += rot(x, s); x += rot(x, 2s), are the call {s, 2s, 3s}.  Needs the rotation keys of all indices. */
 int fhelin_rotate_sum(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const int32_t* indices, int32_t n_rot, fhelin_ct** outs);
+/* out = sum_i EvalRotate(v[i], indices[i]) (index 0 = plain addend): the giant steps of EvalBootstrap's linear
+ * transforms (:445) — one ModUp per term, inner products accumulated in QP, ONE ModDown per group of <= 7 terms */
+int fhelin_rotate_each_sum(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* indices, int32_t n, fhelin_ct** out);
 int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);                          /* ModReduce (implicit in :427/:431) */
 int fhelin_level_reduce(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhelin_ct** out);
 
@@ -141,6 +159,11 @@ int fhelin_level_reduce(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhel
 int fhelin_raw_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);                      /* K5            */
 int fhelin_raw_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** out);        /* K4 + K6-K8    */
 int fhelin_raw_mult_relin(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b, fhelin_ct** out);/* K2 + K6-K8   */
+/* K9 ModRaise, first step of EvalBootstrap (:445): a ciphertext with ONE limb -> new_ell limbs (centred lift) */
+int fhelin_raw_modraise(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhelin_ct** out);
+/* the decryption phase c0 + c1 s (+ c2 s^2) on every live limb, as a 1-component handle (context->Decrypt :389 before
+ * decoding; client side: needs the secret key) */
+int fhelin_raw_phase(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);
 
 /* ---- FHEController composite circuit ops (callers of the hot path) --------
  * One entry point per reference method; `vector<Ctxt>` travels as (array of handles, count); outputs are

@@ -15,16 +15,31 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIBS = {}
 
 
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def use_fast(fast=True):
+    """Select the build every wrapper below calls: the by-definition build (default; the parity checker) or the
+    -DORC_FAST build (Barrett reductions instead of `%`), which bench.py times as `cpu_baseline`."""
+    global _LIB
+    _LIB = _load("libfhe_oracle_fast.so" if fast else "libfhe_oracle.so")
+    return _LIB
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libfhe_oracle.so")
+        _LIB = _load("libfhe_oracle.so")
+    return _LIB
+
+
+def _load(name):
+    if name not in _LIBS:
+        path = os.path.join(_HERE, name)
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
@@ -42,6 +57,12 @@ def lib():
             "orc_add": (None, [vp, vp, vp, i32, i32, vp]),
             "orc_sub": (None, [vp, vp, vp, i32, i32, vp]),
             "orc_mul_scalar": (None, [vp, vp, vp, i32, i32, vp]),
+            "orc_add_scalar": (None, [vp, vp, vp, i32, i32, vp]),
+            "orc_muladd": (None, [vp, vp, vp, vp, i32, i32, vp]),
+            "orc_modraise": (None, [vp, vp, i32, i32, i32, vp, vp]),
+            "orc_rotate_sum": (None, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+            "orc_rotate_each_sum": (None, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+            "orc_is_fast_build": (i32, []),
             "orc_automorph_coeff": (None, [vp, vp, i32, u64, u64]),
             "orc_automorph_ntt": (None, [vp, vp, i32, u64]),
             "orc_galois": (u64, [i32, lng]),
@@ -55,8 +76,8 @@ def lib():
         for n, (r, a) in sig.items():
             f = getattr(L, n)
             f.restype, f.argtypes = r, a
-        _LIB = L
-    return _LIB
+        _LIBS[name] = L
+    return _LIBS[name]
 
 
 def _u(a):
@@ -148,6 +169,30 @@ def mul_scalar(a, s, q):
     return c
 
 
+def add_scalar(a, s, q):
+    a, s, q = _u(a), _u(s), _u(q)
+    c = np.empty_like(a)
+    lib().orc_add_scalar(_p(a), _p(s), _p(c), a.shape[0], int(np.log2(a.shape[1])), _p(q))
+    return c
+
+
+def muladd(acc, a, b, q):
+    """acc + a * b per limb ([nlimbs][N] each)"""
+    acc, a, b, q = _u(acc), _u(a), _u(b), _u(q)
+    c = np.empty_like(a)
+    lib().orc_muladd(_p(acc), _p(a), _p(b), _p(c), a.shape[0], int(np.log2(a.shape[1])), _p(q))
+    return c
+
+
+def modraise(src, nl, q, psi):
+    """src [npoly][N] (one limb per polynomial, NTT form mod q[0]) -> [npoly][nl][N] NTT form over q[:nl]"""
+    src, q, psi = _u(src), _u(q), _u(psi)
+    npoly, n = src.shape
+    out = np.empty((npoly, nl, n), dtype=np.uint64)
+    lib().orc_modraise(_p(src), _p(out), npoly, nl, int(np.log2(n)), _p(q), _p(psi))
+    return out
+
+
 def galois(log_n, r):
     return int(lib().orc_galois(log_n, int(r)))
 
@@ -189,6 +234,30 @@ def rotate(ct, evk, g, alpha, q, p, psi_q, psi_p):
     _, ell, n = ct.shape
     out = np.empty((2, ell, n), dtype=np.uint64)
     lib().orc_rotate(_p(ct), _p(evk), _p(out), int(g), ell, len(q), len(p), alpha, int(np.log2(n)), _p(q), _p(p), _p(psi_q), _p(psi_p))
+    return out
+
+
+def rotate_sum(ct, evks, gs, alpha, q, p, psi_q, psi_p):
+    """merged rotate-and-sum: ct + sum_r rot(ct, r) with ONE ModUp and ONE ModDown; evks [R][digits][2][L1+k][N]"""
+    ct, evks, q, p, psi_q, psi_p = _u(ct), _u(evks), _u(q), _u(p), _u(psi_q), _u(psi_p)
+    gs = _u(gs)
+    _, ell, n = ct.shape
+    assert evks.shape[0] == len(gs) and evks.shape[1:] == (-(-len(q) // alpha), 2, len(q) + len(p), n)
+    out = np.empty((2, ell, n), dtype=np.uint64)
+    lib().orc_rotate_sum(_p(ct), _p(evks), _p(gs), len(gs), _p(out), ell, len(q), len(p), alpha, int(np.log2(n)),
+                         _p(q), _p(p), _p(psi_q), _p(psi_p))
+    return out
+
+
+def rotate_each_sum(cts, evks, gs, alpha, q, p, psi_q, psi_p):
+    """sum_r rot(cts[r], r): own ModUp per term, inner products summed in QP, ONE ModDown; cts [R][2][ell][N]"""
+    cts, evks, q, p, psi_q, psi_p = _u(cts), _u(evks), _u(q), _u(p), _u(psi_q), _u(psi_p)
+    gs = _u(gs)
+    R, _, ell, n = cts.shape
+    assert R == len(gs) == evks.shape[0] and evks.shape[1:] == (-(-len(q) // alpha), 2, len(q) + len(p), n)
+    out = np.empty((2, ell, n), dtype=np.uint64)
+    lib().orc_rotate_each_sum(_p(cts), _p(evks), _p(gs), R, _p(out), ell, len(q), len(p), alpha, int(np.log2(n)),
+                              _p(q), _p(p), _p(psi_q), _p(psi_p))
     return out
 
 

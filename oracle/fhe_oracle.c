@@ -281,12 +281,47 @@ void orc_ntt_batch(u64* data, int nvec, int count, const u64* q, const u64* psi,
     }
 }
 
+/* ------------------------------------------------------------------ per-modulus multiplication context */
+/* Two builds of this file exist (oracle/Makefile):
+ *   libfhe_oracle.so       mq_red = the `%` operator on unsigned __int128: arithmetic BY DEFINITION.  This is the
+ *                          parity checker and the KAT reference.
+ *   libfhe_oracle_fast.so  -DORC_FAST: mq_red = Barrett reduction with the two-word ratio floor(2^128/q), the form
+ *                          production CPU libraries use (OpenFHE's BarrettUint128ModUint64).  Used ONLY as the timed
+ *                          `cpu_baseline` leg of bench.py, so that the baseline is not slowed by hardware division;
+ *                          tests/test_oracle_kat.py checks that both builds return identical residues. */
+typedef struct { u64 q, r0, r1; } modq;
+static inline modq mq_make(u64 q) {
+    modq m; m.q = q;
+    u128 r = ~(u128)0 / q;           /* floor((2^128-1)/q) = floor(2^128/q) for odd q > 1 */
+    m.r0 = (u64)r; m.r1 = (u64)(r >> 64);
+    return m;
+}
+/* x mod q for x < q * 2^64 (every sum below stays under that bound: <= 16 products of residues < 2^60) */
+static inline u64 mq_red(u128 x, const modq* m) {
+#ifdef ORC_FAST
+    u64 lo = (u64)x, hi = (u64)(x >> 64);
+    /* qhat = floor(x * r / 2^128) up to -2: drop the low word of lo*r0 */
+    u128 t = ((u128)lo * m->r0 >> 64) + (u128)lo * m->r1;
+    u128 t2 = (u128)hi * m->r0 + (u64)t;
+    u64 qhat = hi * m->r1 + (u64)(t >> 64) + (u64)(t2 >> 64);
+    u64 r = lo - qhat * m->q;
+    if (r >= m->q) r -= m->q;
+    if (r >= m->q) r -= m->q;
+    return r;
+#else
+    return (u64)(x % m->q);
+#endif
+}
+static inline u64 mq_mul(u64 a, u64 b, const modq* m) { return mq_red((u128)a * b, m); }
+
 /* ------------------------------------------------------------------ K2/K3: dyadic ops on [nlimbs][N] */
 void orc_mul(const u64* a, const u64* b, u64* c, int nlimbs, int log_n, const u64* q) {
     size_t n = (size_t)1 << log_n;
     #pragma omp parallel for schedule(static)
-    for (int l = 0; l < nlimbs; ++l)
-        for (size_t i = 0; i < n; ++i) c[l * n + i] = mulmod(a[l * n + i], b[l * n + i], q[l]);
+    for (int l = 0; l < nlimbs; ++l) {
+        const modq m = mq_make(q[l]);
+        for (size_t i = 0; i < n; ++i) c[l * n + i] = mq_mul(a[l * n + i], b[l * n + i], &m);
+    }
 }
 void orc_add(const u64* a, const u64* b, u64* c, int nlimbs, int log_n, const u64* q) {
     size_t n = (size_t)1 << log_n;
@@ -303,8 +338,27 @@ void orc_sub(const u64* a, const u64* b, u64* c, int nlimbs, int log_n, const u6
 void orc_mul_scalar(const u64* a, const u64* s, u64* c, int nlimbs, int log_n, const u64* q) {
     size_t n = (size_t)1 << log_n;
     #pragma omp parallel for schedule(static)
+    for (int l = 0; l < nlimbs; ++l) {
+        const modq m = mq_make(q[l]);
+        const u64 sl = s[l] % q[l];
+        for (size_t i = 0; i < n; ++i) c[l * n + i] = mq_mul(a[l * n + i], sl, &m);
+    }
+}
+/* a + s (the constant s_l added to every NTT slot == the constant polynomial s added): EvalAdd(ct, double) */
+void orc_add_scalar(const u64* a, const u64* s, u64* c, int nlimbs, int log_n, const u64* q) {
+    size_t n = (size_t)1 << log_n;
+    #pragma omp parallel for schedule(static)
     for (int l = 0; l < nlimbs; ++l)
-        for (size_t i = 0; i < n; ++i) c[l * n + i] = mulmod(a[l * n + i], s[l] % q[l], q[l]);
+        for (size_t i = 0; i < n; ++i) c[l * n + i] = addmod(a[l * n + i], s[l] % q[l], q[l]);
+}
+/* acc + a * b: the decryption phase c0 + c1 * s (reference Decrypt call sites :389,:399) */
+void orc_muladd(const u64* acc, const u64* a, const u64* b, u64* c, int nlimbs, int log_n, const u64* q) {
+    size_t n = (size_t)1 << log_n;
+    #pragma omp parallel for schedule(static)
+    for (int l = 0; l < nlimbs; ++l) {
+        const modq m = mq_make(q[l]);
+        for (size_t i = 0; i < n; ++i) c[l * n + i] = addmod(acc[l * n + i], mq_mul(a[l * n + i], b[l * n + i], &m), q[l]);
+    }
 }
 
 /* ------------------------------------------------------------------ K4: automorphism X -> X^g */
@@ -318,12 +372,19 @@ void orc_automorph_coeff(const u64* in, u64* out, int log_n, u64 g, u64 q) {
     }
 }
 /* NTT (bit-reversed evaluation) domain: slot j holds m(psi^{2 br(j)+1}); (sigma_g m)(psi^e) = m(psi^{e g}) */
-void orc_automorph_ntt(const u64* in, u64* out, int log_n, u64 g) {
+static void automorph_map(u32* map, int log_n, u64 g) {
     u64 n = 1ull << log_n, m = 2 * n;
     for (u64 j = 0; j < n; ++j) {
         u64 e = ((2ull * bitrev((u32)j, log_n) + 1) * g) % m;
-        out[j] = in[bitrev((u32)((e - 1) >> 1), log_n)];
+        map[j] = bitrev((u32)((e - 1) >> 1), log_n);
     }
+}
+void orc_automorph_ntt(const u64* in, u64* out, int log_n, u64 g) {
+    u64 n = 1ull << log_n;
+    u32* map = malloc(4 * n);
+    automorph_map(map, log_n, g);
+    for (u64 j = 0; j < n; ++j) out[j] = in[map[j]];
+    free(map);
 }
 u64 orc_galois(int log_n, long r) { /* 5^r mod 2N, r may be negative */
     u64 n = 1ull << log_n, m = 2 * n, ord = n / 2;
@@ -334,6 +395,12 @@ u64 orc_galois(int log_n, long r) { /* 5^r mod 2N, r may be negative */
 }
 
 /* ------------------------------------------------------------------ K5: rescale (drop last limb) */
+/* centred lift of v in [0, qs) into modulus t:  v > floor(qs/2) ? v - qs : v   (mod t) */
+static inline u64 lift_centred(u64 v, u64 half, u64 qs_mod_t, const modq* t) {
+    u64 r = mq_red((u128)v, t);
+    if (v > half) r = submod(r, qs_mod_t, t->q);
+    return r;
+}
 /* in [npoly][ell][N] (NTT form) -> out [npoly][ell-1][N]:
  *   out_t = (c_t - [c_last]_centred) * q_last^{-1}  mod q_t          (RNS-CKKS rescale, exact division
  * of the centred representative; OpenFHE DropLastElementAndScale semantics). */
@@ -347,20 +414,40 @@ void orc_rescale(const u64* in, u64* out, int npoly, int ell, int log_n, const u
         orc_ntt_inverse(last, log_n, ql, psi[ell - 1]);
         #pragma omp parallel for schedule(dynamic, 1)
         for (int t = 0; t < ell - 1; ++t) {
+            const modq mt = mq_make(q[t]);
             u64 qt = q[t], qlinv = invmod(ql % qt, qt), qlm = ql % qt;
             u64* tmp = malloc(8 * n);
-            for (size_t i = 0; i < n; ++i) {
-                u64 v = last[i], r = v % qt;
-                if (v > half) r = submod(r, qlm, qt); /* centred lift: v - q_last */
-                tmp[i] = r;
-            }
+            for (size_t i = 0; i < n; ++i) tmp[i] = lift_centred(last[i], half, qlm, &mt);
             orc_ntt_forward(tmp, log_n, qt, psi[t]);
             const u64* c = in + ((size_t)p * ell + t) * n;
             u64* o = out + ((size_t)p * (ell - 1) + t) * n;
-            for (size_t i = 0; i < n; ++i) o[i] = mulmod(submod(c[i], tmp[i], qt), qlinv, qt);
+            for (size_t i = 0; i < n; ++i) o[i] = mq_mul(submod(c[i], tmp[i], qt), qlinv, &mt);
             free(tmp);
         }
         free(last);
+    }
+}
+
+/* ------------------------------------------------------------------ K9: ModRaise (bootstrapping, EvalBootstrap :445) */
+/* src [npoly][N]: ONE limb per polynomial, NTT form modulo q[0].  out [npoly][nl][N], NTT form over q[0..nl):
+ * the centred representative of every coefficient (in (-q0/2, q0/2]) read as an integer modulo each q_t. */
+void orc_modraise(const u64* src, u64* out, int npoly, int nl, int log_n, const u64* q, const u64* psi) {
+    size_t n = (size_t)1 << log_n;
+    u64 q0 = q[0], half = q0 >> 1;
+    for (int i = 0; i < nl; ++i) (void)get_tab(q[i], psi[i], log_n);
+    for (int p = 0; p < npoly; ++p) {
+        u64* co = malloc(8 * n);
+        memcpy(co, src + (size_t)p * n, 8 * n);
+        orc_ntt_inverse(co, log_n, q0, psi[0]);
+        #pragma omp parallel for schedule(dynamic, 1)
+        for (int t = 0; t < nl; ++t) {
+            const modq mt = mq_make(q[t]);
+            u64 q0m = q0 % q[t];
+            u64* o = out + ((size_t)p * nl + t) * n;
+            for (size_t i = 0; i < n; ++i) o[i] = lift_centred(co[i], half, q0m, &mt);
+            orc_ntt_forward(o, log_n, q[t], psi[t]);
+        }
+        free(co);
     }
 }
 
@@ -371,84 +458,136 @@ static u64 prodmod_skip(const u64* ms, int lo, int hi, int skip, u64 t) {
     return r;
 }
 
-/* c: [ell][N] NTT form over q_0..q_{ell-1}.
- * evk: [dnum_digits][2][L1+k][N] NTT form over (q_0..q_{L1-1}, p_0..p_{k-1}); digit j, component 0 = "b", 1 = "a".
- * out: [2][ell][N] NTT form:  out_c = ModDown( sum_j ModUp_j(c) * evk[j][c] ).
- *   ModUp_j: digit j = limbs [j*alpha, min((j+1)*alpha, ell)); HPS fast basis extension without
- *            correction:  d_j[t] = sum_{i in D_j} [c_i * (Q_j/q_i)^{-1}]_{q_i} * (Q_j/q_i)  mod t   for t outside D_j,
- *            and d_j[t] = c_t for t in D_j.
- *   ModDown: out_t = (acc_t - sum_p [acc_p * (P/p)^{-1}]_p * (P/p)) * P^{-1}  mod q_t.                */
-void orc_keyswitch(const u64* c, const u64* evk, u64* out, int ell, int L1, int k, int alpha, int log_n,
-                   const u64* q, const u64* p, const u64* psi_q, const u64* psi_p) {
-    size_t n = (size_t)1 << log_n;
-    int beta = (ell + alpha - 1) / alpha, nt = ell + k;
-    for (int i = 0; i < ell; ++i) (void)get_tab(q[i], psi_q[i], log_n);
-    for (int i = 0; i < k; ++i) (void)get_tab(p[i], psi_p[i], log_n);
-    /* coefficient form of the input */
-    u64* cc = malloc(8 * n * ell);
+typedef struct {
+    int ell, L1, k, alpha, log_n;
+    const u64 *q, *p, *psi_q, *psi_p;
+} ks_par;
+static inline int ks_beta(const ks_par* P) { return (P->ell + P->alpha - 1) / P->alpha; }
+static inline u64 ks_mod(const ks_par* P, int t) { return t < P->ell ? P->q[t] : P->p[t - P->ell]; }
+static inline u64 ks_psi(const ks_par* P, int t) { return t < P->ell ? P->psi_q[t] : P->psi_p[t - P->ell]; }
+static void ks_tabs(const ks_par* P) {
+    for (int i = 0; i < P->ell; ++i) (void)get_tab(P->q[i], P->psi_q[i], P->log_n);
+    for (int i = 0; i < P->k; ++i) (void)get_tab(P->p[i], P->psi_p[i], P->log_n);
+}
+
+/* K6 ModUp.  c [ell][N] NTT form -> d [beta][ell+k][N] NTT form.  Digit j = limbs [j*alpha, min((j+1)*alpha, ell));
+ * HPS fast basis extension WITHOUT correction term:
+ *     d_j[t] = sum_{i in D_j} [c_i * (Q_j/q_i)^{-1}]_{q_i} * [(Q_j/q_i)]_t  mod t   for t outside D_j,
+ *     d_j[t] = c_t                                                                 for t inside  D_j. */
+static void ks_modup(const ks_par* P, const u64* c, u64* d) {
+    size_t n = (size_t)1 << P->log_n;
+    int ell = P->ell, nt = ell + P->k, beta = ks_beta(P);
+    u64* cc = malloc(8 * n * ell);      /* coefficient form, pre-multiplied by (Q_j/q_i)^{-1} */
     memcpy(cc, c, 8 * n * ell);
     #pragma omp parallel for schedule(dynamic, 1)
-    for (int i = 0; i < ell; ++i) orc_ntt_inverse(cc + i * n, log_n, q[i], psi_q[i]);
-    u64* acc = calloc((size_t)2 * nt * n, 8); /* [2][nt][N], target t<ell -> q_t else p_{t-ell} */
-    u64* ext = malloc(8 * n * nt);
-    for (int j = 0; j < beta; ++j) {
-        int lo = j * alpha, hi = (j + 1) * alpha < ell ? (j + 1) * alpha : ell;
-        #pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < ell; ++i) {
+        int j = i / P->alpha, lo = j * P->alpha, hi = (j + 1) * P->alpha < ell ? (j + 1) * P->alpha : ell;
+        const modq mi = mq_make(P->q[i]);
+        u64 hinv = invmod(prodmod_skip(P->q, lo, hi, i, P->q[i]), P->q[i]);
+        u64* ci = cc + (size_t)i * n;
+        orc_ntt_inverse(ci, P->log_n, P->q[i], P->psi_q[i]);
+        for (size_t x = 0; x < n; ++x) ci[x] = mq_mul(ci[x], hinv, &mi);
+    }
+    #pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int j = 0; j < beta; ++j)
         for (int t = 0; t < nt; ++t) {
-            u64 mt = t < ell ? q[t] : p[t - ell];
-            u64* e = ext + (size_t)t * n;
-            if (t >= lo && t < hi) { memcpy(e, c + (size_t)t * n, 8 * n); }
-            else {
-                memset(e, 0, 8 * n);
-                for (int i = lo; i < hi; ++i) {
-                    u64 qi = q[i];
-                    u64 hinv = invmod(prodmod_skip(q, lo, hi, i, qi), qi);
-                    u64 hmod = prodmod_skip(q, lo, hi, i, mt);
-                    const u64* ci = cc + (size_t)i * n;
-                    for (size_t x = 0; x < n; ++x) {
-                        u64 y = mulmod(ci[x], hinv, qi);
-                        e[x] = addmod(e[x], mulmod(y % mt, hmod, mt), mt);
-                    }
-                }
-                orc_ntt_forward(e, log_n, mt, t < ell ? psi_q[t] : psi_p[t - ell]);
+            int lo = j * P->alpha, hi = (j + 1) * P->alpha < ell ? (j + 1) * P->alpha : ell;
+            u64* e = d + ((size_t)j * nt + t) * n;
+            if (t >= lo && t < hi) { memcpy(e, c + (size_t)t * n, 8 * n); continue; }
+            u64 mt = ks_mod(P, t);
+            const modq mm = mq_make(mt);
+            u64 hmod[64];
+            for (int i = lo; i < hi; ++i) hmod[i - lo] = prodmod_skip(P->q, lo, hi, i, mt);
+            for (size_t x = 0; x < n; ++x) {
+                u128 s = 0;              /* <= 16 terms of (residue < 2^60) * (residue < 2^60): no overflow */
+                for (int i = lo; i < hi; ++i) s += (u128)mq_red((u128)cc[(size_t)i * n + x], &mm) * hmod[i - lo];
+                e[x] = mq_red(s, &mm);
             }
-            /* inner product with the evaluation key */
-            int kl = t < ell ? t : L1 + (t - ell);
-            for (int comp = 0; comp < 2; ++comp) {
-                const u64* key = evk + (((size_t)j * 2 + comp) * (L1 + k) + kl) * n;
-                u64* a = acc + ((size_t)comp * nt + t) * n;
-                for (size_t x = 0; x < n; ++x) a[x] = addmod(a[x], mulmod(e[x], key[x], mt), mt);
+            orc_ntt_forward(e, P->log_n, mt, ks_psi(P, t));
+        }
+    free(cc);
+}
+
+/* K7 inner product with one evaluation key, accumulated into acc [2][ell+k][N]:
+ *     acc_c[t][x] += (d_j[t] * evk_{j,c}[t]) [ map ? map[x] : x ]          summed over the digits j.
+ * With map = the NTT-domain index map of an automorphism sigma this adds sigma(d_j * evk_j): the merged
+ * rotate-and-sum form applies each rotation's automorphism to its inner product BEFORE the one shared ModDown. */
+static void ks_inner_acc(const ks_par* P, const u64* d, const u64* evk, u64* acc, const u32* map) {
+    size_t n = (size_t)1 << P->log_n;
+    int ell = P->ell, nt = ell + P->k, beta = ks_beta(P);
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int t = 0; t < nt; ++t) {
+        u64 mt = ks_mod(P, t);
+        const modq mm = mq_make(mt);
+        int kl = t < ell ? t : P->L1 + (t - ell);
+        for (int comp = 0; comp < 2; ++comp) {
+            u64* a = acc + ((size_t)comp * nt + t) * n;
+            for (size_t x = 0; x < n; ++x) {
+                size_t y = map ? map[x] : x;
+                u128 s = 0;
+                for (int j = 0; j < beta; ++j) {
+                    const u64* e = d + ((size_t)j * nt + t) * n;
+                    const u64* key = evk + (((size_t)j * 2 + comp) * (P->L1 + P->k) + kl) * n;
+                    s += (u128)e[y] * key[y];
+                }
+                a[x] = addmod(a[x], mq_red(s, &mm), mt);
             }
         }
     }
-    free(ext); free(cc);
-    /* ModDown */
+}
+
+/* K8 ModDown.  acc [2][ell+k][N] NTT form (destroyed) -> out [2][ell][N]:
+ *     out_t = (acc_t - sum_p [acc_p * (P/p)^{-1}]_p * [(P/p)]_t) * P^{-1}  mod q_t          (no centring) */
+static void ks_moddown(const ks_par* P, u64* acc, u64* out) {
+    size_t n = (size_t)1 << P->log_n;
+    int ell = P->ell, k = P->k, nt = ell + k;
     for (int comp = 0; comp < 2; ++comp) {
         u64* a = acc + (size_t)comp * nt * n;
         #pragma omp parallel for schedule(dynamic, 1)
         for (int j = 0; j < k; ++j) {
+            const modq mp = mq_make(P->p[j]);
             u64* ap = a + (size_t)(ell + j) * n;
-            orc_ntt_inverse(ap, log_n, p[j], psi_p[j]);
-            u64 hinv = invmod(prodmod_skip(p, 0, k, j, p[j]), p[j]);
-            for (size_t x = 0; x < n; ++x) ap[x] = mulmod(ap[x], hinv, p[j]);
+            orc_ntt_inverse(ap, P->log_n, P->p[j], P->psi_p[j]);
+            u64 hinv = invmod(prodmod_skip(P->p, 0, k, j, P->p[j]), P->p[j]);
+            for (size_t x = 0; x < n; ++x) ap[x] = mq_mul(ap[x], hinv, &mp);
         }
         #pragma omp parallel for schedule(dynamic, 1)
         for (int t = 0; t < ell; ++t) {
-            u64 qt = q[t];
-            u64* conv = calloc(n, 8);
-            for (int j = 0; j < k; ++j) {
-                u64 hmod = prodmod_skip(p, 0, k, j, qt);
-                const u64* ap = a + (size_t)(ell + j) * n;
-                for (size_t x = 0; x < n; ++x) conv[x] = addmod(conv[x], mulmod(ap[x] % qt, hmod, qt), qt);
+            u64 qt = P->q[t];
+            const modq mt = mq_make(qt);
+            u64 hmod[64];
+            for (int j = 0; j < k; ++j) hmod[j] = prodmod_skip(P->p, 0, k, j, qt);
+            u64* conv = malloc(8 * n);
+            for (size_t x = 0; x < n; ++x) {
+                u128 s = 0;
+                for (int j = 0; j < k; ++j) s += (u128)mq_red((u128)a[(size_t)(ell + j) * n + x], &mt) * hmod[j];
+                conv[x] = mq_red(s, &mt);
             }
-            orc_ntt_forward(conv, log_n, qt, psi_q[t]);
-            u64 pinv = invmod(prodmod_skip(p, 0, k, -1, qt), qt);
+            orc_ntt_forward(conv, P->log_n, qt, P->psi_q[t]);
+            u64 pinv = invmod(prodmod_skip(P->p, 0, k, -1, qt), qt);
             u64* o = out + ((size_t)comp * ell + t) * n;
             const u64* at = a + (size_t)t * n;
-            for (size_t x = 0; x < n; ++x) o[x] = mulmod(submod(at[x], conv[x], qt), pinv, qt);
+            for (size_t x = 0; x < n; ++x) o[x] = mq_mul(submod(at[x], conv[x], qt), pinv, &mt);
             free(conv);
         }
     }
+}
+
+/* c: [ell][N] NTT form over q_0..q_{ell-1}.
+ * evk: [dnum_digits][2][L1+k][N] NTT form over (q_0..q_{L1-1}, p_0..p_{k-1}); digit j, component 0 = "b", 1 = "a".
+ * out: [2][ell][N] NTT form:  out_c = ModDown( sum_j ModUp_j(c) * evk[j][c] ). */
+void orc_keyswitch(const u64* c, const u64* evk, u64* out, int ell, int L1, int k, int alpha, int log_n,
+                   const u64* q, const u64* p, const u64* psi_q, const u64* psi_p) {
+    const ks_par P = {ell, L1, k, alpha, log_n, q, p, psi_q, psi_p};
+    size_t n = (size_t)1 << log_n;
+    int nt = ell + k;
+    ks_tabs(&P);
+    u64* d = malloc(8 * n * nt * ks_beta(&P));
+    ks_modup(&P, c, d);
+    u64* acc = calloc((size_t)2 * nt * n, 8);
+    ks_inner_acc(&P, d, evk, acc, 0);
+    free(d);
+    ks_moddown(&P, acc, out);
     free(acc);
 }
 
@@ -463,6 +602,79 @@ void orc_rotate(const u64* ct, const u64* evk, u64* out, u64 g, int ell, int L1,
     #pragma omp parallel for schedule(dynamic, 1)
     for (int v = 0; v < 2 * ell; ++v) orc_automorph_ntt(ks + (size_t)v * n, out + (size_t)v * n, log_n, g);
     free(ks);
+}
+
+/* out[t][x] (+)= in[t][map[x]] over ell limbs */
+static void gather_add(const u64* in, u64* out, const u32* map, int ell, int log_n, const u64* q) {
+    size_t n = (size_t)1 << log_n;
+    #pragma omp parallel for schedule(static)
+    for (int t = 0; t < ell; ++t)
+        for (size_t x = 0; x < n; ++x) out[(size_t)t * n + x] = addmod(out[(size_t)t * n + x], in[(size_t)t * n + map[x]], q[t]);
+}
+
+/* Two (or three) consecutive steps of the reference's rotate-and-sum loop (rotsum, :829-837),
+ *     x += EvalRotate(x, s);  x += EvalRotate(x, 2s)      ==      x + rot(x,s) + rot(x,2s) + rot(x,3s),
+ * evaluated as ONE hybrid key switch of c1: one ModUp, the R inner products sigma_r(d * evk_r) summed in the
+ * extended basis QP, one ModDown:
+ *     ks    = ModDown( sum_r sigma_r( ModUp(c1) * evk_r ) )
+ *     out_0 = ks_0 + c0 + sum_r sigma_r(c0),      out_1 = ks_1 + c1.
+ * This is a different integer function from R separate EvalRotate calls (one rounding of the ModDown instead of
+ * R), with the same decryption up to key-switching noise.  ct, out: [2][ell][N]; evks: [R] keys, contiguous;
+ * gs[r] = galois element of rotation r. */
+void orc_rotate_sum(const u64* ct, const u64* evks, const u64* gs, int R, u64* out, int ell, int L1, int k, int alpha,
+                    int log_n, const u64* q, const u64* p, const u64* psi_q, const u64* psi_p) {
+    const ks_par P = {ell, L1, k, alpha, log_n, q, p, psi_q, psi_p};
+    size_t n = (size_t)1 << log_n, pn = n * ell;
+    int nt = ell + k, beta = ks_beta(&P);
+    size_t key_words = (size_t)((L1 + alpha - 1) / alpha) * 2 * (L1 + k) * n;
+    ks_tabs(&P);
+    u64* d = malloc(8 * n * nt * beta);
+    ks_modup(&P, ct + pn, d);
+    u64* acc = calloc((size_t)2 * nt * n, 8);
+    u64* c0s = calloc(pn, 8);
+    u32* map = malloc(4 * n);
+    for (int r = 0; r < R; ++r) {
+        automorph_map(map, log_n, gs[r]);
+        ks_inner_acc(&P, d, evks + (size_t)r * key_words, acc, map);
+        gather_add(ct, c0s, map, ell, log_n, q);
+    }
+    free(d); free(map);
+    ks_moddown(&P, acc, out);
+    free(acc);
+    orc_add(out, c0s, out, ell, log_n, q);
+    orc_add(out, ct, out, ell, log_n, q);
+    orc_add(out + pn, ct + pn, out + pn, ell, log_n, q);
+    free(c0s);
+}
+
+/* sum_r EvalRotate(ct_r, index_r) over R DIFFERENT ciphertexts (the giant steps of a baby-step/giant-step linear
+ * transform inside EvalBootstrap, :445): every term has its own ModUp and key, the inner products are summed in QP
+ * and share one ModDown:
+ *     ks = ModDown( sum_r sigma_r( ModUp(c1_r) * evk_r ) ),   out_0 = ks_0 + sum_r sigma_r(c0_r),   out_1 = ks_1.
+ * cts: [R][2][ell][N]. */
+void orc_rotate_each_sum(const u64* cts, const u64* evks, const u64* gs, int R, u64* out, int ell, int L1, int k, int alpha,
+                         int log_n, const u64* q, const u64* p, const u64* psi_q, const u64* psi_p) {
+    const ks_par P = {ell, L1, k, alpha, log_n, q, p, psi_q, psi_p};
+    size_t n = (size_t)1 << log_n, pn = n * ell;
+    int nt = ell + k, beta = ks_beta(&P);
+    size_t key_words = (size_t)((L1 + alpha - 1) / alpha) * 2 * (L1 + k) * n;
+    ks_tabs(&P);
+    u64* d = malloc(8 * n * nt * beta);
+    u64* acc = calloc((size_t)2 * nt * n, 8);
+    u64* c0s = calloc(pn, 8);
+    u32* map = malloc(4 * n);
+    for (int r = 0; r < R; ++r) {
+        const u64* ct = cts + (size_t)r * 2 * pn;
+        ks_modup(&P, ct + pn, d);
+        automorph_map(map, log_n, gs[r]);
+        ks_inner_acc(&P, d, evks + (size_t)r * key_words, acc, map);
+        gather_add(ct, c0s, map, ell, log_n, q);
+    }
+    free(d); free(map);
+    ks_moddown(&P, acc, out);
+    free(acc);
+    orc_add(out, c0s, out, ell, log_n, q);
+    free(c0s);
 }
 
 /* EvalMult(ct, ct) (reference :431) without the surrounding rescale: tensor + relinearise d2.
@@ -482,6 +694,13 @@ void orc_mult_relin(const u64* a, const u64* b, const u64* evk, u64* out, int el
     free(d2); free(t); free(ks);
 }
 
+int orc_is_fast_build(void) {
+#ifdef ORC_FAST
+    return 1;
+#else
+    return 0;
+#endif
+}
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -1,0 +1,273 @@
+"""Residue-level restatement of the evaluator's LEVELED operations and of the composite circuit ops as the
+product runs them BY DEFAULT (merged rotate-and-sum steps, products rescaled before their rotation trees,
+log-depth shift trees, one rotation by -128).  TEST INFRASTRUCTURE (part of oracle/).
+
+Every function is an exact integer function of its inputs, composed from oracle/fhe_oracle.c (orc_mul, orc_add,
+orc_mul_scalar, orc_rescale, orc_rotate, orc_rotate_sum, ...): the GPU library must return the same residues bit for
+bit (tests/test_default_path_gpu.py).  Reference functions restated (all src/FHEController.cpp):
+  EvalMult(ct,pt) :427  EvalAdd :410,:414  EvalRotate :435,:833  FLEXIBLEAUTO level/scale alignment (implicit in
+  :410,:431)  rotsum :829-837  repeat :849-867  matmulRE :869-899  matmulRElarge :915-944  wrapUpExpanded :1070-1084
+  unwrapExpanded :1086-1100  wrap_containers :1193-1205.
+The order of operations inside a tree (which pairs are merged, which operands are rotated) follows
+fhe-linformer_amd/csrc/composite.cpp; it is part of the function (each key switch rounds once).
+
+Scales are numpy longdouble (x87 80-bit, what `long double` is in the library's host code), so the integer
+constants of the level adjustment round identically.  Plaintext operands arrive as residue arrays (the encoder is the
+client-side row a16, not restated here): `enc(ell, scale)` callbacks return them — tests pass
+`lambda ell, scale: eng.pt_export(pt, ell, scale)`."""
+import numpy as np
+
+import oracle as orc
+
+LD = np.longdouble
+
+
+def _llround(x):
+    """C llroundl: round half away from zero"""
+    x = LD(x)
+    r = np.floor(np.abs(x) + LD(0.5))
+    return int(r) if x >= 0 else -int(r)
+
+
+class RCt:
+    """ciphertext as the library holds it: residues [npoly][ell][N], noiseScaleDeg, real scale"""
+
+    def __init__(self, d, deg, scale):
+        self.d = np.ascontiguousarray(d, dtype=np.uint64)
+        self.deg = int(deg)
+        self.scale = LD(scale)
+
+    @property
+    def ell(self):
+        return self.d.shape[1]
+
+    @property
+    def npoly(self):
+        return self.d.shape[0]
+
+
+class ResidueEvaluator:
+    """mirror of fhe-linformer_amd/csrc/evaluator.cpp bookkeeping over oracle residue functions"""
+
+    def __init__(self, q, p, psi_q, psi_p, alpha, log_n, keys, log_slots=14):
+        self.q, self.p = np.asarray(q, dtype=np.uint64), np.asarray(p, dtype=np.uint64)
+        self.psi_q, self.psi_p = np.asarray(psi_q, dtype=np.uint64), np.asarray(psi_p, dtype=np.uint64)
+        self.alpha, self.log_n = alpha, log_n
+        self.keys = keys                      # rotation index -> evk [digits][2][L1+k][N]
+        self.slots = 1 << log_slots
+        L = len(self.q) - 1
+        sf = [LD(int(self.q[L]))]
+        for k in range(L):
+            sf.append(sf[k] * sf[k] / LD(int(self.q[L - k])))
+        self.sf = sf                          # real Delta per level (level = L + 1 - ell)
+
+    # ---- leaf ops
+    def level(self, a):
+        return len(self.q) - a.ell
+
+    def _each(self, fn, a, *others):
+        return np.stack([fn(a.d[c], *[o[c] for o in others]) for c in range(a.npoly)])
+
+    def rescale(self, a):
+        ell = a.ell
+        d = orc.rescale(a.d, self.q[:ell], self.psi_q[:ell])
+        return RCt(d, a.deg - 1 if a.deg > 1 else 1, a.scale / LD(int(self.q[ell - 1])))
+
+    def level_reduce(self, a, new_ell):
+        return RCt(a.d[:, :new_ell], a.deg, a.scale)
+
+    def mult_int(self, a, k, raise_deg, new_scale):
+        ql = self.q[:a.ell]
+        s = np.array([k % int(m) for m in ql], dtype=np.uint64)
+        return RCt(self._each(lambda x: orc.mul_scalar(x, s, ql), a), a.deg + 1 if raise_deg else a.deg, new_scale)
+
+    def adjust(self, a, ell, deg, scale):
+        """FLEXIBLEAUTO alignment of `a` to (ell, deg, scale): evaluator.cpp Evaluator::adjust"""
+        cur = a
+        assert cur.ell >= ell
+        if cur.ell == ell:
+            if cur.deg == deg:
+                return cur
+            assert cur.deg == 1 and deg == 2
+            return self.mult_int(cur, _llround(scale / cur.scale), True, scale)
+        if deg == 1:
+            if cur.deg == 2:
+                cur = self.rescale(cur)
+            if cur.ell == ell:
+                return cur
+            qdrop = LD(int(self.q[ell]))
+            k = _llround(scale * qdrop / cur.scale)
+            cur = self.mult_int(cur, k, True, cur.scale * LD(k))
+            cur = self.level_reduce(cur, ell + 1)
+            cur = self.rescale(cur)
+            cur.scale = LD(scale)
+            return cur
+        if cur.deg == 2:
+            cur = self.rescale(cur)
+        cur = self.mult_int(cur, _llround(scale / cur.scale), True, scale)
+        return self.level_reduce(cur, ell)
+
+    def match(self, a, b):
+        if a.ell == b.ell and a.deg == b.deg:
+            return a, b
+        a_rules = a.ell < b.ell or (a.ell == b.ell and a.deg >= b.deg)
+        if a_rules:
+            return a, self.adjust(b, a.ell, a.deg, a.scale)
+        return self.adjust(a, b.ell, b.deg, b.scale), b
+
+    def add(self, a, b):
+        x, y = self.match(a, b)
+        ql = self.q[:x.ell]
+        return RCt(self._each(lambda u, v: orc.add(u, v, ql), x, y.d), x.deg, x.scale)
+
+    def sub(self, a, b):
+        x, y = self.match(a, b)
+        ql = self.q[:x.ell]
+        return RCt(self._each(lambda u, v: orc.sub(u, v, ql), x, y.d), x.deg, x.scale)
+
+    def mult_plain(self, a, enc):
+        """EvalMult(ct, pt): a degree-2 operand is rescaled first; the plaintext is encoded at the level's Delta"""
+        x = self.rescale(a) if a.deg >= 2 else a
+        sf = self.sf[self.level(x)]
+        e = enc(x.ell, sf)
+        ql = self.q[:x.ell]
+        return RCt(self._each(lambda u: orc.mul(u, e, ql), x), x.deg + 1, x.scale * sf)
+
+    def add_plain(self, a, enc):
+        e = enc(a.ell, a.scale)
+        ql = self.q[:a.ell]
+        d = a.d.copy()
+        d[0] = orc.add(a.d[0], e, ql)
+        return RCt(d, a.deg, a.scale)
+
+    def _g(self, index):
+        return orc.galois(self.log_n, index)
+
+    def rotate(self, a, index):
+        if index % self.slots == 0:
+            return a
+        d = orc.rotate(a.d, self.keys[index], self._g(index), self.alpha, self.q, self.p, self.psi_q, self.psi_p)
+        return RCt(d, a.deg, a.scale)
+
+    def rotate_add(self, a, index):
+        """a + EvalRotate(a, index): one step of the reference's rotsum loop (:833)"""
+        if index % self.slots == 0:
+            return self.add(a, a)
+        return self.add(self.rotate(a, index), a)
+
+    def rotate_sum(self, a, indices):
+        """merged tree steps: a + sum_r rot(a, r), one ModUp / one ModDown (Evaluator::rotate_sum_batch)"""
+        evks = np.stack([self.keys[r] for r in indices])
+        gs = [self._g(r) for r in indices]
+        d = orc.rotate_sum(a.d, evks, gs, self.alpha, self.q, self.p, self.psi_q, self.psi_p)
+        return RCt(d, a.deg, a.scale)
+
+    def rotate_each_sum(self, cts, indices):
+        """sum_i rot(cts[i], indices[i]) (Evaluator::rotate_each_sum): index-0 terms are plain addends, the others go
+        through the shared-ModDown key switch in groups of <= 7, single leftovers through a plain rotation"""
+        acc, rot, ridx = None, [], []
+        for c, i in zip(cts, indices):
+            if i % self.slots == 0:
+                acc = c if acc is None else self.add(acc, c)
+            else:
+                rot.append(c)
+                ridx.append(i)
+        for lo in range(0, len(rot), 7):
+            chunk, idx = rot[lo:lo + 7], ridx[lo:lo + 7]
+            if len(chunk) < 2:
+                t = self.rotate(chunk[0], idx[0])
+            else:
+                evks = np.stack([self.keys[r] for r in idx])
+                d = orc.rotate_each_sum(np.stack([c.d for c in chunk]), evks, [self._g(r) for r in idx], self.alpha,
+                                        self.q, self.p, self.psi_q, self.psi_p)
+                t = RCt(d, chunk[0].deg, chunk[0].scale)
+            acc = t if acc is None else self.add(acc, t)
+        return acc
+
+    # ---- composites as composite.cpp runs them by default
+    @staticmethod
+    def log_steps(slots):
+        n = 0
+        while n < np.log2(slots):
+            n += 1
+        return n
+
+    def have(self, indices):
+        return all(r % self.slots != 0 and r in self.keys for r in indices)
+
+    def tree_steps(self, r, n, unit, merge=True):
+        i = 0
+        while i < n:
+            s = unit * (1 << i)
+            if i + 1 < n and merge and self.have([s, 2 * s, 3 * s]):
+                r = self.rotate_sum(r, [s, 2 * s, 3 * s])
+                i += 2
+            else:
+                r = self.rotate_add(r, s)
+                i += 1
+        return r
+
+    def rotsum(self, a, slots, padding, early_rescale=True, merge=True):
+        n = self.log_steps(slots)
+        r = self.rescale(a) if (n and early_rescale and a.deg >= 2 and a.ell >= 2) else a
+        return self.tree_steps(r, n, padding, merge) if n else a
+
+    def repeat(self, a, slots, padding=1, early_rescale=True, merge=True):
+        return self.rotsum(a, slots, -padding, early_rescale, merge)
+
+    def shift_sum(self, terms, step):
+        """sum_i rot(terms[i], step * i) as the binary tree of Composite::shift_sum"""
+        cur = list(terms)
+        level = 0
+        while len(cur) > 1:
+            odd = [self.rotate(c, step * (1 << level)) for c in cur[1::2]]
+            even = cur[0:len(cur) - 1:2]
+            nxt = [self.add(e, o) for e, o in zip(even, odd)]
+            if len(cur) & 1:
+                nxt.append(cur[-1])
+            cur = nxt
+            level += 1
+        return cur[0]
+
+    def shift_fan(self, c, n, step):
+        """rot(c, step * i), i < n, by doubling (Composite::shift_fan)"""
+        out = [c]
+        have = 1
+        while have < n:
+            cnt = min(have, n - have)
+            out += [self.rotate(x, step * have) for x in out[:cnt]]
+            have *= 2
+        return out[:n]
+
+    def matmul_pt(self, rows, w_enc, bias_enc, slots, padding):
+        out = [self.rotsum(self.mult_plain(r, w_enc), slots, padding) for r in rows]
+        if bias_enc is not None:
+            out = [self.add_plain(o, bias_enc) for o in out]
+        return out
+
+    def matmulRElarge(self, rows, w_encs, bias_enc, mask_enc):
+        res = None
+        for j in range(len(w_encs) - 1, -1, -1):
+            outs = [self.rotsum(self.mult_plain(r, w_encs[j]), 128, 128) for r in rows]
+            masked = [self.mult_plain(o, mask_enc) for o in outs]
+            if res is None:
+                res = masked
+            else:
+                if self.have([-128]):
+                    res = [self.rotate(r, -128) for r in res]
+                else:
+                    res = [self.rotate(self.rotate(r, -64), -64) for r in res]
+                res = [self.add(r, m) for r, m in zip(res, masked)]
+        if bias_enc is not None:
+            res = [self.add_plain(r, bias_enc) for r in res]
+        return res
+
+    def wrap_containers(self, cts, n):
+        terms = list(cts[:n])[::-1]
+        return self.shift_sum(terms, -512)
+
+    def wrapUpExpanded(self, cts, mask_enc):
+        return self.shift_sum([self.mult_plain(c, mask_enc) for c in cts], -1)
+
+    def unwrapExpanded(self, c, n, mask_enc):
+        return [self.repeat(self.mult_plain(x, mask_enc), 128, 1) for x in self.shift_fan(c, n, 1)]

@@ -1,0 +1,292 @@
+"""The path the product runs BY DEFAULT, residue for residue against the oracle (through the C-ABI):
+merged rotate-and-sum key switches (ks_inner_multi + gather_sum, one ModDown), the shared-ModDown giant steps,
+ct x pt / scalar / ct + pt element-wise kernels, the FLEXIBLEAUTO level adjustment, ModRaise, the decryption phase,
+and the composites with every default-on knob (FHELIN_MERGE_ROT, FHELIN_EARLY_RESCALE, log-depth shift trees, the
+single rotation by -128) left ON.  All comparisons are bit-exact (integer functions); plaintext operands enter the
+oracle as the residues the library's encoder produced (fhelin_pt_export; the encoder is the client-side row a16)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LD = np.longdouble
+
+
+def _ct(orc, eng, seed, ell, npoly=2):
+    return np.stack([orc.uniform_residues(seed + 1000 * p, eng.q[:ell], eng.N) for p in range(npoly)])
+
+
+def _evk(orc, eng, seed):
+    d = eng.dnum_digits
+    k = np.stack([orc.uniform_residues(seed + 50 * j, eng.moduli, eng.N) for j in range(2 * d)])
+    return k.reshape(d, 2, eng.n_limbs, eng.N)
+
+
+def _keys(orc, eng, indices, seed=9000):
+    """uniform 'keys' for the given rotation indices, imported into the engine (parity of the residue functions does not
+    need real keys)"""
+    keys = {}
+    for r in indices:
+        keys[r] = _evk(orc, eng, seed + 17 * (r % 100003))
+        eng.key_import(1, r, keys[r])
+    return keys
+
+
+def _rev(orc, eng, keys):
+    from oracle.residue_eval import ResidueEvaluator
+    return ResidueEvaluator(eng.q, eng.p, eng.psi_q, eng.psi_p, eng.alpha, eng.log_n, keys, eng.params.log_slots)
+
+
+def _imp(eng, rev, x, deg=1, level_scale=None):
+    """the same ciphertext on both sides: engine handle + oracle-side RCt (scale = the level's Delta as a double)"""
+    from oracle.residue_eval import RCt
+    ell = x.shape[1]
+    sc = float(rev.sf[len(eng.q) - ell]) if level_scale is None else float(level_scale)
+    if deg == 2:
+        sc = float(LD(sc) * LD(sc))
+    return eng.ct_import(x, deg=deg, scale=sc), RCt(x, deg, LD(sc))
+
+
+def _same(ct, r, what=""):
+    inf = ct.info()
+    assert (inf["npoly"], inf["ell"], inf["deg"]) == (r.npoly, r.ell, r.deg), (what, inf)
+    assert np.array_equal(ct.export(), r.d), what
+
+
+FORWARD16 = dict(log_n=16, n_q=28, n_p=-1)      # bench.py's forward chain: N=2^16, 28+7 limbs, alpha=7
+
+
+@pytest.mark.parametrize("preset,over,ells,idx,rows", [
+    ("toy", {}, [6, 5, 3, 1], [1, 2, 3], 2),                 # dnum=3, alpha=2: full, partial and single digit
+    ("toy13", {}, [7, 4], [64, 128, 192], 3),
+    ("toy13", {}, [6], [1, 2, 3, 4, 5, 6, 7], 2),            # the kernel's maximum of 7 merged rotations
+    ("toy13", {}, [5], [-2], 1),                             # a single merged term
+    ("reference", {}, [28, 9], [128, 256, 384], 2),          # reference parameters: N=2^15, 28+7 limbs, alpha=7
+    ("bench", {}, [24, 13], [1, 2, 3], 2),                   # BASELINE size: N=2^16, 24+6 limbs
+    ("bench", FORWARD16, [28], [128, 256, 384], 1),          # the headline chain
+])
+def test_rotate_sum_bit_exact(engine_factory, orc, preset, over, ells, idx, rows):
+    """fhelin_rotate_sum (Evaluator::rotate_sum_batch -> ks_inner_multi_kernel + gather_sum_kernel, ONE ModDown) ==
+    orc_rotate_sum on every residue, for a batch of rows"""
+    eng = engine_factory(preset, **over)
+    keys = _keys(orc, eng, idx)
+    evks = np.stack([keys[r] for r in idx])
+    gs = [orc.galois(eng.log_n, r) for r in idx]
+    for ell in ells:
+        xs = [_ct(orc, eng, 300 + 7 * i + ell, ell) for i in range(rows)]
+        got = eng.rotate_sum([eng.ct_import(x) for x in xs], idx)
+        for x, g in zip(xs, got):
+            want = orc.rotate_sum(x, evks, gs, eng.alpha, eng.q, eng.p, eng.psi_q, eng.psi_p)
+            assert np.array_equal(g.export(), want), (preset, ell)
+    del keys, evks
+
+
+@pytest.mark.parametrize("preset,over,ell,idx", [
+    ("toy13", {}, 7, [1, 2, 0, 4, 8, 16, 32, 64]),           # an unrotated addend + exactly 7 rotated terms
+    ("toy13", {}, 3, [1, 2, 4, 8, 16, 32, 64, 128, 256]),    # 9 terms: a group of 7 and a group of 2 (partial digit)
+    ("toy13", {}, 5, [1, 2, 4, 8, 16, 32, 64, 128]),         # 8 terms: a group of 7 and one plain rotation
+    ("bench", {}, 24, [16, 32, 48, 64, 80, 96, 112]),        # R * beta = 28 products per coefficient at N=2^16
+    ("reference", {}, 28, [1, 2, 3]),
+])
+def test_rotate_each_sum_bit_exact(engine_factory, orc, preset, over, ell, idx):
+    """fhelin_rotate_each_sum (the giant steps of the bootstrapping linear transforms: one ModUp per term, shared
+    ModDown) == the oracle's composition of orc_rotate_each_sum / orc_rotate / orc_add"""
+    eng = engine_factory(preset, **over)
+    keys = _keys(orc, eng, [r for r in idx if r], seed=4000)
+    rev = _rev(orc, eng, keys)
+    pairs = [_imp(eng, rev, _ct(orc, eng, 800 + 3 * i, ell)) for i in range(len(idx))]
+    got = eng.rotate_each_sum([p[0] for p in pairs], idx)
+    _same(got, rev.rotate_each_sum([p[1] for p in pairs], idx), (preset, ell))
+    del keys
+
+
+@pytest.mark.parametrize("preset,ell,R", [("bench", 24, 7), ("reference", 28, 7), ("toy", 6, 7)])
+def test_merged_inner_product_extreme_operands(engine_factory, orc, preset, ell, R):
+    """all-maximal residues (q-1) in the ciphertexts and in every key limb: the worst case for the 128-bit
+    accumulation of R * beta = 28 products before a Barrett reduction (the kernel folds every 16)"""
+    eng = engine_factory(preset)
+    idx = list(range(1, R + 1))
+    mx_key = np.stack([np.full(eng.N, int(m) - 1, dtype=np.uint64) for m in eng.moduli])
+    mx_key = np.ascontiguousarray(np.broadcast_to(mx_key, (eng.dnum_digits, 2) + mx_key.shape))
+    for r in idx:
+        eng.key_import(1, r, mx_key)
+    keys = {r: mx_key for r in idx}
+    rev = _rev(orc, eng, keys)
+    mx = np.stack([np.stack([np.full(eng.N, int(m) - 1, dtype=np.uint64) for m in eng.q[:ell]])] * 2)
+    pairs = [_imp(eng, rev, mx) for _ in idx]
+    _same(eng.rotate_each_sum([p[0] for p in pairs], idx), rev.rotate_each_sum([p[1] for p in pairs], idx), "each_sum max")
+    got = eng.rotate_sum([pairs[0][0]], idx)[0]
+    _same(got, rev.rotate_sum(pairs[0][1], idx), "rotate_sum max")
+
+
+@pytest.mark.parametrize("preset,over,ells", [("toy13", {}, [7, 3, 1]), ("reference", {}, [28]), ("bench", {}, [24, 8]),
+                                              ("bench", FORWARD16, [28])])
+def test_ct_pt_products_and_sums_bit_exact(engine_factory, orc, preset, over, ells):
+    """EvalMult(ct,pt) / EvalAdd(ct,pt) (reference :427,:414): the single-operand kernels (ew_binary) and the batched
+    ones the forward pass uses (ew_items<0> via mult_plain_batch, ew_items<3> via add_plain_batch), also on a
+    degree-2 operand (rescaled first)"""
+    eng = engine_factory(preset, **over)
+    rev = _rev(orc, eng, {})
+    ns = 1 << eng.params.log_slots
+    rng = np.random.default_rng(5)
+    w = eng.encode(rng.uniform(-1, 1, ns))
+    b = eng.encode(rng.uniform(-1, 1, ns))
+    wenc = lambda ell, sc: eng.pt_export(w, ell, sc)
+    benc = lambda ell, sc: eng.pt_export(b, ell, sc)
+    for ell in ells:
+        c, r = _imp(eng, rev, _ct(orc, eng, 40 + ell, ell))
+        prod, rprod = eng.mult(c, w), rev.mult_plain(r, wenc)
+        _same(prod, rprod, ("mult_plain", preset, ell))
+        _same(eng.add(prod, b), rev.add_plain(rprod, benc), ("add_plain deg2", preset, ell))
+        _same(eng.add(c, b), rev.add_plain(r, benc), ("add_plain", preset, ell))
+        if ell >= 2:
+            _same(eng.mult(prod, b), rev.mult_plain(rprod, benc), ("mult_plain of a degree-2 operand", preset, ell))
+        # batched rows: matmul with a rotate-and-sum over 1 slot = rows[i] * w + bias, no rotations
+        rows = [_imp(eng, rev, _ct(orc, eng, 90 + ell + 5 * i, ell)) for i in range(3)]
+        outs = eng.matmul_pt([x[0] for x in rows], w, b, 1, 1)
+        for o, (_, rr) in zip(outs, rows):
+            _same(o, rev.add_plain(rev.mult_plain(rr, wenc), benc), ("matmul_pt(slots=1)", preset, ell))
+
+
+def _real_scalars(q, v):
+    """round(|v|) with the sign restored, modulo each q (polyeval.cpp real_to_scalars)"""
+    from oracle.residue_eval import _llround
+    k = _llround(v)
+    return np.array([k % int(m) for m in q], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("preset,ells", [("toy13", [7, 2]), ("bench", [24])])
+def test_real_constant_ops_bit_exact(engine_factory, orc, preset, ells):
+    """EvalMult(ct, double) / EvalAdd(ct, double) as per-limb scalars (ew_scalar_kernel / ew_addscalar_kernel), the
+    form every Chebyshev / power-basis evaluation step uses"""
+    eng = engine_factory(preset)
+    rev = _rev(orc, eng, {})
+    for ell in ells:
+        x = _ct(orc, eng, 60 + ell, ell)
+        c, r = _imp(eng, rev, x)
+        ql = eng.q[:ell]
+        for cst in (0.7310585786300049, -1.25e-3, 3.0):
+            sf = rev.sf[len(eng.q) - ell]
+            s = _real_scalars(ql, LD(cst) * sf)
+            want = np.stack([orc.mul_scalar(x[p], s, ql) for p in range(2)])
+            got = eng.mult_real(c, cst)
+            assert got.info()["deg"] == 2 and np.array_equal(got.export(), want), (preset, ell, cst)
+            s = _real_scalars(ql, LD(cst) * r.scale)
+            want = x.copy()
+            want[0] = orc.add_scalar(x[0], s, ql)
+            assert np.array_equal(eng.add_real(c, cst).export(), want), (preset, ell, cst)
+
+
+@pytest.mark.parametrize("preset,over", [("toy13", {}), ("bench", {}), ("bench", FORWARD16)])
+def test_level_and_degree_adjustment_bit_exact(engine_factory, orc, preset, over):
+    """EvalAdd / EvalSub of operands at different (level, noiseScaleDeg) under FLEXIBLEAUTO: the operand with more limbs
+    is multiplied by an integer, level-reduced and rescaled (Evaluator::adjust -> ew_scalar_kernel + rescale)"""
+    eng = engine_factory(preset, **over)
+    rev = _rev(orc, eng, {})
+    L1 = len(eng.q)
+    hi, mid, lo = L1, L1 - 2, max(2, L1 - 4)
+    a, ra = _imp(eng, rev, _ct(orc, eng, 1, hi))
+    b, rb = _imp(eng, rev, _ct(orc, eng, 2, mid))
+    c2, rc2 = _imp(eng, rev, _ct(orc, eng, 3, lo), deg=2)
+    d2, rd2 = _imp(eng, rev, _ct(orc, eng, 4, hi), deg=2)
+    _same(eng.add(a, b), rev.add(ra, rb), "deg1 + deg1, two levels apart")
+    _same(eng.sub(b, a), rev.sub(rb, ra), "sub, operands swapped")
+    _same(eng.add(a, c2), rev.add(ra, rc2), "deg1 raised to a deeper deg2 operand")
+    _same(eng.add(d2, b), rev.add(rd2, rb), "deg2 operand with more limbs: rescale, scale, reduce")
+    _same(eng.add(a, d2), rev.add(ra, rd2), "same level, deg1 -> deg2 (integer multiply only)")
+
+
+@pytest.mark.parametrize("preset,new_ell", [("toy13", 7), ("reference", 28), ("bench", 24), ("deep", 30), ("toy13", 3)])
+def test_modraise_bit_exact(engine_factory, orc, preset, new_ell):
+    """ModRaise (first step of EvalBootstrap, :445): INTT of the q0 limb, centred lift into every limb, NTT"""
+    eng = engine_factory(preset)
+    x = _ct(orc, eng, 77, 1)
+    q0 = int(eng.q[0])
+    co = np.stack([orc.ntt_inverse(x[p, 0], q0, eng.psi_q[0]) for p in range(2)])
+    co[0, :4] = [0, q0 - 1, q0 // 2, q0 // 2 + 1]                 # the boundary of the centring
+    x = np.stack([orc.ntt_forward(co[p], q0, eng.psi_q[0]) for p in range(2)])[:, None, :]
+    got = eng.raw_modraise(eng.ct_import(x), new_ell).export()
+    want = orc.modraise(x[:, 0], new_ell, eng.q[:new_ell], eng.psi_q[:new_ell])
+    assert got.shape == want.shape == (2, new_ell, eng.N)
+    assert np.array_equal(got, want)
+    with pytest.raises(Exception):
+        eng.raw_modraise(eng.ct_import(_ct(orc, eng, 5, 2)), new_ell)   # more than one limb: refused
+
+
+@pytest.mark.parametrize("preset,ell,npoly", [("toy13", 7, 2), ("toy13", 4, 3), ("bench", 24, 2)])
+def test_decryption_phase_bit_exact(fa, orc, preset, ell, npoly):
+    """c0 + c1 s (+ c2 s^2): the multiply-accumulate kernel under context->Decrypt (ew_muladd_kernel)"""
+    eng = fa.Engine(preset, seed=5)
+    try:
+        eng.keygen()
+        s = eng.secret_export()[:ell]
+        x = _ct(orc, eng, 11, ell, npoly)
+        ql = eng.q[:ell]
+        want = orc.muladd(x[0], x[1], s, ql)
+        if npoly == 3:
+            want = orc.muladd(want, x[2], orc.mul(s, s, ql), ql)
+        got = eng.raw_phase(eng.ct_import(x)).export()
+        assert got.shape == (1, ell, eng.N) and np.array_equal(got[0], want)
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("preset,over,ell", [("bench", FORWARD16, 16), ("reference", {}, 28), ("toy13", {}, 5)])
+def test_rotsum_repeat_default_knobs_bit_exact(engine_factory, orc, preset, over, ell):
+    """rotsum / repeat exactly as the forward pass runs them (FHELIN_MERGE_ROT and FHELIN_EARLY_RESCALE at their
+    defaults): a degree-2 product is rescaled first, tree steps run in merged pairs {s,2s,3s}, an odd last step as
+    rotate+add"""
+    eng = engine_factory(preset, **over)
+    need = [128, 256, 384, 512, -1, -2, -3, -4, -8, -12, -16]
+    keys = _keys(orc, eng, need, seed=600)
+    rev = _rev(orc, eng, keys)
+    c1, r1 = _imp(eng, rev, _ct(orc, eng, 7, ell))
+    c2, r2 = _imp(eng, rev, _ct(orc, eng, 8, ell), deg=2)
+    _same(eng.rotsum(c1, 8, 128), rev.rotsum(r1, 8, 128), "rotsum: merged pair + single step")
+    _same(eng.rotsum(c2, 4, 128), rev.rotsum(r2, 4, 128), "rotsum of a product: early rescale + one merged pair")
+    _same(eng.repeat(c2, 32, 1), rev.repeat(r2, 32, 1), "repeat: two merged pairs + single step, negative steps")
+    _same(eng.rotsum(c1, 1, 128), r1, "zero steps: a copy")
+    del keys
+
+
+def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
+    """the log-depth forms of the reference's rotate-by-one chains (shift_sum in wrapUpExpanded / wrap_containers,
+    shift_fan in unwrapExpanded) and matmulRElarge with its single rotation by -128, composed on the oracle side in the
+    same tree order, at the reference's ring (N=2^15, 16384 slots) on a short chain"""
+    eng = fa.Engine("reference", seed=3, n_q=6, n_p=2, dnum=3)
+    try:
+        need = set()
+        for u in (128, 512, 2048):
+            need.update((u, 2 * u, 3 * u))
+        need.update((8192, -128))                                   # rotsum(128,128) + the -128 shift of matmulRElarge
+        for u in (-1, -4, -16):
+            need.update((u, 2 * u, 3 * u))
+        need.update((-64, 1, 2, -512, -1024, -2048))                # repeat(128,1), fans, wrap_containers
+        keys = _keys(orc, eng, sorted(need), seed=100)
+        rev = _rev(orc, eng, keys)
+        ns, rng = 16384, np.random.default_rng(9)
+        pt = lambda v: eng.encode(v)
+        enc_of = lambda p: (lambda ell, sc: eng.pt_export(p, ell, sc))
+        ell = 6
+        # wrap_containers: sum_i rot(c[n-1-i], -512 i)
+        cts = [_imp(eng, rev, _ct(orc, eng, 200 + i, ell)) for i in range(5)]
+        _same(eng.wrap_containers([c[0] for c in cts], 5), rev.wrap_containers([c[1] for c in cts], 5), "wrap_containers")
+        # wrapUpExpanded / unwrapExpanded with the (i % 128 == 0) mask
+        m128 = np.zeros(ns)
+        m128[::128] = 1.0
+        menc = enc_of(pt(m128))
+        w, rw = eng.wrapUpExpanded([c[0] for c in cts[:3]]), rev.wrapUpExpanded([c[1] for c in cts[:3]], menc)
+        _same(w, rw, "wrapUpExpanded")
+        for o, r in zip(eng.unwrapExpanded(w, 3), rev.unwrapExpanded(rw, 3, menc)):
+            _same(o, r, "unwrapExpanded")
+        # matmulRElarge: 2 weight blocks, mask value 0.5, bias
+        ws = [pt(rng.uniform(-1, 1, ns) / 8) for _ in range(2)]
+        bias = pt(rng.uniform(-1, 1, ns))
+        first = np.zeros(ns)
+        first[:128] = 0.5
+        rows = cts[:2]
+        outs = eng.matmulRElarge([c[0] for c in rows], ws, bias, 0.5)
+        want = rev.matmulRElarge([c[1] for c in rows], [enc_of(x) for x in ws], enc_of(bias), enc_of(pt(first)))
+        for o, r in zip(outs, want):
+            _same(o, r, "matmulRElarge")
+    finally:
+        eng.close()

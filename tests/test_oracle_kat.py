@@ -242,3 +242,140 @@ def test_mult_relin_by_decryption(orc):
     diff = orc.ntt_batch(orc.sub(dout, orc.mul(da, db, q), q), q, psi_q, inverse=True)
     err = _crt2(diff[0], diff[1], int(q[0]), int(q[1]))
     assert max(abs(e) for e in err) < 2 ** 40
+
+
+def _rot_keys(orc, log_n, q, p, psi_q, psi_p, alpha, s, rots, rng):
+    """rotation keys (s -> sigma_{g^-1}(s)) for every index in rots, stacked [R][dnum][2][L1+k][N]; galois elements"""
+    n = 1 << log_n
+    q0 = int(q[0])
+    s_coeff = np.array([v % q0 for v in s], dtype=np.uint64)
+    evks, gs = [], []
+    for r in rots:
+        g = orc.galois(log_n, r)
+        s_perm = orc.automorph_coeff(s_coeff, pow(g, -1, 2 * n), q0)
+        s_perm_int = [int(v) if v < q0 // 2 else int(v) - q0 for v in s_perm]
+        evks.append(_toy_keys(orc, log_n, q, p, psi_q, psi_p, alpha, s, s_perm_int, rng)[0])
+        gs.append(g)
+    return np.stack(evks), gs
+
+
+def _phase(orc, ct, s_ntt, q):
+    return orc.add(ct[0], orc.mul(ct[1], s_ntt, q), q)
+
+
+@pytest.mark.parametrize("ell,rots", [(4, [1, 2, 3]), (3, [128, -64]), (4, [5])])
+def test_rotate_sum_by_decryption(orc, ell, rots):
+    """merged rotate-and-sum (one ModUp, inner products summed in QP, one ModDown): decrypts to
+    m + sum_r sigma_r(m) up to key-switching noise, at a full and a partial-digit level"""
+    log_n, L1, k, alpha = 12, 4, 2, 2
+    q, p, psi_q, psi_p = _chain(orc, log_n, L1, k)
+    rng = np.random.default_rng(11)
+    n = 1 << log_n
+    s = [int(v) for v in rng.integers(-1, 2, size=n)]
+    evks, gs = _rot_keys(orc, log_n, q, p, psi_q, psi_p, alpha, s, rots, rng)
+    ql, pl = q[:ell], psi_q[:ell]
+    ct = np.array([[rng.integers(0, int(m), size=n, dtype=np.uint64) for m in ql] for _ in range(2)])
+    out = orc.rotate_sum(ct, evks, gs, alpha, q, p, psi_q, psi_p)
+    s_ntt = orc.ntt_batch(np.array([[v % int(m) for v in s] for m in ql], dtype=np.uint64), ql, pl)
+    din = _phase(orc, ct, s_ntt, ql)
+    expect = din
+    for g in gs:
+        expect = orc.add(expect, np.array([orc.automorph_ntt(x, g) for x in din]), ql)
+    diff = orc.ntt_batch(orc.sub(_phase(orc, out, s_ntt, ql), expect, ql), ql, pl, inverse=True)
+    err = _crt2(diff[0], diff[1], int(ql[0]), int(ql[1]))
+    assert max(abs(e) for e in err) < 2 ** 40
+    # the merged form differs from separate rotations only by ModDown rounding: tiny, but not zero
+    sep = ct
+    acc = ct
+    for r, g in zip(range(len(gs)), gs):
+        acc = np.stack([orc.add(acc[c], orc.rotate(ct, evks[r], g, alpha, q, p, psi_q, psi_p)[c], ql) for c in range(2)])
+    d2 = orc.ntt_batch(orc.sub(_phase(orc, out, s_ntt, ql), _phase(orc, acc, s_ntt, ql), ql), ql, pl, inverse=True)
+    assert max(abs(e) for e in _crt2(d2[0], d2[1], int(ql[0]), int(ql[1]))) < 2 ** 40
+    del sep
+
+
+def test_rotate_each_sum_by_decryption(orc):
+    """giant-step form: sum_r rot(ct_r, r) with one ModUp per term and ONE shared ModDown"""
+    log_n, L1, k, alpha, ell = 12, 4, 2, 2, 4
+    q, p, psi_q, psi_p = _chain(orc, log_n, L1, k)
+    rng = np.random.default_rng(12)
+    n = 1 << log_n
+    rots = [4, 8, -16]
+    s = [int(v) for v in rng.integers(-1, 2, size=n)]
+    evks, gs = _rot_keys(orc, log_n, q, p, psi_q, psi_p, alpha, s, rots, rng)
+    cts = np.array([[[rng.integers(0, int(m), size=n, dtype=np.uint64) for m in q] for _ in range(2)] for _ in rots])
+    out = orc.rotate_each_sum(cts, evks, gs, alpha, q, p, psi_q, psi_p)
+    s_ntt = orc.ntt_batch(np.array([[v % int(m) for v in s] for m in q], dtype=np.uint64), q, psi_q)
+    expect = None
+    for ct, g in zip(cts, gs):
+        t = np.array([orc.automorph_ntt(x, g) for x in _phase(orc, ct, s_ntt, q)])
+        expect = t if expect is None else orc.add(expect, t, q)
+    diff = orc.ntt_batch(orc.sub(_phase(orc, out, s_ntt, q), expect, q), q, psi_q, inverse=True)
+    assert max(abs(e) for e in _crt2(diff[0], diff[1], int(q[0]), int(q[1]))) < 2 ** 40
+    # a single term is the plain rotation minus nothing: ModDown(sigma(x)) vs sigma(ModDown(x)) differ by rounding only
+    one = orc.rotate_each_sum(cts[:1], evks[:1], gs[:1], alpha, q, p, psi_q, psi_p)
+    ref = orc.rotate(cts[0], evks[0], gs[0], alpha, q, p, psi_q, psi_p)
+    d1 = orc.ntt_batch(orc.sub(_phase(orc, one, s_ntt, q), _phase(orc, ref, s_ntt, q), q), q, psi_q, inverse=True)
+    assert max(abs(e) for e in _crt2(d1[0], d1[1], int(q[0]), int(q[1]))) < 2 ** 40
+
+
+def test_modraise_is_the_centred_lift(orc):
+    """ModRaise: every coefficient's centred representative modulo q0, read modulo each q_t (python big ints)"""
+    log_n, nl = 12, 4
+    q, _, psi, _ = _chain(orc, log_n, nl, 1)
+    rng = np.random.default_rng(13)
+    n = 1 << log_n
+    q0 = int(q[0])
+    co = rng.integers(0, q0, size=(2, n), dtype=np.uint64)
+    co[0, :4] = [0, q0 - 1, q0 // 2, q0 // 2 + 1]          # boundary values of the centring
+    src = np.stack([orc.ntt_forward(c, q0, psi[0]) for c in co])
+    out = orc.modraise(src, nl, q, psi)
+    assert out.shape == (2, nl, n)
+    for pidx in range(2):
+        back = orc.ntt_batch(out[pidx], q, psi, inverse=True)
+        for t in range(nl):
+            qt = int(q[t])
+            want = np.array([(int(v) - q0 if int(v) > q0 // 2 else int(v)) % qt for v in co[pidx]], dtype=np.uint64)
+            assert np.array_equal(back[t], want), t
+
+
+def test_fast_build_equals_definition_build(orc):
+    """libfhe_oracle_fast.so (Barrett reductions; the timed cpu_baseline leg) returns the residues of the
+    by-definition build (`%`) for every residue function, including all-maximal operands"""
+    log_n, L1, k, alpha = 12, 5, 2, 2
+    q, p, psi_q, psi_p = _chain(orc, log_n, L1, k)
+    n = 1 << log_n
+    rng = np.random.default_rng(14)
+    allm = np.concatenate([q, p])
+    d = -(-L1 // alpha)
+    evks = np.stack([np.stack([orc.uniform_residues(900 + 50 * j + 7 * r, allm, n) for j in range(2 * d)]).reshape(d, 2, L1 + k, n)
+                     for r in range(2)])
+    gs = [orc.galois(log_n, 1), orc.galois(log_n, -2)]
+    res = {}
+    for fast in (False, True):
+        orc.use_fast(fast)
+        try:
+            assert bool(orc.lib().orc_is_fast_build()) == fast
+            for ell in (5, 3):
+                ql = q[:ell]
+                a = np.stack([orc.uniform_residues(1 + i, ql, n) for i in range(2)])
+                b = np.stack([orc.uniform_residues(5 + i, ql, n) for i in range(2)])
+                mx = np.stack([np.stack([np.full(n, int(m) - 1, dtype=np.uint64) for m in ql])] * 2)
+                sc = np.array([int(m) - 2 for m in ql], dtype=np.uint64)
+                for tag, x in (("rnd", a), ("max", mx)):
+                    out = [orc.mul(x[0], b[1], ql), orc.mul_scalar(x[0], sc, ql), orc.muladd(x[0], x[1], b[0], ql),
+                           orc.rescale(x, ql, psi_q[:ell]) if ell > 1 else x,
+                           orc.rotate(x, evks[0], gs[0], alpha, q, p, psi_q, psi_p),
+                           orc.rotate_sum(x, evks, gs, alpha, q, p, psi_q, psi_p),
+                           orc.rotate_each_sum(np.stack([x, b]), evks, gs, alpha, q, p, psi_q, psi_p),
+                           orc.mult_relin(x, b, evks[1], alpha, q, p, psi_q, psi_p),
+                           orc.modraise(x[:, 0], ell, ql, psi_q[:ell])]
+                    key = (ell, tag)
+                    if fast:
+                        for u, v in zip(res[key], out):
+                            assert np.array_equal(u, v), key
+                    else:
+                        res[key] = out
+        finally:
+            orc.use_fast(False)
+    del rng
