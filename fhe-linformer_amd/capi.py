@@ -117,6 +117,11 @@ def load_library():
         "fhelin_rotate_each": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(vp)]),
         "fhelin_rotate_sum": (i32, [vp, C.POINTER(vp), i32, C.POINTER(i32), i32, C.POINTER(vp)]),
         "fhelin_rescale": (i32, [vp, vp, C.POINTER(vp)]),
+        "fhelin_rotate_batch": (i32, [vp, C.POINTER(vp), i32, i32, C.POINTER(vp)]),
+        "fhelin_rescale_batch": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp)]),
+        "fhelin_mult_plain_batch": (i32, [vp, C.POINTER(vp), i32, vp, C.POINTER(vp)]),
+        "fhelin_mult_batch": (i32, [vp, C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(vp)]),
+        "fhelin_add_batch": (i32, [vp, C.POINTER(vp), C.POINTER(vp), i32, C.POINTER(vp)]),
         "fhelin_level_reduce": (i32, [vp, vp, i32, C.POINTER(vp)]),
         "fhelin_raw_rescale": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_raw_rotate": (i32, [vp, vp, i32, C.POINTER(vp)]),
@@ -275,9 +280,9 @@ class Engine:
         self._ck(self.lib.fhelin_ntt(self.h, buf.ptr, nvec, limb_first, limb_count, 1 if inverse else 0))
 
     def stats(self, reset=False):
-        out = np.zeros(7, dtype=np.uint64)
-        self._ck(self.lib.fhelin_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), 7, 1 if reset else 0))
-        keys = ["limb_ntt", "keyswitch", "keyswitch_limbs", "rescale", "ct_pt_mult", "bootstrap", "encode"]
+        out = np.zeros(9, dtype=np.uint64)
+        self._ck(self.lib.fhelin_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), 9, 1 if reset else 0))
+        keys = ["limb_ntt", "keyswitch", "keyswitch_limbs", "rescale", "ct_pt_mult", "bootstrap", "encode", "rescale_limbs", "ct_pt_limbs"]
         return {k: int(v) for k, v in zip(keys, out)}
 
     def microbench(self, variant, iters=4096, blocks=2048):
@@ -416,6 +421,31 @@ class Engine:
 
     def rescale(self, a):
         return self._un(self.lib.fhelin_rescale, a)
+
+    # ---- leaf ops over independent rows (one launch set per chunk of rows of equal shape)
+    def _rows(self, fn, v, *extra):
+        outs = self._outs(len(v))
+        self._ck(fn(self.h, self._harr(v), *extra, outs))
+        return self._cts(outs, len(v))
+
+    def rotate_batch(self, v, index):
+        return self._rows(self.lib.fhelin_rotate_batch, v, len(v), index)
+
+    def rescale_batch(self, v):
+        return self._rows(self.lib.fhelin_rescale_batch, v, len(v))
+
+    def mult_plain_batch(self, v, pt):
+        return self._rows(self.lib.fhelin_mult_plain_batch, v, len(v), pt.h)
+
+    def mult_batch(self, a, b):
+        outs = self._outs(len(a))
+        self._ck(self.lib.fhelin_mult_batch(self.h, self._harr(a), self._harr(b), len(a), outs))
+        return self._cts(outs, len(a))
+
+    def add_batch(self, a, b):
+        outs = self._outs(len(a))
+        self._ck(self.lib.fhelin_add_batch(self.h, self._harr(a), self._harr(b), len(a), outs))
+        return self._cts(outs, len(a))
 
     def level_reduce(self, a, new_ell):
         return self._un(self.lib.fhelin_level_reduce, a, new_ell)

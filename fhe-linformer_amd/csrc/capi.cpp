@@ -199,6 +199,10 @@ int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset) {
     out[4] = s.ct_pt_mult;
     out[5] = s.bootstrap;
     out[6] = s.encode;
+    if (cap >= 9) {
+        out[7] = s.rescale_limbs;
+        out[8] = s.ct_pt_limbs;
+    }
     if (reset) s = OpStats();
     return FHELIN_OK;
 }

@@ -26,6 +26,36 @@ static PtPtr opt(const fhelin_pt* p) { return p ? p->p : PtPtr(); }
 
 extern "C" {
 
+int fhelin_rotate_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t index, fhelin_ct** outs) {
+    NEED(c && v && outs && n >= 0);
+    FHELIN_TRY
+    emit(c->ev.rotate_batch(vec_of(c, v, n), index), outs);
+    FHELIN_CATCH
+}
+int fhelin_rescale_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** outs) {
+    NEED(c && v && outs && n >= 0);
+    FHELIN_TRY
+    emit(c->ev.rescale_batch(vec_of(c, v, n)), outs);
+    FHELIN_CATCH
+}
+int fhelin_mult_plain_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const fhelin_pt* p, fhelin_ct** outs) {
+    NEED(c && v && p && outs && n >= 0);
+    FHELIN_TRY
+    emit(c->ev.mult_plain_batch(vec_of(c, v, n), p->p), outs);
+    FHELIN_CATCH
+}
+int fhelin_mult_batch(fhelin_ctx* c, const fhelin_ct* const* a, const fhelin_ct* const* b, int32_t n, fhelin_ct** outs) {
+    NEED(c && a && b && outs && n >= 0);
+    FHELIN_TRY
+    emit(c->ev.mult_batch(vec_of(c, a, n), vec_of(c, b, n)), outs);
+    FHELIN_CATCH
+}
+int fhelin_add_batch(fhelin_ctx* c, const fhelin_ct* const* a, const fhelin_ct* const* b, int32_t n, fhelin_ct** outs) {
+    NEED(c && a && b && outs && n >= 0);
+    FHELIN_TRY
+    emit(c->ev.add_batch(vec_of(c, a, n), vec_of(c, b, n)), outs);
+    FHELIN_CATCH
+}
 int fhelin_fc_mult_const(fhelin_ctx* c, const fhelin_ct* a, double d, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY

@@ -13,12 +13,12 @@ namespace fhelin {
 // 20 rounds yields LANES blocks (lowered to SSE2/AVX2 by the compiler; no intrinsics).
 namespace {
 typedef u32 vw __attribute__((vector_size(4 * Prng::LANES)));
-inline vw rotl_v(vw x, int k) { return (x << k) | (x >> (32 - k)); }
-inline void quarter(vw& a, vw& b, vw& c, vw& d) {
-    a += b; d ^= a; d = rotl_v(d, 16);
-    c += d; b ^= c; b = rotl_v(b, 12);
-    a += b; d ^= a; d = rotl_v(d, 8);
-    c += d; b ^= c; b = rotl_v(b, 7);
+#define FHELIN_ROTL(x, k) (((x) << (k)) | ((x) >> (32 - (k))))
+inline void quarter(vw& a, vw& b, vw& c, vw& d) {  // vectors travel by reference only (no vector ABI involved)
+    a += b; d ^= a; d = FHELIN_ROTL(d, 16);
+    c += d; b ^= c; b = FHELIN_ROTL(b, 12);
+    a += b; d ^= a; d = FHELIN_ROTL(d, 8);
+    c += d; b ^= c; b = FHELIN_ROTL(b, 7);
 }
 void chacha20_blocks(const u32 key[8], u64 counter, u64 stream, u32* out /* [LANES][16] */) {
     static const u32 sigma[4] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};  // "expand 32-byte k"

@@ -81,6 +81,8 @@ struct OpStats {
     u64 ct_pt_mult = 0;
     u64 bootstrap = 0;
     u64 encode = 0;
+    u64 rescale_limbs = 0;    // sum of live Q limbs (before the drop) over those rescales
+    u64 ct_pt_limbs = 0;      // sum of live Q limbs over those products
 };
 
 struct Context {

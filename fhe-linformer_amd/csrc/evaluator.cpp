@@ -480,6 +480,7 @@ CtPtr Evaluator::raw_rescale(const CtPtr& a) {
     hipStream_t s = c_.stream;
     u64* last = c_.dalloc<u64>((size_t)P * N);
     c_.stats.rescale += 1;
+    c_.stats.rescale_limbs += (u64)ell;
     {
         // INTT of the last limb of every polynomial, read in place (stride = one polynomial), written densely
         LimbBatch lb{last, P, nullptr, ell - 1, 1, a->d + (size_t)(ell - 1) * N};
@@ -576,6 +577,7 @@ std::vector<CtPtr> Evaluator::rescale_batch(const std::vector<CtPtr>& vin) {
         const u64* base = chunk[0]->d;
         u64* last = c_.dalloc<u64>((size_t)P * N);
         c_.stats.rescale += (u64)B;
+        c_.stats.rescale_limbs += (u64)B * ell;
         LimbBatch lb{last, P, nullptr, ell - 1, 1, base + (size_t)(ell - 1) * N};
         lb.src_group = 1;
         lb.src_group_stride = (size_t)ell * N;
@@ -656,6 +658,7 @@ std::vector<CtPtr> Evaluator::mult_plain_each(const std::vector<CtPtr>& vin, con
                  }
                  launch_ew_items(c_.dt, it, 0, f->ell, c_.stream);
                  c_.stats.ct_pt_mult += (u64)(hi - lo);
+                 c_.stats.ct_pt_limbs += (u64)(hi - lo) * f->ell;
              });
     launch_ok("mult_plain_each");
     return out;
@@ -918,6 +921,7 @@ CtPtr Evaluator::mult_plain(const CtPtr& a, const PtPtr& p) {
     CtPtr o = new_ct(x->npoly, x->ell, x->deg + 1, x->scale * enc->scale, x->slots);
     launch_ew_mul(c_.dt, o->d, x->d, enc->d, x->npoly * x->ell, x->ell, 0, x->ell, c_.stream);
     c_.stats.ct_pt_mult += 1;
+    c_.stats.ct_pt_limbs += (u64)x->ell;
     launch_ok("mult_plain");
     return o;
 }

@@ -13,10 +13,13 @@
  * Every arithmetic instruction runs in libfhelin_amd.so on the GPU; this header only marshals handles,
  * parses the reference's text files into its three packing layouts, and fits Chebyshev coefficients.
  *
- * Persistence: OpenFHE's cereal BINARY files are out of scope.  `generate_context(true)`
- * writes the parameter set and PRNG seed to ../<parameters_folder>/crypto-context.txt; key generation is
- * deterministic in that seed, so `load_context` + `load_bootstrapping_and_rotation_keys` regenerate
- * bit-identical keys.  Ciphertexts are saved in the engine's own little-endian limb format.
+ * Persistence: OpenFHE's cereal BINARY files are out of scope.  `generate_context(true)` writes the
+ * PUBLIC parameter set to ../<parameters_folder>/crypto-context.txt and — separately, like the reference's
+ * secret-key.txt (:80-86) — the client's 256-bit SECRET seed to ../<parameters_folder>/secret-key.txt.  All key material
+ * derives from that seed through a ChaCha20 stream, so `load_context` (which, like the reference :208-214, reads the
+ * secret key file) + `load_bootstrapping_and_rotation_keys` regenerate bit-identical keys.  Whoever holds secret-key.txt
+ * can decrypt: ship it to an evaluation server only where the reference would ship its own secret-key.txt (it does, for
+ * its debug prints).  Ciphertexts are saved in the engine's own little-endian limb format.
  */
 #ifndef FHELIN_FHECONTROLLER_SHIM_H
 #define FHELIN_FHECONTROLLER_SHIM_H
@@ -189,9 +192,21 @@ public:
             cerr << "Error serializing the crypto context in \"" << "../" + parameters_folder + "/crypto-context.txt" << "\"" << endl;
             exit(1);
         }
-        f << "fhelin-context 1\n" << p.log_n << ' ' << p.n_q << ' ' << p.first_bits << ' ' << p.scale_bits << ' ' << p.n_p << ' '
-          << p.special_bits << ' ' << p.dnum << ' ' << p.log_slots << ' ' << p.hamming << ' ' << p.seed << '\n';
+        f << "fhelin-context 2\n" << p.log_n << ' ' << p.n_q << ' ' << p.first_bits << ' ' << p.scale_bits << ' ' << p.n_p << ' '
+          << p.special_bits << ' ' << p.dnum << ' ' << p.log_slots << ' ' << p.hamming << '\n';
         cout << "Crypto Context have been serialized" << std::endl;
+        // the secret goes to its own file, as in the reference (:80-86)
+        uint8_t seed[32];
+        fhelin_shim::check(fhelin_ctx_secret_seed(context, seed), "Serialize(secret)");
+        ofstream sk("../" + parameters_folder + "/secret-key.txt", ios::out | ios::binary);
+        if (!sk.is_open()) {
+            cerr << "Error writing serialization of private key to secret-key.txt" << endl;
+            exit(1);
+        }
+        sk << "fhelin-secret-seed ";
+        for (int i = 0; i < 32; i++) sk << hex << setw(2) << setfill('0') << (int)seed[i];
+        sk << dec << '\n';
+        cout << "The secret key has been serialized." << std::endl;
     }
     void generate_context(int log_ring, int log_scale, int log_primes, int digits_hks, int cts_levels, int stc_levels, int relu_deg,
                           bool serialize = false) {
@@ -219,15 +234,30 @@ public:
         int ver = 0;
         fhelin_params p = default_params();
         f >> magic >> ver >> p.log_n >> p.n_q >> p.first_bits >> p.scale_bits >> p.n_p >> p.special_bits >> p.dnum >> p.log_slots >>
-            p.hamming >> p.seed;
-        if (!f || magic != "fhelin-context") {
+            p.hamming;
+        if (!f || magic != "fhelin-context" || ver != 2) {
             cerr << "Error reading serialization of the crypto context from crypto-context.txt" << endl;
             exit(1);
         }
+        ifstream sk("../" + parameters_folder + "/secret-key.txt", ios::in | ios::binary);
+        if (!sk.is_open()) {
+            cerr << "I cannot read serialization from ../" << parameters_folder << "/secret-key.txt" << endl;
+            exit(1);
+        }
+        string smagic, hexseed;
+        sk >> smagic >> hexseed;
+        uint8_t seed[32];
+        if (!sk || smagic != "fhelin-secret-seed" || hexseed.size() != 64) {
+            cerr << "Could not read secret key" << endl;
+            exit(1);
+        }
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)std::stoul(hexseed.substr(2 * i, 2), nullptr, 16);
         num_slots = 1 << 14;
         level_budget = {3, 3};
         circuit_depth = 12 + 14;  // the reference recomputes the depth without the +1 here (:226-230, quirk Q2)
-        create(p);
+        fhelin_ctx_destroy(context);
+        context = nullptr;
+        fhelin_shim::check(fhelin_ctx_create_seeded(&p, seed, &context), "GenCryptoContext");
         fhelin_shim::check(fhelin_keygen(context), "KeyGen");
         fhelin_shim::check(fhelin_gen_relin_key(context), "EvalMultKeyGen");
         if (verbose) cout << "CtoS: " << level_budget[0] << ", StoC: " << level_budget[1] << endl;
@@ -698,8 +728,8 @@ private:
         p.hamming = 192;
         const char* dev = std::getenv("FHELIN_DEVICE");
         p.device = dev ? std::atoi(dev) : 0;
-        const char* seed = std::getenv("FHELIN_SEED");
-        p.seed = seed ? std::strtoull(seed, nullptr, 10) : 20240112ull;
+        const char* seed = std::getenv("FHELIN_SEED");   // explicit deterministic TEST seed; default 0 = OS entropy
+        p.seed = seed ? std::strtoull(seed, nullptr, 10) : 0ull;
         return p;
     }
     void create(const fhelin_params& p) {

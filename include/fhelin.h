@@ -92,7 +92,8 @@ int fhelin_dev_download(fhelin_ctx* c, void* dst, const void* src, size_t bytes)
 int fhelin_ntt(fhelin_ctx* c, uint64_t* d_data, int32_t nvec, int32_t limb_first, int32_t limb_count, int32_t inverse);
 
 /* host-side operation counters since the last reset: [0] limb-NTTs, [1] key switches, [2] sum of live limbs over
- * key switches, [3] rescales, [4] ct x pt products, [5] bootstraps, [6] plaintext encodes */
+ * key switches, [3] rescales, [4] ct x pt products, [5] bootstraps, [6] plaintext encodes, and with cap >= 9:
+ * [7] sum of live limbs over rescales, [8] sum of live limbs over ct x pt products */
 int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset);
 
 /* instruction-rate probe (bench.py --micro): variant 0..7, see csrc/kernels_micro.hip */
@@ -153,6 +154,13 @@ int fhelin_rotate_sum(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const
  * transforms (:445) — one ModUp per term, inner products accumulated in QP, ONE ModDown per group of <= 7 terms */
 int fhelin_rotate_each_sum(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* indices, int32_t n, fhelin_ct** out);
 int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);                          /* ModReduce (implicit in :427/:431) */
+/* the leaf operations over n independent ciphertexts (the rows of the reference's matmul loops, :872,:888,:904,:918,
+ * :949,:963,:985,:1001) in one call: same results as n single calls, one launch set per chunk of rows of equal shape */
+int fhelin_rotate_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t index, fhelin_ct** outs);
+int fhelin_rescale_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** outs);
+int fhelin_mult_plain_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const fhelin_pt* p, fhelin_ct** outs);
+int fhelin_mult_batch(fhelin_ctx* c, const fhelin_ct* const* a, const fhelin_ct* const* b, int32_t n, fhelin_ct** outs);
+int fhelin_add_batch(fhelin_ctx* c, const fhelin_ct* const* a, const fhelin_ct* const* b, int32_t n, fhelin_ct** outs);
 int fhelin_level_reduce(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhelin_ct** out);
 
 /* ---- the same residue functions without scale/level bookkeeping (bit-exact parity vs oracle/) -- */

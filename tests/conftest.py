@@ -16,7 +16,7 @@ def pytest_configure(config):
 def _built_library():
     """The .so files are build artefacts (git-ignored): build them when a fresh checkout runs the tests first."""
     lib = os.path.join(ROOT, "fhe-linformer_amd", "libfhelin_amd.so")
-    drv = os.path.join(ROOT, "tests", "shim", "shim_driver")
+    drv = os.path.join(ROOT, "tests", "shim", "shim_forward")
     if not (os.path.exists(lib) and os.path.exists(drv)):
         import __graft_entry__
         __graft_entry__.build()

@@ -90,3 +90,30 @@ def test_special_prime_count_follows_openfhe_rule(fa, n_q, dnum, want):
         assert sum(np.log2(e.p.astype(np.float64))) >= widest
     finally:
         e.close()
+
+
+def test_client_generator_is_chacha20_rfc8439(fa):
+    """the client-side generator (secret keys, encryption randomness, key-switching noise) is the ChaCha20 stream:
+    RFC 8439 section 2.3.2 block-function test vector (key 00..1f, counter 1, nonce 00 00 00 09 00 00 00 4a 00 00 00 00)"""
+    lib = fa.load_library()
+    out = (C.c_uint8 * 64)()
+    key = (C.c_uint8 * 32)(*range(32))
+    assert lib.fhelin_prng_block(key, (0x09000000 << 32) | 1, 0x4A000000, out) == 0
+    want = bytes.fromhex("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+                         "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    assert bytes(out) == want
+    assert lib.fhelin_prng_block(key, 2, 0, out) == 0 and bytes(out) != want
+
+
+def test_default_seed_is_os_entropy_and_test_seed_is_deterministic(fa):
+    """seed 0 (the default) keys the generator with 256 bits of OS entropy: two contexts never share it; a non-zero seed is
+    the explicit deterministic test opt-in; an exported seed re-creates the same context (load_context path)"""
+    a, b = fa.Engine("toy", device=-1), fa.Engine("toy", device=-1)
+    sa, sb = a.secret_seed(), b.secret_seed()
+    assert len(sa) == 32 and sa != sb and sa != bytes(32)
+    c, d = fa.Engine("toy", device=-1, seed=7), fa.Engine("toy", device=-1, seed=7)
+    assert c.secret_seed() == d.secret_seed() == (7).to_bytes(8, "little") + bytes(24)
+    e = fa.Engine("toy", device=-1, seed_bytes=sa)
+    assert e.secret_seed() == sa
+    for x in (a, b, c, d, e):
+        x.close()

@@ -290,3 +290,31 @@ def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
             _same(o, r, "matmulRElarge")
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("preset,ell", [("toy13", 6), ("bench", 24)])
+def test_batched_leaf_ops_bit_exact(engine_factory, orc, preset, ell):
+    """the batched leaf entry points (fhelin_rotate_batch / rescale_batch / mult_plain_batch / mult_batch / add_batch:
+    rows of a matmul in one launch set; bench.py's op section times them) return the residues of the single ops"""
+    eng = engine_factory(preset)
+    keys = _keys(orc, eng, [5], seed=1500)
+    relin = _evk(orc, eng, 31)
+    eng.key_import(0, 0, relin)
+    rev = _rev(orc, eng, keys)
+    rows = [_imp(eng, rev, _ct(orc, eng, 900 + 11 * i, ell)) for i in range(3)]
+    cs, rs = [r[0] for r in rows], [r[1] for r in rows]
+    w = eng.encode(np.random.default_rng(1).uniform(-1, 1, 1 << eng.params.log_slots))
+    wenc = lambda e, sc: eng.pt_export(w, e, sc)
+    for got, r in zip(eng.rotate_batch(cs, 5), rs):
+        _same(got, rev.rotate(r, 5), "rotate_batch")
+    prods = eng.mult_plain_batch(cs, w)
+    rprods = [rev.mult_plain(r, wenc) for r in rs]
+    for got, r in zip(prods, rprods):
+        _same(got, r, "mult_plain_batch")
+    for got, r in zip(eng.rescale_batch(prods), rprods):
+        _same(got, rev.rescale(r), "rescale_batch")
+    for got, a, b in zip(eng.add_batch(cs, cs[1:] + cs[:1]), rs, rs[1:] + rs[:1]):
+        _same(got, rev.add(a, b), "add_batch")
+    for got, a, b in zip(eng.mult_batch(cs, cs[1:] + cs[:1]), rs, rs[1:] + rs[:1]):
+        want = orc.mult_relin(a.d, b.d, relin, eng.alpha, eng.q, eng.p, eng.psi_q, eng.psi_p)
+        assert got.info()["deg"] == 2 and np.array_equal(got.export(), want), "mult_batch"

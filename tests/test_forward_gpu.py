@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
     ("main", "reference", 28),       # src/main.cpp as built: CLS-query attention (BASELINE configs 2-3), the reference's 28+7 limbs
     ("main_2", "reference", 28),     # src/main_2.cpp: full attention over all S tokens
     ("main_2", "deep", 30),          # BASELINE config 5: N=2^17, 30+7 limbs, sparse (N/8) bootstrapping
+    ("main", "bench", 28),           # the headline configuration of bench.py: N=2^16, 28+7 limbs (alpha=7), sparse (N/4) packing
 ])
 def test_encrypted_forward_matches_plaintext_circuit(fa, variant, preset, n_q):
     from fhe_linformer_amd import linformer as lf

@@ -28,3 +28,27 @@ def test_shim_driver_builds():
                         "-o", out], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     assert os.path.exists(out)
+
+
+@pytest.mark.parametrize("driver", ["main.cpp", "main_2.cpp"])
+def test_reference_driver_links_and_starts(driver):
+    """beyond -fsyntax-only: the reference's drivers LINK unchanged against the shim + libfhelin_amd.so (recipe:
+    oracle/Makefile `ref`, outputs in oracle/_ref/) and the resulting binary starts (usage text, exit 0: no GPU touched)"""
+    if not os.path.exists(os.path.join(REF, driver)):
+        pytest.skip("reference tree not present")
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_" + driver[:-4])
+    assert os.path.exists(exe)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60, cwd=os.path.join(ROOT, "oracle", "_ref"))
+    assert r.returncode == 0 and "FHE-Linformer" in r.stdout
+    syms = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+    assert "fhelin_bootstrap" in syms and "fhelin_fc_matmulRElarge" in syms     # the engine is reached through the C ABI only
+
+
+def test_shim_forward_builds():
+    out = os.path.join(ROOT, "tests", "shim", "shim_forward")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "shim", "shim_forward.cpp"),
+                        "-L", os.path.join(ROOT, "fhe-linformer_amd"), "-lfhelin_amd", "-Wl,-rpath," + os.path.join(ROOT, "fhe-linformer_amd"),
+                        "-o", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]

@@ -60,3 +60,96 @@ def test_shim_driver_matches_slot_model(tmp_path, early_rescale):
     assert np.max(np.abs(_read(tmp_path / "cr.out") - cr)) < 1e-6
     lv = open(tmp_path / "levels.out").read().strip().split(",")
     assert lv[0] == ("1" if early_rescale == "1" else "0") and lv[3] == "1" and int(lv[1]) >= 1 and int(lv[2]) > int(lv[1])
+
+
+REF_MAIN = os.path.join(ROOT, "oracle", "_ref", "ref_main")
+FWD = os.path.join(ROOT, "tests", "shim", "shim_forward")
+
+
+def _write_model(root, w, x_in, X_E, X_F):
+    """synthetic weights / tokens in the files and formats the reference's drivers read (src/main.cpp:159-173,
+    :177-470; written like src/python/extract_parameters_numeric.py:28, split like split_ffn_w1.py / split_ffn_w2_cols.py)"""
+    from oracle.plain_forward import PFX
+    from fhe_linformer_amd import linformer as lf
+    wd = os.path.join(root, "weights-20NG")
+    for d in ("weights-20NG", "input", "tokens", "build"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    files = {
+        "cls_token.txt": x_in[0],
+        PFX + "selfAttn_WQ_weight_T.txt": w["WQ"].T, PFX + "selfAttn_WQ_bias.txt": w["BQ"],
+        PFX + "selfAttn_WK_weight_T.txt": w["WK"].T, PFX + "selfAttn_WK_bias.txt": w["BK"],
+        PFX + "selfAttn_WV_weight_T.txt": w["WV"].T, PFX + "selfAttn_WV_bias.txt": w["BV"],
+        PFX + "selfAttn_WO_weight.txt": w["WO"], PFX + "selfAttn_WO_bias.txt": w["BO"],
+        PFX + "ffn_affine1_a.txt": w["a1"], PFX + "ffn_affine1_b.txt": w["b1"],
+        PFX + "ffn_affine2_a.txt": w["a2"], PFX + "ffn_affine2_b.txt": w["b2"],
+        PFX + "ffn_Wffn_0_bias.txt": w["Bffn0"], PFX + "ffn_Wffn_2_bias.txt": w["Bffn2"],
+        "pooler_dense_weight_T.txt": w["Wp"].T, "pooler_dense_bias.txt": w["bp"],
+        "fcLinear_0_weight.txt": w["fc_w"],
+        "fcLinear_0_bias.txt": np.concatenate([w["fc_b"], np.zeros(108)]),   # the driver indexes 128 values (quirk Q12)
+    }
+    for i in (1, 2):
+        for j in range(3):
+            files[PFX + f"ffn_affine{i}_c{j}.txt"] = np.array([w[f"c{i}{j}"]])
+    for k, blk in enumerate(lf.split_transposed_blocks(w["Wffn0"])):
+        files[f"ffn_W0_transposed_block_{k}.txt"] = blk
+    for k, blk in enumerate(lf.split_col_blocks(w["Wffn2"])):
+        files[f"ffn_W2_block_{k}.txt"] = blk
+    for name, arr in files.items():
+        _write(os.path.join(wd, name), arr)
+    for i in range(32):
+        _write(os.path.join(root, "input", f"XE_{i}.txt"), X_E[i])
+        _write(os.path.join(root, "input", f"XF_{i}.txt"), X_F[i])
+    for i in range(1, x_in.shape[0]):
+        _write(os.path.join(root, "tokens", f"input_{i - 1}.txt"), x_in[i])
+
+
+def _run(cmd, cwd, timeout=900):
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fhe-linformer_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    env.pop("FHELIN_SEED", None)            # keys from OS entropy, persisted through ../keys/secret-key.txt
+    r = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (cmd, r.stdout[-3000:], r.stderr[-3000:])
+    return r.stdout
+
+
+@pytest.mark.parametrize("variant", ["main", "main_2"])
+def test_full_forward_through_cpp_shim_and_reference_binary(tmp_path, variant):
+    """The whole encoder1 -> pooler -> classifier sequence through include/FHEController.h in C++ (tests/shim/shim_forward.cpp:
+    every read_* layout, the shim's own Chebyshev fit, 8 bootstraps) at the reference's parameters, against the clear-text
+    circuit (oracle/circuit_sim.py, tolerances of tests/test_forward_gpu.py).  Where the reference tree was available at
+    build time, the reference's OWN main.cpp — compiled unchanged against the shim (oracle/_ref/ref_main) — generates the
+    keys (`--generate_keys`) and afterwards resumes from the encoder checkpoint this driver saved (main.cpp:105-110) to run
+    pooler + classifier itself: its printed softmax must match."""
+    from fhe_linformer_amd import linformer as lf
+    from oracle import plain_forward as pf, circuit_sim as cs
+    assert os.path.exists(FWD), "tests/shim/shim_forward missing: run __graft_entry__.build()"
+    S = 129
+    w = pf.synthetic_model(1234)
+    x_in, X_E, X_F = pf.client_inputs(w, pf.synthetic_tokens(S, 4321))
+    root = str(tmp_path)
+    _write_model(root, w, x_in, X_E, X_F)
+    build = os.path.join(root, "build")
+    have_ref = os.path.exists(REF_MAIN) and variant == "main"
+    if have_ref:
+        _run([REF_MAIN, "--generate_keys"], build)                       # the reference binary writes ../keys
+        _run([FWD, root, variant], build)
+    else:
+        _run([FWD, root, variant, "generate"], build)
+    assert open(os.path.join(root, "keys", "crypto-context.txt")).read().startswith("fhelin-context 2")
+    assert "seed" not in open(os.path.join(root, "keys", "crypto-context.txt")).read()
+    sim, st = cs.SlotSimController(), {}
+    ref = lf.forward(sim, w, x_in, X_E, X_F, st, variant)
+    tol = {"scores": 5e-8, "exp": 5e-8, "self_attention": 5e-8, "affine1_0": 5e-8, "encoder_out": 1e-4, "pooled": 5e-3}
+    for k, t in tol.items():
+        err = np.max(np.abs(_read(os.path.join(root, "out", k + ".out")) - st[k]))
+        assert err < t, (k, err)
+    lg, lr = lf.logits_from_slots(_read(os.path.join(root, "out", "logits.out"))), lf.logits_from_slots(ref)
+    assert np.max(np.abs(lg - lr)) < 2e-2 and int(np.argmax(lg)) == int(np.argmax(lr))
+    meta = open(os.path.join(root, "out", "meta.out")).read().strip().split(",")
+    assert int(meta[0]) == 8                                             # bootstraps: 2 + 5 + 1
+    if have_ref:
+        out = _run([REF_MAIN, "--verbose"], build)                       # load keys + checkpoint, pooler, classifier
+        probs = np.array([float(l.split(":")[1]) for l in out.splitlines() if l.startswith("Softmax Prob:")])
+        pred = [int(l.split(":")[1]) for l in out.splitlines() if l.startswith("Pred:")]
+        e = np.exp(lg - lg.max())
+        assert probs.shape == (20,) and np.max(np.abs(probs - e / e.sum())) < 5e-3
+        assert pred == [int(np.argmax(lg))]
