@@ -75,6 +75,7 @@ def load_library():
         "fhelin_ctx_roots": (i32, [vp, u64p, i32]),
         "fhelin_ctx_scaling_factors": (i32, [vp, C.POINTER(C.c_double), i32]),
         "fhelin_ctx_set_stream": (i32, [vp, vp]),
+        "fhelin_ctx_set_lazy_rows": (i32, [vp, i32]),
         "fhelin_sync": (i32, [vp]),
         "fhelin_timer_start": (i32, [vp]),
         "fhelin_timer_stop": (i32, [vp, f32p]),
@@ -238,6 +239,10 @@ class Engine:
     def _ck(self, rc):
         if rc != 0:
             raise FhelinError(rc, self.lib.fhelin_last_error().decode())
+
+    def set_lazy_rows(self, on):
+        """deferred evaluation of the rows of matmul_pt / unwrapExpanded (default on)"""
+        self._ck(self.lib.fhelin_ctx_set_lazy_rows(self.h, 1 if on else 0))
 
     def secret_seed(self):
         out = (C.c_uint8 * 32)()

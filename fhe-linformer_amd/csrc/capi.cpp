@@ -1,6 +1,7 @@
 // extern "C" boundary: translates C++ exceptions into status codes, owns nothing but handles.
 #include "../../include/fhelin.h"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include "context.h"
@@ -16,6 +17,10 @@ int capi_fail(int code, const std::string& msg) {
     return code;
 }
 }  // namespace fhelin
+
+fhelin_ctx::fhelin_ctx(const fhelin::Params& p) : ctx(p), ev(ctx), cl(ev, ctx.prm.seed_bytes), comp(ev, cl), boot(ev, cl) {
+    if (const char* e = std::getenv("FHELIN_LAZY_ROWS")) lazy_rows = std::atoi(e) != 0;
+}
 
 extern "C" {
 
@@ -114,6 +119,12 @@ int fhelin_ctx_set_stream(fhelin_ctx* c, void* hip_stream) {
     c->ctx.stream = c->ctx.main_stream = (hipStream_t)hip_stream;
     c->ctx.own_stream = false;
     FHELIN_CATCH
+}
+
+int fhelin_ctx_set_lazy_rows(fhelin_ctx* c, int32_t on) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    c->lazy_rows = on != 0;
+    return FHELIN_OK;
 }
 
 int fhelin_sync(fhelin_ctx* c) {

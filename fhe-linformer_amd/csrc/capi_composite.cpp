@@ -1,5 +1,6 @@
 // extern "C" boundary, part 3: one entry point per FHEController composite method.
 #include "../../include/fhelin.h"
+#include <algorithm>
 #include "capi_internal.h"
 
 using namespace fhelin;
@@ -12,13 +13,60 @@ static fhelin_ct* wrap(const CtPtr& p) {
     return h;
 }
 static CtVec vec_of(fhelin_ctx* c, const fhelin_ct* const* v, int n) {
-    CtVec out;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext handle in array");
-        out.push_back(ct_in(c, v[i]));
-    }
+    force_many(c, v, n);
+    CtVec out;
+    for (int i = 0; i < n; ++i) out.push_back(ct_in(c, v[i]));
     return out;
 }
+// handles to the rows of a deferred group
+static void emit_lazy(fhelin_ctx* c, const std::shared_ptr<LazyRows>& g, int n, fhelin_ct** outs) {
+    g->done.assign(n, CtPtr());
+    for (int i = 0; i < n; ++i) {
+        auto* h = new fhelin_ct;
+        h->lazy = g;
+        h->lazy_idx = i;
+        h->owner = c;
+        outs[i] = h;
+    }
+}
+
+namespace fhelin {
+void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx) {
+    std::vector<int> todo;
+    for (int i : idx)
+        if (!g.done[i]) todo.push_back(i);
+    if (todo.empty()) return;
+    CtVec r;
+    if (g.kind == LazyRows::MatmulPt) {
+        CtVec sub;
+        for (int i : todo) sub.push_back(g.rows[i]);
+        r = c->comp.matmul_pt(sub, g.w, g.bias, g.slots, g.padding);
+    } else {
+        r = c->comp.unwrapExpanded_rows(g.src, g.n, todo);
+    }
+    for (size_t k = 0; k < todo.size(); ++k) g.done[todo[k]] = r[k];
+    bool all = true;
+    for (const CtPtr& d : g.done) all = all && d;
+    if (all) {  // nothing left to evaluate: release the inputs
+        g.rows.clear();
+        g.src.reset();
+    }
+}
+void force_many(fhelin_ctx* c, const fhelin_ct* const* v, int n) {
+    std::vector<std::pair<LazyRows*, std::vector<int>>> groups;
+    for (int i = 0; i < n; ++i) {
+        const fhelin_ct* h = v[i];
+        if (!h || h->p || !h->lazy) continue;
+        LazyRows* g = h->lazy.get();
+        auto it = std::find_if(groups.begin(), groups.end(), [&](const auto& e) { return e.first == g; });
+        if (it == groups.end()) it = groups.insert(groups.end(), {g, {}});
+        if (std::find(it->second.begin(), it->second.end(), h->lazy_idx) == it->second.end()) it->second.push_back(h->lazy_idx);
+    }
+    for (auto& e : groups) force_rows(c, *e.first, e.second);
+}
+}  // namespace fhelin
 static void emit(const CtVec& v, fhelin_ct** outs) {
     for (size_t i = 0; i < v.size(); ++i) outs[i] = wrap(v[i]);
 }
@@ -97,7 +145,18 @@ int fhelin_fc_matmul_pt(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, 
                         int32_t slots, int32_t padding, fhelin_ct** outs) {
     NEED(c && rows && w && outs);
     FHELIN_TRY
-    emit(c->comp.matmul_pt(vec_of(c, rows, n), w->p, opt(bias), slots, padding), outs);
+    if (c->lazy_rows && n > 1) {
+        auto g = std::make_shared<LazyRows>();
+        g->kind = LazyRows::MatmulPt;
+        g->rows = vec_of(c, rows, n);
+        g->w = w->p;
+        g->bias = opt(bias);
+        g->slots = slots;
+        g->padding = padding;
+        emit_lazy(c, g, n, outs);
+    } else {
+        emit(c->comp.matmul_pt(vec_of(c, rows, n), w->p, opt(bias), slots, padding), outs);
+    }
     FHELIN_CATCH
 }
 int fhelin_fc_matmul_ct(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_ct* w, int32_t slots,
@@ -154,7 +213,15 @@ int fhelin_fc_wrapUpExpanded(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n
 int fhelin_fc_unwrapExpanded(fhelin_ctx* c, const fhelin_ct* a, int32_t n, fhelin_ct** outs) {
     NEED(c && a && outs);
     FHELIN_TRY
-    emit(c->comp.unwrapExpanded(ct_in(c, a), n), outs);
+    if (c->lazy_rows && n > 1) {
+        auto g = std::make_shared<LazyRows>();
+        g->kind = LazyRows::UnwrapExpanded;
+        g->src = ct_in(c, a);
+        g->n = n;
+        emit_lazy(c, g, n, outs);
+    } else {
+        emit(c->comp.unwrapExpanded(ct_in(c, a), n), outs);
+    }
     FHELIN_CATCH
 }
 int fhelin_fc_unwrapScoresExpanded(fhelin_ctx* c, const fhelin_ct* a, int32_t n, fhelin_ct** outs) {

@@ -131,13 +131,23 @@ int fhelin_ct_import(fhelin_ctx* c, const uint64_t* limbs, int32_t npoly, int32_
 int fhelin_ct_export(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* out, size_t cap) {
     NEED(c && ct && out);
     FHELIN_TRY
-    if (cap < ct->p->words()) throw Error(FHELIN_ERR_ARG, "buffer too small");
-    hip_check(hipMemcpyAsync(out, ct_in(c, ct)->d, ct->p->words() * 8, hipMemcpyDeviceToHost, c->ctx.stream), "ct export");
+    const CtPtr& p = ct_in(c, ct);
+    if (cap < p->words()) throw Error(FHELIN_ERR_ARG, "buffer too small");
+    hip_check(hipMemcpyAsync(out, p->d, p->words() * 8, hipMemcpyDeviceToHost, c->ctx.stream), "ct export");
     c->ctx.sync();
     FHELIN_CATCH
 }
 int fhelin_ct_info(const fhelin_ct* ct, int32_t* npoly, int32_t* ell, int32_t* level, int32_t* deg, double* scale, int32_t* slots) {
     NEED(ct);
+    if (!ct->p && ct->lazy) {  // a deferred row: its shape is known only once evaluated
+        try {
+            force(ct->owner, ct);
+        } catch (const fhelin::Error& e) {
+            return capi_fail(e.code, e.what());
+        } catch (const std::exception& e) {
+            return capi_fail(FHELIN_ERR_INTERNAL, e.what());
+        }
+    }
     if (npoly) *npoly = ct->p->npoly;
     if (ell) *ell = ct->p->ell;
     if (level) *level = ct->p->level();
@@ -202,10 +212,10 @@ int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* 
     NEED(c && v && indices && outs && n >= 0);
     FHELIN_TRY
     std::vector<CtPtr> in;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext in array");
-        in.push_back(ct_in(c, v[i]));
-    }
+    force_many(c, v, n);
+    for (int i = 0; i < n; ++i) in.push_back(ct_in(c, v[i]));
     std::vector<CtPtr> r = c->ev.rotate_each(in, std::vector<int>(indices, indices + n));
     for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
     FHELIN_CATCH
@@ -214,10 +224,10 @@ int fhelin_rotate_sum(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const
     NEED(c && v && indices && outs && n >= 0 && n_rot >= 1);
     FHELIN_TRY
     std::vector<CtPtr> in;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext in array");
-        in.push_back(ct_in(c, v[i]));
-    }
+    force_many(c, v, n);
+    for (int i = 0; i < n; ++i) in.push_back(ct_in(c, v[i]));
     std::vector<CtPtr> r = c->ev.rotate_sum_batch(in, std::vector<int>(indices, indices + n_rot));
     for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
     FHELIN_CATCH
@@ -226,10 +236,10 @@ int fhelin_rotate_each_sum(fhelin_ctx* c, const fhelin_ct* const* v, const int32
     NEED(c && v && indices && out && n >= 1);
     FHELIN_TRY
     std::vector<CtPtr> in;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext in array");
-        in.push_back(ct_in(c, v[i]));
-    }
+    force_many(c, v, n);
+    for (int i = 0; i < n; ++i) in.push_back(ct_in(c, v[i]));
     *out = wrap(c->ev.rotate_each_sum(in, std::vector<int>(indices, indices + n)));
     FHELIN_CATCH
 }
@@ -242,7 +252,8 @@ int fhelin_raw_modraise(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhel
 int fhelin_raw_phase(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->cl.phase(ct_in(c, a), a->p->ell));
+    const CtPtr& p = ct_in(c, a);
+    *out = wrap(c->cl.phase(p, p->ell));
     FHELIN_CATCH
 }
 int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {

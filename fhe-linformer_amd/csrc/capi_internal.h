@@ -15,10 +15,32 @@ struct fhelin_ctx {
     fhelin::Client cl;
     fhelin::Composite comp;
     fhelin::Bootstrapper boot;
-    explicit fhelin_ctx(const fhelin::Params& p) : ctx(p), ev(ctx), cl(ev, ctx.prm.seed_bytes), comp(ev, cl), boot(ev, cl) {}
+    bool lazy_rows = true;      // FHELIN_LAZY_ROWS
+    explicit fhelin_ctx(const fhelin::Params& p);
 };
+// Rows of a batched composite whose evaluation is DEFERRED until a row is consumed (fhelin_fc_matmul_pt,
+// fhelin_fc_unwrapExpanded): the reference's drivers compute whole row sets of which later code reads a single row
+// (src/main.cpp:183,:196 — all S query projections, only Q[0] used; :416-424 — all S tokens expanded, only output_2[0]
+// used).  A row is evaluated the first time a handle to it is read — together with every other
+// deferred row of the same call that the consuming operation also takes — and never if nobody reads it.  Rows are
+// independent, so a forced row holds exactly the residues eager evaluation gives (bit-exact tests run with deferral
+// on).  FHELIN_LAZY_ROWS=0 evaluates eagerly.
+namespace fhelin {
+struct LazyRows {
+    enum Kind { MatmulPt, UnwrapExpanded } kind = MatmulPt;
+    CtVec rows;                 // MatmulPt: the input rows (kept alive)
+    PtPtr w, bias;
+    int slots = 0, padding = 0;
+    CtPtr src;                  // UnwrapExpanded: the wrapped ciphertext
+    int n = 0;
+    std::vector<CtPtr> done;    // per row: null until evaluated
+};
+}
 struct fhelin_ct {
-    fhelin::CtPtr p;
+    mutable fhelin::CtPtr p;                          // null while the row is still deferred
+    mutable std::shared_ptr<fhelin::LazyRows> lazy;
+    int lazy_idx = 0;
+    fhelin_ctx* owner = nullptr;
 };
 struct fhelin_pt {
     fhelin::PtPtr p;
@@ -26,10 +48,21 @@ struct fhelin_pt {
 
 namespace fhelin {
 int capi_fail(int code, const std::string& msg);
+// evaluate the listed rows of a deferred group in ONE batched call (capi_composite.cpp)
+void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx);
+inline void force(fhelin_ctx* c, const fhelin_ct* h) {
+    if (h->p || !h->lazy) return;
+    if (!h->lazy->done[h->lazy_idx]) force_rows(c, *h->lazy, std::vector<int>{h->lazy_idx});
+    h->p = h->lazy->done[h->lazy_idx];
+    h->lazy.reset();
+}
+// the deferred rows among v[0..n) are evaluated together, one batched call per group
+void force_many(fhelin_ctx* c, const fhelin_ct* const* v, int n);
 
 // The main stream is about to consume `h`: if a worker lane is still producing it, order the main stream behind the
 // producing op (no host wait) and drop the holds that op needed.
 inline const CtPtr& ct_in(fhelin_ctx* c, const fhelin_ct* h) {
+    force(c, h);
     Ciphertext& ct = *h->p;
     if (ct.async_pending) {
         Context& x = c->ctx;
@@ -47,6 +80,7 @@ inline const CtPtr& ct_in(fhelin_ctx* c, const fhelin_ct* h) {
 template <class F>
 CtPtr run_heavy(fhelin_ctx* c, const fhelin_ct* in, F&& f) {
     Context& x = c->ctx;
+    force(c, in);               // a deferred input is evaluated on the main stream, before the lane is entered
     if (x.n_lanes < 2 || !x.async_lanes || x.stream != x.main_stream) return f(ct_in(c, in));
     Ciphertext& ci = *in->p;
     const int k = ci.async_pending ? ci.async_lane : 1 + (x.async_rr++ % x.n_lanes);

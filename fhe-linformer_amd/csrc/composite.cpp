@@ -348,6 +348,42 @@ CtVec Composite::unwrapExpanded(CtPtr c, int n) {
     return repeat_batch(ev_.mult_plain_batch(shift_fan(c, n, 1), mod_n_mask(128, 0)), 128, 1);
 }
 
+CtVec Composite::unwrapExpanded_rows(CtPtr c, int n, const std::vector<int>& idx) {
+    if ((int)idx.size() == n) {
+        bool identity = true;
+        for (int i = 0; i < n; ++i) identity = identity && idx[i] == i;
+        if (identity) return unwrapExpanded(c, n);
+    }
+    // shift_fan builds rot(c, i) as rot(rot(c, i - 2^h), 2^h), h = highest set bit of i: the needed rows and their prefixes
+    std::map<int, CtPtr> fan;
+    fan[0] = c;
+    std::vector<char> need(std::max(n, 1), 0);
+    for (int i : idx) {
+        if (i < 0 || i >= n) throw Error(FHELIN_ERR_ARG, "unwrapExpanded_rows: row out of range");
+        for (int j = i; j > 0;) {
+            need[j] = 1;
+            int h = 0;
+            while ((2 << h) <= j) ++h;
+            j -= 1 << h;
+        }
+    }
+    for (int have = 1; have < n; have *= 2) {
+        CtVec src;
+        std::vector<int> dst;
+        for (int j = have; j < std::min(2 * have, n); ++j)
+            if (need[j]) {
+                src.push_back(fan.at(j - have));
+                dst.push_back(j);
+            }
+        if (src.empty()) continue;
+        CtVec rot = ev_.rotate_batch(src, have);
+        for (size_t k = 0; k < dst.size(); ++k) fan[dst[k]] = rot[k];
+    }
+    CtVec sel;
+    for (int i : idx) sel.push_back(fan.at(i));
+    return repeat_batch(ev_.mult_plain_batch(sel, mod_n_mask(128, 0)), 128, 1);
+}
+
 CtVec Composite::unwrapScoresExpanded(CtPtr c, int n) {
     const CtVec fan = shift_fan(c, n, 1);
     CtVec a = repeat_batch(ev_.mult_plain_batch(fan, mod_n_mask(128, 0)), 64, 1);

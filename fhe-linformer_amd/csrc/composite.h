@@ -60,6 +60,9 @@ public:
     CtPtr wrapUpRepeated(const CtVec& v);
     CtPtr wrapUpExpanded(const CtVec& v);
     CtVec unwrapExpanded(CtPtr c, int inputs_num);
+    // the rows `idx` of unwrapExpanded(c, inputs_num) only, each with the residues the full call gives (the rotation
+    // chain of row i is that of shift_fan: the set bits of i in ascending order)
+    CtVec unwrapExpanded_rows(CtPtr c, int inputs_num, const std::vector<int>& idx);
     CtVec unwrapScoresExpanded(CtPtr c, int inputs_num);
     CtVec unwrap_512_in_4_128(const CtPtr& c, int index);
     std::vector<CtVec> unwrapRepeatedLarge(const CtVec& containers, int input_number);

@@ -76,6 +76,11 @@ int fhelin_ctx_moduli(const fhelin_ctx* c, uint64_t* out, int32_t cap);         
 int fhelin_ctx_roots(const fhelin_ctx* c, uint64_t* out, int32_t cap);           /* psi per limb */
 int fhelin_ctx_scaling_factors(const fhelin_ctx* c, double* out, int32_t cap);   /* real Delta per level */
 int fhelin_ctx_set_stream(fhelin_ctx* c, void* hip_stream);                      /* adopt a caller stream */
+/* Deferred rows (default on; FHELIN_LAZY_ROWS=0 or on = 0 here: eager).  fhelin_fc_matmul_pt and fhelin_fc_unwrapExpanded
+ * return handles whose rows are evaluated when first read (together with the other rows of the same call the reading
+ * operation takes) and never if nobody reads them: the reference's drivers compute whole row sets and then use one row
+ * (src/main.cpp:183,:196; :416-424).  A forced row holds exactly the residues eager evaluation gives. */
+int fhelin_ctx_set_lazy_rows(fhelin_ctx* c, int32_t on);
 int fhelin_sync(fhelin_ctx* c);
 /* HIP-event timer on the context's stream (bench.py measures kernel time with these) */
 int fhelin_timer_start(fhelin_ctx* c);

@@ -27,6 +27,15 @@ def _built_library():
 def orc():
     import oracle
     oracle.lib()
+    # OpenMP sees every core of the host, the cgroup grants fewer: dynamic schedules over more threads than CPUs crawl
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cpus = min(cpus, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    oracle.set_threads(min(cpus, 16))
     return oracle
 
 

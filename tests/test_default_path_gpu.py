@@ -318,3 +318,47 @@ def test_batched_leaf_ops_bit_exact(engine_factory, orc, preset, ell):
     for got, a, b in zip(eng.mult_batch(cs, cs[1:] + cs[:1]), rs, rs[1:] + rs[:1]):
         want = orc.mult_relin(a.d, b.d, relin, eng.alpha, eng.q, eng.p, eng.psi_q, eng.psi_p)
         assert got.info()["deg"] == 2 and np.array_equal(got.export(), want), "mult_batch"
+
+
+def test_deferred_rows_match_eager_and_skip_dead_rows(fa, orc):
+    """fhelin_fc_matmul_pt / fhelin_fc_unwrapExpanded return deferred rows: whatever subset is read, in whatever order,
+    every row holds the residues of the eager call; rows nobody reads are never evaluated (no key switch is counted)"""
+    eng = fa.Engine("reference", seed=3, n_q=6, n_p=2, dnum=3)
+    try:
+        need = set()
+        for u in (128, 512, 2048, -1, -4, -16):
+            need.update((u, 2 * u, 3 * u))
+        need.update((8192, -64, 1, 2, 4))
+        _keys(orc, eng, sorted(need), seed=100)
+        rng = np.random.default_rng(4)
+        ns = 16384
+        w, b = eng.encode(rng.uniform(-1, 1, ns) / 8), eng.encode(rng.uniform(-1, 1, ns))
+        rows = [eng.ct_import(_ct(orc, eng, 500 + i, 6)) for i in range(6)]
+        eng.set_lazy_rows(False)
+        eager = [o.export() for o in eng.matmulRE(rows, w, b)]
+        src = eng.mult(rows[0], w)
+        eager_un = [o.export() for o in eng.unwrapExpanded(src, 6)]
+        eng.set_lazy_rows(True)
+        eng.sync()
+        eng.stats(reset=True)
+        lazy = eng.matmulRE(rows, w, b)
+        assert eng.stats()["keyswitch"] == 0                           # nothing evaluated yet
+        assert np.array_equal(lazy[4].export(), eager[4])              # one row alone
+        assert eng.stats()["keyswitch"] == 7                           # one rotate-and-sum tree (7 steps), not six
+        s = eng.add(lazy[1], lazy[2])                                  # a consumer of two rows of the group
+        want = eng.add(eng.ct_import(eager[1]), eng.ct_import(eager[2])).export()
+        assert np.array_equal(s.export(), want)
+        assert eng.stats()["keyswitch"] == 21
+        assert lazy[0].info()["ell"] == 5                              # GetLevel() on a deferred row evaluates it
+        for i in (0, 3, 5):
+            assert np.array_equal(lazy[i].export(), eager[i])
+        un = eng.unwrapExpanded(src, 6)
+        for i in (5, 0, 3):                                            # odd order; row 5 needs rot(rot(c,1),4)
+            assert np.array_equal(un[i].export(), eager_un[i]), i
+        before = eng.stats()["keyswitch"]
+        dead = eng.matmulRE(rows, w, b)                                # never read
+        del dead
+        eng.sync()
+        assert eng.stats()["keyswitch"] == before
+    finally:
+        eng.close()
