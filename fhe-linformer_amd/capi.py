@@ -48,7 +48,8 @@ def circuit_rotation_indices():
 
 
 def library_path():
-    return os.path.join(_HERE, "libfhelin_amd.so")
+    # FHELIN_LIB: an alternative build of the same library (A/B measurements of kernel variants: tools/build_variant.sh)
+    return os.environ.get("FHELIN_LIB") or os.path.join(_HERE, "libfhelin_amd.so")
 
 
 def load_library():
@@ -101,6 +102,9 @@ def load_library():
         "fhelin_raw_modraise": (i32, [vp, vp, i32, C.POINTER(vp)]),
         "fhelin_raw_phase": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_encrypt": (i32, [vp, vp, C.POINTER(vp)]),
+        "fhelin_encrypt_batch": (i32, [vp, C.POINTER(C.c_double), i32, i32, i32, i32, C.POINTER(vp)]),
+        "fhelin_ctx_set_host_encode": (i32, [vp, i32]),
+        "fhelin_debug_sample": (i32, [vp, i32, i32, vp, C.c_size_t]),
         "fhelin_decrypt": (i32, [vp, vp, C.POINTER(C.c_double), i32]),
         "fhelin_ct_import": (i32, [vp, vp, i32, i32, i32, C.c_double, i32, C.POINTER(vp)]),
         "fhelin_ct_export": (i32, [vp, vp, vp, C.c_size_t]),
@@ -345,6 +349,22 @@ class Engine:
         h = C.c_void_p()
         self._ck(self.lib.fhelin_encrypt(self.h, pt.h, C.byref(h)))
         return Ct(self, h)
+
+    def encrypt_batch(self, rows, level=0, slots=0):
+        """rows [n_vec][n_per] -> n_vec fresh ciphertexts: encode + sample + combine as batched GPU kernels"""
+        a = np.ascontiguousarray(rows, dtype=np.float64)
+        assert a.ndim == 2
+        outs = self._outs(a.shape[0])
+        self._ck(self.lib.fhelin_encrypt_batch(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[0], a.shape[1], level, slots, outs))
+        return self._cts(outs, a.shape[0])
+
+    def set_host_encode(self, on):
+        self._ck(self.lib.fhelin_ctx_set_host_encode(self.h, 1 if on else 0))
+
+    def debug_sample(self, kind, n_poly=1):
+        out = np.empty((n_poly, self.N), dtype=np.int64)
+        self._ck(self.lib.fhelin_debug_sample(self.h, kind, n_poly, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
 
     def decrypt(self, ct, slots=0):
         n = slots or ct.slots or (1 << self.params.log_slots)

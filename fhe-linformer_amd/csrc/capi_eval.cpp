@@ -111,6 +111,26 @@ int fhelin_encrypt(fhelin_ctx* c, const fhelin_pt* p, fhelin_ct** out) {
     *out = wrap(c->cl.encrypt(p->p));
     FHELIN_CATCH
 }
+int fhelin_encrypt_batch(fhelin_ctx* c, const double* vals, int32_t n_vec, int32_t n_per, int32_t level, int32_t slots, fhelin_ct** outs) {
+    NEED(c && (vals || n_vec == 0) && outs);
+    FHELIN_TRY
+    std::vector<CtPtr> r = c->cl.encrypt_batch(vals, n_vec, n_per, level, slots);
+    for (int i = 0; i < n_vec; ++i) outs[i] = wrap(r[i]);
+    FHELIN_CATCH
+}
+int fhelin_ctx_set_host_encode(fhelin_ctx* c, int32_t on) {
+    NEED(c);
+    c->ctx.host_encode = on != 0;
+    return FHELIN_OK;
+}
+int fhelin_debug_sample(fhelin_ctx* c, int32_t kind, int32_t n_poly, int64_t* out, size_t cap) {
+    NEED(c && out);
+    FHELIN_TRY
+    if (n_poly < 1 || cap < (size_t)n_poly * c->ctx.N) throw Error(FHELIN_ERR_ARG, "debug_sample: buffer too small");
+    std::vector<long> v = c->cl.debug_sample(kind, n_poly);
+    for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    FHELIN_CATCH
+}
 int fhelin_decrypt(fhelin_ctx* c, const fhelin_ct* ct, double* out, int32_t slots) {
     NEED(c && ct && out);
     FHELIN_TRY

@@ -200,11 +200,67 @@ static void ld_to_i128(long double v, u64& lo, u64& hi) {
     hi = h;
 }
 
+static const Context::FftDev& fft_dev_tables(Context& c, int slots) {
+    auto it = c.fft_dev.find(slots);
+    if (it != c.fft_dev.end()) return it->second;
+    const FftTables& t = fft_tables(slots);
+    std::vector<double> k(2 * t.ksi.size());
+    for (size_t i = 0; i < t.ksi.size(); ++i) {
+        k[2 * i] = t.ksi[i].real();
+        k[2 * i + 1] = t.ksi[i].imag();
+    }
+    Context::FftDev d;
+    d.rot = c.upload_table(t.rot);
+    d.ksi = c.upload_table(k);
+    return c.fft_dev.emplace(slots, d).first->second;
+}
+
+void encode_batch_device(Context& c, u64* dst, const double* re, const double* im, int n_vec, int n_per, int slots, int ell, long double scale) {
+    c.require_device();
+    if (slots < 2 || (slots & (slots - 1)) || slots > c.N / 2) throw Error(FHELIN_ERR_ARG, "encode: slots must be a power of two in [2, N/2]");
+    if (ell < 1 || ell > c.L + 1) throw Error(FHELIN_ERR_ARG, "encode: level out of range");
+    if (n_vec < 1) return;
+    const Context::FftDev& tab = fft_dev_tables(c, slots);
+    const size_t words = (size_t)2 * slots;                 // one complex vector, in doubles
+    double* dv = reinterpret_cast<double*>(c.dalloc<u64>(words * n_vec));
+    std::vector<u64> host(words);
+    for (int b = 0; b < n_vec; ++b) {                       // through the pinned staging ring: no stream drain
+        double* h = reinterpret_cast<double*>(host.data());
+        for (int i = 0; i < slots; ++i) {
+            h[2 * i] = i < n_per ? re[(size_t)b * n_per + i] : 0.0;
+            h[2 * i + 1] = (im && i < n_per) ? im[(size_t)b * n_per + i] : 0.0;
+        }
+        c.upload_async(reinterpret_cast<u64*>(dv) + words * b, host.data(), words);
+    }
+    launch_fft_special_inv(dv, tab.rot, tab.ksi, slots, n_vec, c.stream);
+    // scale = mant * 2^exp with a 64-bit significand, exactly (the host code multiplies in x87 extended precision)
+    int e2 = 0;
+    const long double m = frexpl(scale, &e2);               // scale = m * 2^e2, m in [0.5, 1)
+    const u64 mant = (u64)ldexpl(m, 64);
+    launch_encode_round_reduce(c.dt, dst, dv, slots, ell, mant, e2 - 64, n_vec, c.stream);
+    c.stats.encode += (u64)n_vec;
+    c.ntt(LimbBatch{dst, n_vec * ell, nullptr, 0, ell}, false);
+    hip_check(hipGetLastError(), "encode kernels (device)");
+    c.pool.free(dv);
+}
+
 std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>& values, const std::vector<double>& imag, int slots,
                                            int ell, long double scale) {
     c.require_device();
     if (slots < 1 || (slots & (slots - 1)) || slots > c.N / 2) throw Error(FHELIN_ERR_ARG, "encode: slots must be a power of two <= N/2");
     if (ell < 1 || ell > c.L + 1) throw Error(FHELIN_ERR_ARG, "encode: level out of range");
+    if (!c.host_encode && slots >= 2) {
+        auto e = std::make_shared<Encoding>();
+        e->ctx = &c;
+        e->ell = ell;
+        e->scale = scale;
+        e->d = c.dalloc<u64>((size_t)ell * c.N);
+        std::vector<double> re(slots, 0.0), im(slots, 0.0);
+        for (int i = 0; i < slots && i < (int)values.size(); ++i) re[i] = values[i];
+        for (int i = 0; i < slots && i < (int)imag.size(); ++i) im[i] = imag[i];
+        encode_batch_device(c, e->d, re.data(), imag.empty() ? nullptr : im.data(), 1, slots, slots, ell, scale);
+        return e;
+    }
     std::vector<std::pair<double, double>> v(slots, {0.0, 0.0});
     for (int i = 0; i < slots && i < (int)values.size(); ++i) v[i].first = values[i];
     for (int i = 0; i < slots && i < (int)imag.size(); ++i) v[i].second = imag[i];
@@ -402,26 +458,75 @@ PtPtr Client::encode(const double* vals, int n, int level, int slots) {
     return p;
 }
 
+void Client::sample_small_device(u64* dst, int n_poly, int ell, int kind) {
+    SamplerKey key;   // a fresh ChaCha20 key per call, drawn from the client's own (secret-seeded) stream
+    for (int i = 0; i < 4; ++i) {
+        const u64 w = rng_.next();
+        key.w[2 * i] = (u32)w;
+        key.w[2 * i + 1] = (u32)(w >> 32);
+    }
+    launch_sample_small(c_.dt, dst, key, (sample_calls_++) << 32, kind, ell, n_poly, c_.stream);
+}
+
+std::vector<long> Client::debug_sample(int kind, int n_poly) {
+    c_.require_device();
+    const size_t N = c_.N;
+    u64* d = c_.dalloc<u64>((size_t)n_poly * N);
+    sample_small_device(d, n_poly, 1, kind);
+    std::vector<u64> h((size_t)n_poly * N);
+    hip_check(hipMemcpyAsync(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost, c_.stream), "sample download");
+    hip_check(hipStreamSynchronize(c_.stream), "sample sync");
+    c_.pool.free(d);
+    const u64 q0 = c_.chain.q[0];
+    std::vector<long> out(h.size());
+    for (size_t i = 0; i < h.size(); ++i) out[i] = h[i] > q0 / 2 ? -(long)(q0 - h[i]) : (long)h[i];
+    return out;
+}
+
+// c0 = b u + e0 + m, c1 = a u + e1 for n_vec encodings enc [n_vec][ell][N] (stride enc_stride words; 0 = one shared encoding)
+void Client::encrypt_encoded(const u64* enc, size_t enc_stride, int n_vec, int ell, long double scale, int slots, std::vector<CtPtr>& out) {
+    Context& c = c_;
+    const size_t N = c.N, pn = (size_t)ell * N;
+    const int L1 = c.L + 1;
+    std::vector<CtPtr> cts = ev_.new_ct_batch(n_vec, 2, ell, 1, scale, slots);
+    u64* rnd = c.dalloc<u64>((size_t)3 * n_vec * pn);       // u | e0 | e1, each [n_vec][ell][N]
+    sample_small_device(rnd, n_vec, ell, 1);
+    sample_small_device(rnd + (size_t)n_vec * pn, 2 * n_vec, ell, 0);
+    c.ntt(LimbBatch{rnd, 3 * n_vec * ell, nullptr, 0, ell}, false);
+    launch_encrypt_combine(c.dt, cts[0]->d, pk, rnd, rnd + (size_t)n_vec * pn, rnd + (size_t)2 * n_vec * pn, enc, ell, L1, enc_stride, n_vec,
+                           c.stream);
+    hip_check(hipGetLastError(), "encrypt kernels");
+    c.pool.free(rnd);
+    for (auto& ct : cts) out.push_back(ct);
+}
+
 CtPtr Client::encrypt(const PtPtr& p) {
     if (!pk) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
-    const int L1 = c_.L + 1;
-    const int ell = L1 - p->level;
-    const size_t N = c_.N, pn = (size_t)ell * N;
+    const int ell = c_.L + 1 - p->level;
     auto enc = p->at(ell, c_.sf_real[p->level]);
-    CtPtr ct = ev_.new_ct(2, ell, 1, enc->scale, p->slots);
-    u64* u = c_.dalloc<u64>(pn);
-    u64* e = c_.dalloc<u64>(pn);
-    sample_small_to_ntt(u, ell, false, 1);
-    // c0 = b u + e0 + m ; c1 = a u + e1
-    sample_small_to_ntt(e, ell, false, 0);
-    launch_ew_muladd(c_.dt, ct->d, e, pk, u, ell, ell, 0, ell, c_.stream);
-    launch_ew_add(c_.dt, ct->d, ct->d, enc->d, ell, ell, 0, ell, c_.stream);
-    sample_small_to_ntt(e, ell, false, 0);
-    launch_ew_muladd(c_.dt, ct->d + pn, e, pk + (size_t)L1 * N, u, ell, ell, 0, ell, c_.stream);
-    hip_check(hipGetLastError(), "encrypt kernels");
-    c_.pool.free(u);
-    c_.pool.free(e);
-    return ct;
+    std::vector<CtPtr> out;
+    encrypt_encoded(enc->d, 0, 1, ell, enc->scale, p->slots, out);
+    return out[0];
+}
+
+std::vector<CtPtr> Client::encrypt_batch(const double* vals, int n_vec, int n_per, int level, int slots) {
+    if (!pk) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
+    if (slots <= 0) slots = 1 << c_.prm.log_slots;
+    if (level < 0 || level > c_.L) throw Error(FHELIN_ERR_ARG, "encrypt: level out of range");
+    if (n_vec < 0 || n_per < 0) throw Error(FHELIN_ERR_ARG, "encrypt_batch: negative count");
+    const int ell = c_.L + 1 - level;
+    const size_t pn = (size_t)ell * c_.N;
+    const long double scale = c_.sf_real[level];
+    std::vector<CtPtr> out;
+    const int CHUNK = 32;                                    // bounds the temporaries (4 polynomials per vector in flight)
+    for (int lo = 0; lo < n_vec; lo += CHUNK) {
+        const int n = std::min(CHUNK, n_vec - lo);
+        u64* enc = c_.dalloc<u64>((size_t)n * pn);
+        encode_batch_device(c_, enc, vals + (size_t)lo * n_per, nullptr, n, n_per, slots, ell, scale);
+        encrypt_encoded(enc, pn, n, ell, scale, slots, out);
+        c_.pool.free(enc);
+    }
+    return out;
 }
 
 CtPtr Client::phase(const CtPtr& ct, int nl) {

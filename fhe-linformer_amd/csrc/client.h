@@ -5,6 +5,7 @@
 #pragma once
 #include <vector>
 #include "evaluator.h"
+#include "kernels_client.h"
 
 namespace fhelin {
 
@@ -42,6 +43,11 @@ public:
 
     PtPtr encode(const double* vals, int n, int level, int slots);
     CtPtr encrypt(const PtPtr& p);
+    // n_vec real vectors of n_per values each (row-major) -> n_vec fresh ciphertexts at `level`: encoding (special FFT, scaling,
+    // rounding), sampling of (u, e0, e1) and the dyadic combination all on the GPU, in batched launches
+    std::vector<CtPtr> encrypt_batch(const double* vals, int n_vec, int n_per, int level, int slots);
+    // test hook: the sampler's raw output, n_poly polynomials of N centred coefficients (kind 0 Gaussian, 1 ternary)
+    std::vector<long> debug_sample(int kind, int n_poly);
     std::vector<double> decrypt(const CtPtr& c, int slots);
     CtPtr phase(const CtPtr& c, int nlimbs);   // c0 + c1 s (+ c2 s^2) on the first nlimbs limbs, NTT form, 1 component
 
@@ -55,7 +61,12 @@ private:
     Prng rng_;
     u64* s_all = nullptr;   // secret, NTT form over Q and P limbs [L+1+k][N]
     u64* pk = nullptr;      // [2][L+1][N]: b = -a s + e, a
-    void sample_small_to_ntt(u64* dst, int nlimbs_q, bool with_p, int kind);  // kind 0 gaussian, 1 ternary
+    void sample_small_to_ntt(u64* dst, int nlimbs_q, bool with_p, int kind);  // kind 0 gaussian, 1 ternary (host sampler: key generation)
+    // device sampler (encryption randomness): dst [n_poly][ell][N] coefficient form; a fresh ChaCha20 key per call
+    void sample_small_device(u64* dst, int n_poly, int ell, int kind);
+    // c0 = b u + e0 + m, c1 = a u + e1 for n_vec encodings enc [n_vec][ell][N] (enc_stride words apart; 0 = one shared encoding)
+    void encrypt_encoded(const u64* enc, size_t enc_stride, int n_vec, int ell, long double scale, int slots, std::vector<CtPtr>& out);
+    u64 sample_calls_ = 0;
 };
 
 // special FFT helpers (shared by encode/decode); slots must be a power of two
@@ -64,5 +75,7 @@ void ckks_fft_special(std::vector<std::pair<double, double>>& v, bool inverse);
 void ckks_fft_tables(int slots, std::vector<u32>& rot, std::vector<std::pair<double, double>>& ksi);
 std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>& values, const std::vector<double>& imag, int slots,
                                            int ell, long double scale);
+// device encoder for n_vec vectors: re / im [n_vec][n_per] (im may be null) -> dst [n_vec][ell][N] NTT form
+void encode_batch_device(Context& c, u64* dst, const double* re, const double* im, int n_vec, int n_per, int slots, int ell, long double scale);
 
 }  // namespace fhelin

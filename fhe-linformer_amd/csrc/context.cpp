@@ -77,6 +77,7 @@ const T* Context::upload_table(const std::vector<T>& v) {
 template const u64* Context::upload_table<u64>(const std::vector<u64>&);
 template const int* Context::upload_table<int>(const std::vector<int>&);
 template const u32* Context::upload_table<u32>(const std::vector<u32>&);
+template const double* Context::upload_table<double>(const std::vector<double>&);
 
 static u64 prod_mod(const std::vector<u64>& ms, int skip, u64 t) {
     u64 r = 1 % t;
@@ -167,6 +168,7 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
         hip_check(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming), "hipEventCreate(fork)");
         if (const char* e = std::getenv("FHELIN_ASYNC")) async_lanes = std::atoi(e) != 0;
         if (const char* e = std::getenv("FHELIN_FUSE_MODDOWN")) fuse_moddown = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FHELIN_HOST_ENCODE")) host_encode = std::atoi(e) != 0;
     }
     hip_check(hipEventCreate(&ev_start), "hipEventCreate");
     stage_words = (size_t)2 << p.log_n;

@@ -173,6 +173,14 @@ struct Context {
     // memory pass fewer — and measured SLOWER end to end (1615 vs 1574 ms/sample): the epilogue's ~25 instructions per
     // residue land in the VALU-bound NTT, while the separate kernel is bandwidth-bound and overlaps with it.  Off.
     bool fuse_moddown = false;
+    // FHELIN_HOST_ENCODE=1 / fhelin_ctx_set_host_encode: the special FFT of CKKS encoding on the host (the original path, kept
+    // as the reference the device encoder is compared with bit for bit); default: on the GPU (kernels_client.hip)
+    bool host_encode = false;
+    struct FftDev {
+        const u32* rot = nullptr;     // [slots]      5^j mod 4 slots
+        const double* ksi = nullptr;  // [4 slots + 1][2]
+    };
+    std::map<int, FftDev> fft_dev;    // by slot count
     void sync();
     // K1 launch + accounting (active = vectors actually transformed, for tables with skipped entries)
     void ntt(const LimbBatch& b, bool inverse, int active = -1) {

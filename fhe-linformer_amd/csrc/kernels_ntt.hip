@@ -121,11 +121,17 @@ __device__ __forceinline__ void fwd_stage(u64 (&x)[16], const RoundTw& tw, const
         if (k0 & (1 << KB)) continue;
         const int k1 = k0 | (1 << KB);
         const u64x2 w = tw.t[(8 >> KB) - 1 + (k0 >> (KB + 1))];
-        // A = X + T comes out of the multiply-add chain itself; B = X + 5q - T = (2X + 5q) - A
         const u64 X = LAZY ? x[k0] : csub_mask(x[k0], c.q5);
+#if defined(FHELIN_BFLY15)  // A/B measurement builds only (tools/build_variant.sh): the 15-instruction form
+        const u64 T = mul_shoup_lazy5(x[k1], w.x, w.y, c.nq);
+        x[k0] = X + T;
+        x[k1] = X + c.q5 - T;
+#else
+        // A = X + T comes out of the multiply-add chain itself; B = X + 5q - T = (2X + 5q) - A
         const u64 A = mul_shoup_lazy5_add(x[k1], w.x, w.y, c.nq, X);
         x[k0] = A;
         x[k1] = shl1_add(X, c.q5) - A;
+#endif
     }
 }
 template <int KB_LO, int KB_HI, bool LAZY>

@@ -75,6 +75,10 @@ class GpuController:
     def read_expanded_input(self, v, scale=1.0):
         return self.encrypt(expanded(np.asarray(v) * scale), 0)
 
+    def read_expanded_inputs(self, rows, scale=1.0):
+        """all inputs of a sample in one batched client call (encode + sample + encrypt on the GPU)"""
+        return self.e.encrypt_batch(np.stack([expanded(np.asarray(v) * scale) for v in rows]), 0, SLOTS)
+
     def read_plain_input(self, m, level=0, scale=1.0):
         return self.encode(np.asarray(m, dtype=np.float64).reshape(-1) * scale, level)
 
@@ -156,9 +160,14 @@ class GpuController:
 # ---- the circuit: reference src/main.cpp:145-475 (CLS-query variant, as built) -----------------------------
 def encrypt_inputs(ctl, x_in, X_E, X_F):
     """client side (main.cpp:159-173): x_in [S_total,128] (row 0 = CLS token), X_E / X_F [32,128] (Linformer projections)"""
-    return {"inputs_E": [ctl.read_expanded_input(X_E[i]) for i in range(32)],               # main.cpp:159-162
-            "inputs_F": [ctl.read_expanded_input(X_F[i]) for i in range(32)],               # :164-167
-            "inputs": [ctl.read_expanded_input(x_in[i]) for i in range(x_in.shape[0])]}     # :169-173
+    rows = [X_E[i] for i in range(32)] + [X_F[i] for i in range(32)] + [x_in[i] for i in range(x_in.shape[0])]
+    if hasattr(ctl, "read_expanded_inputs"):
+        cts = ctl.read_expanded_inputs(rows)            # one batched call instead of 194 read_expanded_input calls
+    else:
+        cts = [ctl.read_expanded_input(r) for r in rows]
+    return {"inputs_E": cts[:32],                                                           # main.cpp:159-162
+            "inputs_F": cts[32:64],                                                         # :164-167
+            "inputs": cts[64:]}                                                             # :169-173
 
 
 def encoder1(ctl, w, enc, trace=None, full_attention=False):

@@ -129,6 +129,17 @@ int fhelin_pt_export(fhelin_ctx* c, const fhelin_pt* p, int32_t ell, double scal
 
 /* ---- ciphertexts ----------------------------------------------------------------------------- */
 int fhelin_encrypt(fhelin_ctx* c, const fhelin_pt* p, fhelin_ct** out);                 /* context->Encrypt   :380,:384 */
+/* n_vec inputs at once (the driver's 194 read_expanded_input calls per sample, src/main.cpp:159-173; FHEController.cpp:623-650):
+ * vals [n_vec][n_per] real slot values -> n_vec fresh ciphertexts at `level`.  Encoding (special FFT in fp64, scaling,
+ * rounding), the sampling of the encryption randomness (ChaCha20 on the GPU, keyed from the client's generator) and the
+ * dyadic combination run as batched kernels. */
+int fhelin_encrypt_batch(fhelin_ctx* c, const double* vals, int32_t n_vec, int32_t n_per, int32_t level, int32_t slots, fhelin_ct** outs);
+/* 1: the special FFT of CKKS encoding runs on the host (the original encoder, the reference the device encoder is compared
+ * with bit for bit); 0 (default): on the GPU.  Both produce identical residues. */
+int fhelin_ctx_set_host_encode(fhelin_ctx* c, int32_t on);
+/* test hook: n_poly polynomials of N centred coefficients straight from the device sampler (kind 0: rounded Gaussian
+ * sigma 3.19, 1: uniform ternary) */
+int fhelin_debug_sample(fhelin_ctx* c, int32_t kind, int32_t n_poly, int64_t* out, size_t cap);
 int fhelin_decrypt(fhelin_ctx* c, const fhelin_ct* ct, double* out, int32_t slots);     /* context->Decrypt + GetRealPackedValue :387-404 */
 int fhelin_ct_import(fhelin_ctx* c, const uint64_t* limbs, int32_t npoly, int32_t ell, int32_t deg, double scale,
                      int32_t slots, fhelin_ct** out);
