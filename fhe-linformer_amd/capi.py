@@ -152,6 +152,7 @@ def load_library():
         "fhelin_mult_real": (i32, [vp, vp, C.c_double, C.POINTER(vp)]),
         "fhelin_add_real": (i32, [vp, vp, C.c_double, C.POINTER(vp)]),
         "fhelin_mult_many": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp)]),
+        "fhelin_lincomb": (i32, [vp, C.POINTER(vp), C.POINTER(C.c_double), i32, C.c_double, C.POINTER(vp)]),
         "fhelin_eval_poly": (i32, [vp, vp, C.POINTER(C.c_double), i32, C.POINTER(vp)]),
         "fhelin_eval_chebyshev": (i32, [vp, vp, C.POINTER(C.c_double), i32, C.c_double, C.c_double, C.POINTER(vp)]),
         "fhelin_bootstrap_setup": (i32, [vp, i32, i32, i32]),
@@ -504,6 +505,12 @@ class Engine:
     def mult_many(self, v):
         h = C.c_void_p()
         self._ck(self.lib.fhelin_mult_many(self.h, self._harr(v), len(v), C.byref(h)))
+        return Ct(self, h)
+
+    def lincomb(self, v, coeffs, c0=0.0):
+        cf = np.ascontiguousarray(coeffs, dtype=np.float64)
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_lincomb(self.h, self._harr(v), cf.ctypes.data_as(C.POINTER(C.c_double)), len(v), float(c0), C.byref(h)))
         return Ct(self, h)
 
     def eval_poly(self, x, coeffs):

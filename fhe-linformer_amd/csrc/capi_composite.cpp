@@ -278,6 +278,12 @@ int fhelin_mult_many(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin
     *out = wrap(c->ev.mult_many(vec_of(c, v, n)));
     FHELIN_CATCH
 }
+int fhelin_lincomb(fhelin_ctx* c, const fhelin_ct* const* v, const double* coeffs, int32_t n, double c0, fhelin_ct** out) {
+    NEED(c && v && coeffs && out && n >= 1);
+    FHELIN_TRY
+    *out = wrap(c->ev.lincomb(vec_of(c, v, n), std::vector<double>(coeffs, coeffs + n), c0));
+    FHELIN_CATCH
+}
 int fhelin_eval_poly(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, int32_t n, fhelin_ct** out) {
     NEED(c && x && coeffs && out);
     FHELIN_TRY

@@ -176,6 +176,9 @@ struct Context {
     // FHELIN_HOST_ENCODE=1 / fhelin_ctx_set_host_encode: the special FFT of CKKS encoding on the host (the original path, kept
     // as the reference the device encoder is compared with bit for bit); default: on the GPU (kernels_client.hip)
     bool host_encode = false;
+    // FHELIN_FUSE_GATHER=0: the rotated c0 parts of a merged rotation sum go through their own gather-and-sum kernel instead of
+    // the ModDown epilogue (bit-identical; kept for A/B measurements)
+    bool fuse_gather = true;
     struct FftDev {
         const u32* rot = nullptr;     // [slots]      5^j mod 4 slots
         const double* ksi = nullptr;  // [4 slots + 1][2]

@@ -274,8 +274,14 @@ std::vector<CtPtr> Evaluator::rotate_sum_batch(const std::vector<CtPtr>& vin, co
         u64* accQ = c_.dalloc<u64>((size_t)B * 2 * ell * N);
         u64* accP = c_.dalloc<u64>((size_t)B * 2 * K * N);
         launch_ks_inner_multi(c_.dt, sh, accQ, accP, ext, base + pn, s);
-        u64* c0sum = c_.dalloc<u64>((size_t)B * ell * N);
-        launch_gather_sum(c_.dt, sh, c0sum, base, ctw, s);
+        u64* c0sum = nullptr;
+        if (c_.fuse_gather) {
+            sh.gsrc = base;      // the epilogue gathers the rotated c0 parts itself
+            sh.gsrc_stride = ctw;
+        } else {
+            c0sum = c_.dalloc<u64>((size_t)B * ell * N);
+            launch_gather_sum(c_.dt, sh, c0sum, base, ctw, s);
+        }
         // one ModDown; the epilogue adds the gathered c0 parts and the unrotated input
         c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
         u64* conv = c_.dalloc<u64>((size_t)B * 2 * ell * N);
@@ -287,7 +293,7 @@ std::vector<CtPtr> Evaluator::rotate_sum_batch(const std::vector<CtPtr>& vin, co
         c_.pool.free(ext);
         c_.pool.free(accQ);
         c_.pool.free(accP);
-        c_.pool.free(c0sum);
+        if (c0sum) c_.pool.free(c0sum);
         c_.pool.free(conv);
         for (int b = 0; b < B; ++b) {
             o[b]->scale = vin[idx[b]]->scale;
@@ -364,8 +370,14 @@ CtPtr Evaluator::rotate_each_sum(const std::vector<CtPtr>& vin, const std::vecto
         u64* accQ = c_.dalloc<u64>((size_t)2 * ell * N);
         u64* accP = c_.dalloc<u64>((size_t)2 * K * N);
         launch_ks_inner_multi(c_.dt, sh, accQ, accP, ext, base + pn, s);
-        u64* c0sum = c_.dalloc<u64>((size_t)ell * N);
-        launch_gather_sum(c_.dt, sh, c0sum, base, 0, s);
+        u64* c0sum = nullptr;
+        if (c_.fuse_gather) {
+            sh.gsrc = base;
+            sh.gsrc_stride = 0;
+        } else {
+            c0sum = c_.dalloc<u64>((size_t)ell * N);
+            launch_gather_sum(c_.dt, sh, c0sum, base, 0, s);
+        }
         c_.ntt(LimbBatch{accP, 2 * K, nullptr, L1, K}, true);
         u64* conv = c_.dalloc<u64>((size_t)2 * ell * N);
         launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
@@ -377,7 +389,7 @@ CtPtr Evaluator::rotate_each_sum(const std::vector<CtPtr>& vin, const std::vecto
         c_.pool.free(ext);
         c_.pool.free(accQ);
         c_.pool.free(accP);
-        c_.pool.free(c0sum);
+        if (c0sum) c_.pool.free(c0sum);
         c_.pool.free(conv);
         acc = acc ? add(acc, o) : o;
     }

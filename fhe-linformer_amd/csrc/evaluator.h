@@ -147,6 +147,10 @@ public:
     CtPtr mult_int(const CtPtr& a, u64 k, bool raise_deg, long double new_scale);  // by an integer constant
     CtPtr mult_real(const CtPtr& a, double c);              // by a real constant: per-limb scalar round(c * Delta_level)
     CtPtr add_real(const CtPtr& a, double c);               // add a real constant to every slot
+    // sum_k coef[k] * terms[k] + c0 for ciphertexts of identical (level, degree 1, scale): the residues of the chain
+    // add(mult_real(t_1, c_1), mult_real(t_2, c_2), ...) + add_real(c0), in one kernel pass (falls back to that chain when
+    // the shapes differ).  Terms with coef 0 are skipped.
+    CtPtr lincomb(const std::vector<CtPtr>& terms, const std::vector<double>& coef, double c0);
     CtPtr rotate(const CtPtr& a, int index);
     CtPtr conjugate(const CtPtr& a);
     // polynomial evaluation (EvalPoly :1291, EvalMultMany :1297, EvalChebyshevFunction :1319-1335)

@@ -18,6 +18,16 @@ void launch_ew_muladd(const DeviceTables& t, u64* out, const u64* acc, const u64
 void launch_ew_neg(const DeviceTables& t, u64* out, const u64* a, int nvec, int limb_first, int limb_count, hipStream_t s);
 void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s);
 void launch_ew_addscalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s);
+// out[v] = sum_k a_k[v] * scal[k][limb] + scal[n][limb]  (limb = v % ell): a linear combination with real constants of up to
+// MAX_TERMS ciphertexts of identical shape in ONE pass — the base case of a Chebyshev / power-basis evaluation, which as
+// single ops is one scalar-multiply launch and one add launch per term.  scal: device array [(n + 1)][ell] of residues.
+struct LinComb {
+    static constexpr int MAX_TERMS = 32;
+    int n = 0;
+    int vecs = 0;  // limb vectors per operand (npoly * ell)
+    const u64* a[MAX_TERMS];
+};
+void launch_ew_lincomb(const DeviceTables& t, u64* out, const LinComb& lc, const u64* scal, int ell, hipStream_t s);
 void launch_tensor(const DeviceTables& t, u64* d, const u64* a, const u64* b, int ell, hipStream_t s);
 void launch_automorph(const DeviceTables& t, u64* out, const u64* in, const u32* map, int nvec, hipStream_t s);
 void launch_rescale_lift(const DeviceTables& t, u64* lifted, const u64* last, int npoly, int ell, const u64* qlmod_row, hipStream_t s);
@@ -70,6 +80,10 @@ struct KsShape {
     // rot_input_stride): a sum of rotations of different ciphertexts (giant steps) shares the one ModDown
     size_t rot_ext_stride = 0;
     size_t rot_input_stride = 0;
+    // K8b epilogue of a merged rotation sum: component 0 additionally receives sum_r gsrc[bi][tt][map_rot[r][n]] (the rotated
+    // c0 parts, gathered in place of a separate gather-and-sum pass); rotation r reads gsrc + r * rot_input_stride
+    const u64* gsrc = nullptr;
+    size_t gsrc_stride = 0;   // per batch row
 };
 // K6: cc [ell][N] coefficient form, c_ntt [ell][N] NTT form -> ext [beta][ell+k][N]
 //     (own-digit slots stay unused — K7 reads c_ntt there; the others get the fast-basis-extended values, coefficient form)
@@ -84,6 +98,7 @@ void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* a
 void launch_ks_inner_multi(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* c_ntt,
                            hipStream_t s);
 // out[v][n] = sum_r in[v][map_rot[r][n]]  for v in [0, nvec) (the c0 parts of the rotated copies), per batch row
+// (FHELIN_FUSE_GATHER=0 only: by default the sum rides in launch_moddown_finish, KsShape::gsrc)
 void launch_gather_sum(const DeviceTables& t, const KsShape& sh, u64* out, const u64* in, size_t in_stride, hipStream_t s);
 // K8a: accP coefficient form [2][k][N] -> conv [2][ell][N] (coefficient form)
 void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,

@@ -140,6 +140,28 @@ __global__ __launch_bounds__(256) void ew_addscalar_kernel(DeviceTables t, u64* 
     reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
 }
 
+// out[v] = sum_k a_k[v] * s_k[limb] + s_n[limb]; grid (N/512, vecs).  The products are summed in 128 bits and reduced once:
+// the canonical residue of the sum, whatever the order (32 q^2 < q 2^64 for the Q limbs, q < 2^59).
+__global__ __launch_bounds__(256) void ew_lincomb_kernel(DeviceTables t, u64* out, LinComb lc, const u64* __restrict__ scal, int ell) {
+    const int v = blockIdx.y;
+    const int l = v % ell;
+    const Barrett br = load_barrett(t, l);
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    Acc128 ax = {0, 0}, ay = {0, 0};
+    for (int k = 0; k < lc.n; ++k) {
+        const u64 sk = scal[(size_t)k * ell + l];
+        const u64x2 x = reinterpret_cast<const u64x2*>(lc.a[k])[(size_t)v * row + n2];
+        acc_mac(ax, x.x, sk);
+        acc_mac(ay, x.y, sk);
+    }
+    const u64 c0 = v < ell ? scal[(size_t)lc.n * ell + l] : 0;   // the constant is added to component 0 only
+    u64x2 r;
+    r.x = add_mod(barrett_reduce128(ax.lo, ax.hi, br), c0, br.q);
+    r.y = add_mod(barrett_reduce128(ay.lo, ay.hi, br), c0, br.q);
+    reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
+}
+
 // tensor product of two 2-component ciphertexts a, b [2][ell][N] -> d [3][ell][N]
 __global__ __launch_bounds__(256) void tensor_kernel(DeviceTables t, u64* d, const u64* a, const u64* b, int ell) {
     const int l = blockIdx.y;
@@ -295,6 +317,10 @@ void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const Scala
 void launch_ew_addscalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s) {
     if (nvec <= 0) return;
     hipLaunchKernelGGL(ew_addscalar_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, sc, limb_first, limb_count);
+}
+void launch_ew_lincomb(const DeviceTables& t, u64* out, const LinComb& lc, const u64* scal, int ell, hipStream_t s) {
+    if (lc.n <= 0 || lc.vecs <= 0) return;
+    hipLaunchKernelGGL(ew_lincomb_kernel, grid2(t.log_n, lc.vecs), dim3(256), 0, s, t, out, lc, scal, ell);
 }
 void launch_tensor(const DeviceTables& t, u64* d, const u64* a, const u64* b, int ell, hipStream_t s) {
     hipLaunchKernelGGL(tensor_kernel, grid2(t.log_n, ell), dim3(256), 0, s, t, d, a, b, ell);

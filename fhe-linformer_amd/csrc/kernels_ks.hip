@@ -319,6 +319,15 @@ __global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsS
         r.x = add_mod(r.x, p.x, q);
         r.y = add_mod(r.y, p.y, q);
     }
+    if (sh.gsrc && c == 0) {  // merged rotation sum: + sum_r sigma_r(c0), gathered here
+        const u64* __restrict__ g = sh.gsrc + (size_t)bi * sh.gsrc_stride + (size_t)tt * N;
+        for (int rr = 0; rr < sh.n_rot; ++rr) {
+            const u64* __restrict__ gr = g + (size_t)rr * sh.rot_input_stride;
+            const u32* __restrict__ mr = sh.map_rot[rr];
+            r.x = add_mod(r.x, gr[mr ? (size_t)mr[j] : j], q);
+            r.y = add_mod(r.y, gr[mr ? (size_t)mr[j + 1] : j + 1], q);
+        }
+    }
     reinterpret_cast<u64x2*>(out)[((size_t)v * N + j) >> 1] = r;
 }
 

@@ -43,6 +43,54 @@ CtPtr Evaluator::add_real(const CtPtr& a, double cst) {
     return o;
 }
 
+CtPtr Evaluator::lincomb(const std::vector<CtPtr>& terms_in, const std::vector<double>& coef_in, double c0) {
+    std::vector<CtPtr> terms;
+    std::vector<double> coef;
+    for (size_t i = 0; i < terms_in.size(); ++i)
+        if (coef_in[i] != 0.0) {
+            terms.push_back(terms_in[i]);
+            coef.push_back(coef_in[i]);
+        }
+    if (terms.empty()) throw Error(FHELIN_ERR_ARG, "lincomb: all coefficients are zero");
+    bool uniform = (int)terms.size() <= LinComb::MAX_TERMS && terms.size() >= 2;
+    for (const CtPtr& t : terms)
+        uniform = uniform && t->deg == 1 && t->npoly == terms[0]->npoly && t->ell == terms[0]->ell &&
+                  fabsl(t->scale / terms[0]->scale - 1.0L) < 1e-9L;
+    if (!uniform) {  // the chain of single operations (also the definition of the result)
+        CtPtr acc;
+        for (size_t i = 0; i < terms.size(); ++i) {
+            CtPtr t = mult_real(terms[i], coef[i]);
+            acc = acc ? add(acc, t) : t;
+        }
+        return c0 != 0.0 ? add_real(acc, c0) : acc;
+    }
+    const CtPtr& x = terms[0];
+    const int ell = x->ell, n = (int)terms.size();
+    const long double sf = c_.sf_real[x->level()];
+    const long double out_scale = x->scale * sf;
+    std::vector<u64> sc((size_t)(n + 1) * ell, 0);
+    ScalarSet one;
+    for (int k = 0; k < n; ++k) {
+        real_to_scalars(c_, (long double)coef[k] * sf, ell, one);
+        for (int l = 0; l < ell; ++l) sc[(size_t)k * ell + l] = one.v[2 * l];
+    }
+    if (c0 != 0.0) {
+        real_to_scalars(c_, (long double)c0 * out_scale, ell, one);
+        for (int l = 0; l < ell; ++l) sc[(size_t)n * ell + l] = one.v[2 * l];
+    }
+    u64* dsc = c_.dalloc<u64>(sc.size());
+    c_.upload_async(dsc, sc.data(), sc.size());
+    LinComb lc;
+    lc.n = n;
+    lc.vecs = x->npoly * ell;
+    for (int k = 0; k < n; ++k) lc.a[k] = terms[k]->d;
+    CtPtr o = new_ct(x->npoly, ell, 2, out_scale, x->slots);
+    launch_ew_lincomb(c_.dt, o->d, lc, dsc, ell, c_.stream);
+    hip_check(hipGetLastError(), "lincomb");
+    c_.pool.free(dsc);
+    return o;
+}
+
 CtPtr Evaluator::conjugate(const CtPtr& a) {
     if (!conj_key) throw Error(FHELIN_ERR_KEY, "no conjugation key");
     return raw_rotate(a, 2ull * c_.N - 1, *conj_key);
@@ -87,14 +135,8 @@ CtPtr Evaluator::eval_poly(const CtPtr& x, const std::vector<double>& coeffs) {
         pw[i] = (hi == i) ? mult(pw[i / 2], pw[i / 2]) : mult(pw[hi], pw[i - hi]);
     }
     align_deg1(*this, pw, 1);
-    CtPtr acc;
-    for (int i = 1; i <= n; ++i) {
-        if (coeffs[i] == 0.0) continue;
-        CtPtr t = mult_real(pw[i], coeffs[i]);
-        acc = acc ? add(acc, t) : t;
-    }
-    if (!acc) throw Error(FHELIN_ERR_ARG, "eval_poly: all non-constant coefficients are zero");
-    return coeffs[0] != 0.0 ? add_real(acc, coeffs[0]) : acc;
+    std::vector<CtPtr> terms(pw.begin() + 1, pw.begin() + n + 1);
+    return lincomb(terms, std::vector<double>(coeffs.begin() + 1, coeffs.begin() + n + 1), coeffs[0]);
 }
 
 // Chebyshev evaluation over a ROW of ciphertexts (one value per input): every op below acts on all inputs at once, the
@@ -105,19 +147,22 @@ Evaluator::CtRow Evaluator::cheb_recurse(const std::vector<double>& c, const std
     while (n > 0 && c[n] == 0.0) --n;
     const size_t rows = T[1].size();
     if (n < baby) {
-        CtRow acc;
-        for (int k = 1; k <= n; ++k) {
-            if (c[k] == 0.0) continue;
-            CtRow t(rows);
-            for (size_t i = 0; i < rows; ++i) t[i] = mult_real(T[k][i], c[k]);
-            acc = acc.empty() ? t : add_batch(acc, t);
+        bool any = false;
+        for (int k = 1; k <= n; ++k) any = any || c[k] != 0.0;
+        CtRow acc(rows);
+        if (!any) {  // constant polynomial: c0 as an encryption-free shift of 0 * T_1
+            for (size_t i = 0; i < rows; ++i) {
+                acc[i] = mult_real(T[1][i], 0.0);
+                if (c[0] != 0.0) acc[i] = add_real(acc[i], c[0]);
+            }
+            return acc;
         }
-        if (acc.empty()) {  // constant polynomial: c0 as an encryption-free shift of 0 * T_1
-            acc.resize(rows);
-            for (size_t i = 0; i < rows; ++i) acc[i] = mult_real(T[1][i], 0.0);
+        // sum_k c_k T_k + c_0 in one pass per input (the babies share one level: align_deg1)
+        for (size_t i = 0; i < rows; ++i) {
+            std::vector<CtPtr> terms;
+            for (int k = 1; k <= n; ++k) terms.push_back(T[k][i]);
+            acc[i] = lincomb(terms, std::vector<double>(c.begin() + 1, c.begin() + n + 1), c[0]);
         }
-        if (c[0] != 0.0)
-            for (size_t i = 0; i < rows; ++i) acc[i] = add_real(acc[i], c[0]);
         return acc;
     }
     int m = baby;

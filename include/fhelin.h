@@ -228,6 +228,10 @@ int fhelin_fc_wrap_containers(fhelin_ctx* c, const fhelin_ct* const* v, int32_t 
 int fhelin_mult_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out);              /* EvalMult(ct, double)            */
 int fhelin_add_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out);               /* EvalAdd(ct, double)             */
 int fhelin_mult_many(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out);      /* EvalMultMany       :1297        */
+/* sum_k coeffs[k] * v[k] + c0 (OpenFHE's EvalLinearWSum, the inner sums of EvalPoly / EvalChebyshevSeries :1291,:1319-1335):
+ * ciphertexts of one (level, degree 1, scale) are combined in a single kernel pass; same residues as the chain of
+ * EvalMult(ct,double) / EvalAdd / EvalAdd(ct,double) */
+int fhelin_lincomb(fhelin_ctx* c, const fhelin_ct* const* v, const double* coeffs, int32_t n, double c0, fhelin_ct** out);
 /* power-basis polynomial sum_i coeffs[i] x^i                                                      EvalPoly           :1291        */
 int fhelin_eval_poly(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, int32_t n, fhelin_ct** out);
 /* Chebyshev series coeffs[0]/2 + sum_{k>=1} coeffs[k] T_k(u), u = (2x-(a+b))/(b-a)     EvalChebyshevFunction :1319-1335

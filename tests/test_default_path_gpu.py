@@ -362,3 +362,31 @@ def test_deferred_rows_match_eager_and_skip_dead_rows(fa, orc):
         assert eng.stats()["keyswitch"] == before
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("preset,ell,n", [("toy13", 6, 5), ("bench", 24, 31), ("toy13", 3, 1)])
+def test_linear_combination_bit_exact(engine_factory, orc, preset, ell, n):
+    """fhelin_lincomb (EvalLinearWSum; the base case of every Chebyshev / power-basis evaluation) in one kernel pass ==
+    the chain EvalMult(ct,double) -> EvalAdd -> EvalAdd(ct,double) on the oracle side"""
+    from oracle.residue_eval import RCt
+    eng = engine_factory(preset)
+    rev = _rev(orc, eng, {})
+    rng = np.random.default_rng(8)
+    pairs = [_imp(eng, rev, _ct(orc, eng, 700 + i, ell)) for i in range(n)]
+    coef = rng.uniform(-2, 2, n)
+    if n > 3:
+        coef[2] = 0.0                                                # a skipped term
+    c0 = 0.37
+    ql = eng.q[:ell]
+    sf = rev.sf[len(eng.q) - ell]
+    acc = None
+    for (_, r), ck in zip(pairs, coef):
+        if ck == 0.0:
+            continue
+        s = _real_scalars(ql, LD(ck) * sf)
+        t = np.stack([orc.mul_scalar(r.d[p], s, ql) for p in range(2)])
+        acc = t if acc is None else np.stack([orc.add(acc[p], t[p], ql) for p in range(2)])
+    out_scale = pairs[0][1].scale * sf
+    acc[0] = orc.add_scalar(acc[0], _real_scalars(ql, LD(c0) * out_scale), ql)
+    got = eng.lincomb([p[0] for p in pairs], coef, c0)
+    _same(got, RCt(acc, 2, out_scale), ("lincomb", preset, n))
