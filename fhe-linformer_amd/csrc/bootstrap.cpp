@@ -211,36 +211,15 @@ CtPtr Bootstrapper::apply(const LinStage& st, const CtPtr& xin) {
     std::vector<CtPtr> brot = ev_.rotate_many(x, bidx);
     std::map<int, CtPtr> babies;
     for (size_t i = 0; i < bidx.size(); ++i) babies[bidx[i]] = brot[i];
-    // all diagonal products of the stage in one batched launch sequence, then the per-giant-step sums as pairwise trees
-    // evaluated level by level across all groups (one add launch per level)
-    std::vector<CtPtr> tin;
-    std::vector<PtPtr> tdiag;
+    // per giant step: sum_b diag_{g,b} * rot_b(x) as ONE inner-product pass (Evaluator::dot_plain) instead of a product
+    // launch per term and a tree of additions
+    std::map<int, std::pair<std::vector<CtPtr>, std::vector<PtPtr>>> groups;
     for (const auto& t : st.terms) {
-        tin.push_back(babies[t.baby]);
-        tdiag.push_back(t.diag);
-    }
-    std::vector<CtPtr> prod = ev_.mult_plain_each(tin, tdiag);
-    std::map<int, std::vector<CtPtr>> groups;
-    for (size_t i = 0; i < st.terms.size(); ++i) groups[st.terms[i].giant].push_back(prod[i]);
-    for (;;) {
-        std::vector<CtPtr> lhs, rhs;
-        for (auto& g : groups)
-            for (size_t i = 0; i + 1 < g.second.size(); i += 2) {
-                lhs.push_back(g.second[i]);
-                rhs.push_back(g.second[i + 1]);
-            }
-        if (lhs.empty()) break;
-        std::vector<CtPtr> sum = ev_.add_batch(lhs, rhs);
-        size_t k = 0;
-        for (auto& g : groups) {
-            std::vector<CtPtr> nxt;
-            for (size_t i = 0; i + 1 < g.second.size(); i += 2) nxt.push_back(sum[k++]);
-            if (g.second.size() & 1) nxt.push_back(g.second.back());
-            g.second.swap(nxt);
-        }
+        groups[t.giant].first.push_back(babies[t.baby]);
+        groups[t.giant].second.push_back(t.diag);
     }
     std::map<int, CtPtr> inner;
-    for (auto& g : groups) inner[g.first] = g.second[0];
+    for (auto& g : groups) inner[g.first] = ev_.dot_plain(g.second.first, g.second.second);
     // giant steps: different inputs, different keys, same shape
     std::vector<CtPtr> gin;
     std::vector<int> gidx;

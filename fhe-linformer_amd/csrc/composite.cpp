@@ -333,7 +333,7 @@ CtPtr Composite::matmulScores(const CtVec& queries, const CtPtr& key) {
 CtPtr Composite::wrapUpRepeated(const CtVec& v) {
     std::vector<PtPtr> masks;
     for (size_t i = 0; i < v.size(); ++i) masks.push_back(block_mask(128 * (int)i, 128 * ((int)i + 1), 1));
-    return add_many(ev_.mult_plain_each(v, masks));
+    return ev_.dot_plain(v, masks);   // sum_i v_i * mask_i in one inner-product pass (EvalAddMany of the masked rows, :1060-1068)
 }
 
 CtPtr Composite::wrapUpExpanded(const CtVec& v) {

@@ -676,6 +676,56 @@ std::vector<CtPtr> Evaluator::mult_plain_each(const std::vector<CtPtr>& vin, con
     return out;
 }
 
+CtPtr Evaluator::dot_plain(const std::vector<CtPtr>& vin, const std::vector<PtPtr>& p) {
+    if (vin.size() != p.size() || vin.empty()) throw Error(FHELIN_ERR_ARG, "dot_plain: one plaintext per ciphertext, at least one term");
+    // degree-2 operands are rescaled first, every distinct ciphertext once (as mult_plain does)
+    std::vector<CtPtr> x = vin;
+    {
+        std::vector<CtPtr> need;
+        std::map<const Ciphertext*, size_t> slot;
+        for (size_t i = 0; i < vin.size(); ++i)
+            if (vin[i]->deg >= 2 && !slot.count(vin[i].get())) {
+                slot[vin[i].get()] = need.size();
+                need.push_back(vin[i]);
+            }
+        if (!need.empty()) {
+            std::vector<CtPtr> r = rescale_batch(need);
+            for (size_t i = 0; i < vin.size(); ++i)
+                if (vin[i]->deg >= 2) x[i] = r[slot[vin[i].get()]];
+        }
+    }
+    bool uniform = x.size() >= 2;
+    for (const CtPtr& c : x)
+        uniform = uniform && c->npoly == x[0]->npoly && c->ell == x[0]->ell && c->deg == x[0]->deg && fabsl(c->scale / x[0]->scale - 1.0L) < 1e-9L;
+    if (!uniform) {
+        std::vector<CtPtr> prod = mult_plain_each(x, p);
+        CtPtr acc = prod[0];
+        for (size_t i = 1; i < prod.size(); ++i) acc = add(acc, prod[i]);
+        return acc;
+    }
+    const CtPtr& f = x[0];
+    const long double sf = c_.sf_real[f->level()];
+    CtPtr acc;
+    for (size_t lo = 0; lo < x.size(); lo += EwItems::MAX_ITEMS) {
+        const size_t hi = std::min(x.size(), lo + (size_t)EwItems::MAX_ITEMS);
+        EwItems it;
+        it.n = (int)(hi - lo);
+        it.vecs = f->npoly * f->ell;
+        it.b_vecs = f->ell;
+        for (size_t i = lo; i < hi; ++i) {
+            it.a[i - lo] = x[i]->d;
+            it.b[i - lo] = p[i]->at(f->ell, sf)->d;
+        }
+        CtPtr o = new_ct(f->npoly, f->ell, f->deg + 1, f->scale * sf, f->slots);
+        launch_ew_dot(c_.dt, o->d, it, f->ell, c_.stream);
+        c_.stats.ct_pt_mult += (u64)(hi - lo);
+        c_.stats.ct_pt_limbs += (u64)(hi - lo) * f->ell;
+        acc = acc ? add(acc, o) : o;
+    }
+    launch_ok("dot_plain");
+    return acc;
+}
+
 std::vector<CtPtr> Evaluator::add_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 1); }
 std::vector<CtPtr> Evaluator::sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 2); }
 

@@ -50,6 +50,10 @@ struct EwItems {
     const u64* b[MAX_ITEMS];
 };
 void launch_ew_items(const DeviceTables& t, const EwItems& it, int op, int limb_count, hipStream_t s);
+// out[v] = sum_i a_i[v] * b_i[v % b_vecs] over the n items (n <= MAX_ITEMS): an inner product of ciphertexts with plaintexts in
+// one pass (the diagonal sums of the bootstrapping linear transforms, wrapUpRepeated, matmulCRlarge) instead of n product
+// launches and a tree of additions.  128-bit accumulation, one reduction: the canonical residue of the sum.
+void launch_ew_dot(const DeviceTables& t, u64* out, const EwItems& it, int limb_count, hipStream_t s);
 
 struct KsShape {
     int ell;     // live Q limbs

@@ -79,6 +79,25 @@ __global__ __launch_bounds__(256) void ew_items_kernel(DeviceTables t, EwItems i
     reinterpret_cast<u64x2*>(it.out[item])[(size_t)v * row + n2] = r;
 }
 
+// out[v] = sum_i a_i[v] * b_i[v % b_vecs]; grid (N/512, vecs)
+__global__ __launch_bounds__(256) void ew_dot_kernel(DeviceTables t, u64* out, EwItems it, int limb_count) {
+    const int v = blockIdx.y;
+    const Barrett br = load_barrett(t, v % limb_count);
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    Acc128 ax = {0, 0}, ay = {0, 0};
+    for (int i = 0; i < it.n; ++i) {
+        const u64x2 x = reinterpret_cast<const u64x2*>(it.a[i])[(size_t)v * row + n2];
+        const u64x2 y = reinterpret_cast<const u64x2*>(it.b[i])[(size_t)(v % it.b_vecs) * row + n2];
+        acc_mac(ax, x.x, y.x);
+        acc_mac(ay, x.y, y.y);
+    }
+    u64x2 r;
+    r.x = barrett_reduce128(ax.lo, ax.hi, br);
+    r.y = barrett_reduce128(ay.lo, ay.hi, br);
+    reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
+}
+
 // out[v] = acc[v] + a[v] * b[v % b_mod]
 __global__ __launch_bounds__(256) void ew_muladd_kernel(DeviceTables t, u64* out, const u64* acc, const u64* a, const u64* b,
                                                         int b_mod, int limb_first, int limb_count) {
@@ -288,6 +307,10 @@ void launch_ew_items(const DeviceTables& t, const EwItems& it, int op, int limb_
         case 2: hipLaunchKernelGGL((ew_items_kernel<2>), g, dim3(256), 0, s, t, it, limb_count); break;
         default: hipLaunchKernelGGL((ew_items_kernel<3>), g, dim3(256), 0, s, t, it, limb_count); break;
     }
+}
+void launch_ew_dot(const DeviceTables& t, u64* out, const EwItems& it, int limb_count, hipStream_t s) {
+    if (it.n <= 0 || it.vecs <= 0) return;
+    hipLaunchKernelGGL(ew_dot_kernel, grid2(t.log_n, it.vecs), dim3(256), 0, s, t, out, it, limb_count);
 }
 void launch_ew_mul(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s) {
     if (nvec <= 0) return;

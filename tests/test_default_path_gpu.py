@@ -390,3 +390,23 @@ def test_linear_combination_bit_exact(engine_factory, orc, preset, ell, n):
     acc[0] = orc.add_scalar(acc[0], _real_scalars(ql, LD(c0) * out_scale), ql)
     got = eng.lincomb([p[0] for p in pairs], coef, c0)
     _same(got, RCt(acc, 2, out_scale), ("lincomb", preset, n))
+
+
+@pytest.mark.parametrize("preset,ell,n,deg", [("bench", 24, 3, 1), ("reference", 9, 33, 2)])
+def test_wrapUpRepeated_inner_product_bit_exact(engine_factory, orc, preset, ell, n, deg):
+    """wrapUpRepeated (:1060-1068) = sum_i v_i * block_mask_i: the fused inner-product kernel (ew_dot, also the diagonal sums
+    of the bootstrapping stages) == products and additions composed on the oracle side; 33 terms cross the 32-term chunk;
+    degree-2 inputs are rescaled first"""
+    eng = engine_factory(preset)
+    rev = _rev(orc, eng, {})
+    ns = 1 << eng.params.log_slots
+    pairs = [_imp(eng, rev, _ct(orc, eng, 40 + i, ell), deg=deg) for i in range(n)]
+    got = eng.wrapUpRepeated([p[0] for p in pairs])
+    acc = None
+    for i, (_, r) in enumerate(pairs):
+        m = np.zeros(ns)
+        m[128 * i:128 * (i + 1)] = 1.0
+        pt = eng.encode(m)
+        t = rev.mult_plain(r, lambda e, sc: eng.pt_export(pt, e, sc))
+        acc = t if acc is None else rev.add(acc, t)
+    _same(got, acc, ("wrapUpRepeated", preset, n))

@@ -14,7 +14,7 @@ t0 = time.time(); e.bootstrap_setup(3, 3, 1 << e.params.log_slots); print("setup
 n = 1 << e.params.log_slots
 m = np.random.default_rng(1).uniform(-1, 1, n)
 ct = e.encrypt(m, level=e.n_q - 3)
-for it in range(3):
+for it in range(int(os.environ.get("BOOT_REPS", "3"))):
     e.sync(); t0 = time.time()
     out = e.bootstrap(ct)
     e.sync(); dt = time.time() - t0
