@@ -133,7 +133,13 @@ CtVec Composite::tree_steps(CtVec r, int n, int unit) {
     int i = 0;
     while (i < n) {
         const int s = unit * (1 << i);
-        if (i + 1 < n && merge_rot_ && ev_.have_rotation_keys({s, 2 * s, 3 * s}, r[0]->slots)) {
+        // three steps x += rot(x,s); x += rot(x,2s); x += rot(x,4s) equal x + sum_{m=1..7} rot(x, m s): ONE merged key switch
+        // with the keys of s..7s (measured at N=2^16, 28+7 limbs: a 7-step tree as 3+3+1 takes 0.85x the time of 2+2+2+1 at 12
+        // limbs, 0.96x at 27: profiles/r02_m_radix_probe.txt); two steps with the keys of s, 2s, 3s; else one plain step
+        if (i + 2 < n && merge_rot_ && ev_.have_rotation_keys({s, 2 * s, 3 * s, 4 * s, 5 * s, 6 * s, 7 * s}, r[0]->slots)) {
+            r = ev_.rotate_sum_batch(r, {s, 2 * s, 3 * s, 4 * s, 5 * s, 6 * s, 7 * s});
+            i += 3;
+        } else if (i + 1 < n && merge_rot_ && ev_.have_rotation_keys({s, 2 * s, 3 * s}, r[0]->slots)) {
             r = ev_.rotate_sum_batch(r, {s, 2 * s, 3 * s});
             i += 2;
         } else {

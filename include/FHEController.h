@@ -273,7 +273,7 @@ public:
             return;
         }
         // the reference's list (src/main.cpp:84) omits indices the circuit uses (quirk Q3): generate the union, plus the
-        // 3*2^i rotations that let the engine run two steps of a rotate-and-sum tree as one merged key switch
+        // 3*2^i (and 5s, 7s) rotations that let the engine run two (three) steps of a rotate-and-sum tree as one merged key switch
         vector<int32_t> all(rotations.begin(), rotations.end());
         for (int i = 0; i < 14; i++) {
             all.push_back(1 << i);
@@ -283,6 +283,11 @@ public:
             all.push_back(3 << i);
             all.push_back(-(3 << i));
         }
+        for (int s : {1, 8, 128, 1024})  // with s..7s three tree steps run as one merged key switch (6s = 3 * 2s is above)
+            for (int m : {5, 7}) {
+                all.push_back(m * s);
+                all.push_back(-m * s);
+            }
         fhelin_shim::check(fhelin_gen_rotation_keys(context, all.data(), (int32_t)all.size()), "EvalRotateKeyGen");
         if (serialize) {
             ofstream f("../" + parameters_folder + "/rot_" + filename, ios::out | ios::binary);

@@ -199,7 +199,10 @@ class ResidueEvaluator:
         i = 0
         while i < n:
             s = unit * (1 << i)
-            if i + 1 < n and merge and self.have([s, 2 * s, 3 * s]):
+            if i + 2 < n and merge and self.have([m * s for m in range(1, 8)]):
+                r = self.rotate_sum(r, [m * s for m in range(1, 8)])
+                i += 3
+            elif i + 1 < n and merge and self.have([s, 2 * s, 3 * s]):
                 r = self.rotate_sum(r, [s, 2 * s, 3 * s])
                 i += 2
             else:

@@ -245,7 +245,13 @@ def test_rotsum_repeat_default_knobs_bit_exact(engine_factory, orc, preset, over
     _same(eng.rotsum(c2, 4, 128), rev.rotsum(r2, 4, 128), "rotsum of a product: early rescale + one merged pair")
     _same(eng.repeat(c2, 32, 1), rev.repeat(r2, 32, 1), "repeat: two merged pairs + single step, negative steps")
     _same(eng.rotsum(c1, 1, 128), r1, "zero steps: a copy")
-    del keys
+    # with the keys of s..7s three steps run as one merged key switch: 5 steps = a triple + a pair
+    more = _keys(orc, eng, [m * 128 for m in (5, 6, 7)] + [1024, 2048, 3072], seed=777)
+    keys.update(more)
+    rev = _rev(orc, eng, keys)
+    _same(eng.rotsum(c2, 32, 128), rev.rotsum(r2, 32, 128), "rotsum: merged triple {s..7s} + merged pair")
+    _same(eng.rotsum(c1, 8, 128), rev.rotsum(r1, 8, 128), "rotsum: exactly one merged triple")
+    del keys, more
 
 
 def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
