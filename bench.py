@@ -332,8 +332,11 @@ def main():
             dist.barrier()
         t0 = time.perf_counter()
         logits = []
+        host_enqueue = 0.0
         for i in range(args.warmup * per_rank, n_samples):
+            th = time.perf_counter()
             out = lf.forward_encrypted(ctl, w, samples[i][1])
+            host_enqueue += time.perf_counter() - th           # host time to ISSUE the pass (the GPU runs behind asynchronously)
             logits.append(lf.logits_from_slots(eng.decrypt(out)))
         eng.sync()
         torch.cuda.synchronize()
@@ -378,7 +381,8 @@ def main():
             if rank == 0:
                 print(json.dumps({"metric": "encrypted Linformer-d128 forward ms/sample (profiling run)",
                                   "value": round(elapsed * 1e3 / (n_timed * world), 2), "unit": "ms/sample", "n_gpus": world,
-                                  "steps": args.steps, "warmup": args.warmup, "log_n": args.log_n, "ops_per_sample": stats}))
+                                  "steps": args.steps, "warmup": args.warmup, "log_n": args.log_n,
+                                  "host_issue_ms_per_sample": round(host_enqueue * 1e3 / n_timed, 2), "ops_per_sample": stats}))
             eng.close()
             if dist:
                 dist.destroy_process_group()

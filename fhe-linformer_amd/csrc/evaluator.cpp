@@ -25,6 +25,9 @@ EvalKey::~EvalKey() {
     if (d && ctx) {
         try { ctx->pool.free(d); } catch (...) {}
     }
+    if (d_perm && ctx) {
+        try { ctx->pool.free(d_perm); } catch (...) {}
+    }
 }
 
 static void launch_ok(const char* what) { hip_check(hipGetLastError(), what); }
@@ -207,6 +210,17 @@ bool Evaluator::have_rotation_keys(const std::vector<int>& indices, int slots) c
     return !indices.empty();
 }
 
+const u64* Evaluator::permuted(const EvalKey& key, const u32* map) {
+    if (key.d_perm) return key.d_perm;
+    const int nvec = key.digits * 2 * (c_.L + 1 + c_.K);
+    key.d_perm = c_.dalloc<u64>(key.words());
+    launch_automorph(c_.dt, key.d_perm, key.d, map, nvec, c_.stream);
+    launch_ok("key permutation");
+    // built once, read from every stream afterwards: finish it before anyone else can see the pointer
+    hip_check(hipStreamSynchronize(c_.stream), "key permutation sync");
+    return key.d_perm;
+}
+
 std::vector<CtPtr> Evaluator::rotate_sum_batch(const std::vector<CtPtr>& vin, const std::vector<int>& indices) {
     if (vin.empty()) return {};
     const int R = (int)indices.size();
@@ -246,7 +260,7 @@ std::vector<CtPtr> Evaluator::rotate_sum_batch(const std::vector<CtPtr>& vin, co
         KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, ctw, ctw, pn, ctw};
         sh.n_rot = R;
         for (int r = 0; r < R; ++r) {
-            sh.evk_rot[r] = keys[r]->d;
+            sh.evk_rot[r] = permuted(*keys[r], maps[r]);
             sh.map_rot[r] = maps[r];
         }
         // accounting in units of the reference's rotations: R = 2^k - 1 merged terms stand for k tree steps
@@ -362,8 +376,8 @@ CtPtr Evaluator::rotate_each_sum(const std::vector<CtPtr>& vin, const std::vecto
         sh.rot_input_stride = ctw;
         for (int r = 0; r < R; ++r) {
             const u64 g = c_.galois_element(ridx[first + r]);
-            sh.evk_rot[r] = rot_keys.at(g)->d;
             sh.map_rot[r] = c_.automorph_map(g);
+            sh.evk_rot[r] = permuted(*rot_keys.at(g), sh.map_rot[r]);
         }
         c_.stats.keyswitch += (u64)R;
         c_.stats.keyswitch_limbs += (u64)R * ell;

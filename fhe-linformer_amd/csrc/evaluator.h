@@ -64,6 +64,10 @@ typedef std::shared_ptr<Plaintext> PtPtr;
 struct EvalKey {
     Context* ctx = nullptr;
     u64* d = nullptr;  // [dnum][2][L+1+k][N] NTT form; component 0 = b, 1 = a
+    // the same key with every limb vector gathered through the key's own automorphism map (d_perm[v][n] = d[v][map_g[n]]):
+    // the merged rotation sums apply sigma_g to the inner product d * evk BEFORE the shared ModDown, so with this copy the
+    // key streams of ks_inner_multi are contiguous and only the digits are gathered.  Built on first use (Evaluator::permuted).
+    mutable u64* d_perm = nullptr;
     int digits = 0;
     ~EvalKey();
     size_t words() const { return (size_t)digits * 2 * (ctx->L + 1 + ctx->K) * ctx->N; }
@@ -110,6 +114,7 @@ public:
     // x += rot(x, 2s), are the call {s, 2s, 3s}.  All keys must exist (have_rotation_keys).
     std::vector<CtPtr> rotate_sum_batch(const std::vector<CtPtr>& v, const std::vector<int>& indices);
     bool have_rotation_keys(const std::vector<int>& indices, int slots) const;
+    const u64* permuted(const EvalKey& key, const u32* map);   // key.d_perm, built once
     // sum_i rot(v[i], indices[i]) for up to 7 ciphertexts of identical shape (index 0 = unrotated term allowed): every
     // term has its own ModUp and key, the inner products are accumulated in QP and share ONE ModDown (giant steps)
     CtPtr rotate_each_sum(const std::vector<CtPtr>& v, const std::vector<int>& indices);

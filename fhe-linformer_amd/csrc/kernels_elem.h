@@ -78,7 +78,7 @@ struct KsShape {
     // merged rotations (launch_ks_inner_multi): n_rot <= MAX_ROT rotations of every row are accumulated before ONE ModDown
     static constexpr int MAX_ROT = 7;
     int n_rot = 0;
-    const u64* evk_rot[MAX_ROT] = {};
+    const u64* evk_rot[MAX_ROT] = {};   // the keys in PERMUTED layout (EvalKey::d_perm): evk_rot[r][v][n] = key_r[v][map_rot[r][n]]
     const u32* map_rot[MAX_ROT] = {};
     // rot_input_stride > 0: rotation r acts on its OWN input (digits at ext + r * rot_ext_stride, polynomial at c + r *
     // rot_input_stride): a sum of rotations of different ciphertexts (giant steps) shares the one ModDown

@@ -151,65 +151,96 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
     }
 }
 
-// grid (N/256, batch*(ell + k)): one coefficient per thread (the gathered positions of neighbours are not adjacent)
+// r = mask_bit(lane) ? b : a with the lane mask in SGPRs (the VCC form of v_cndmask issues ~5x slower on gfx950)
+__device__ __forceinline__ u32 sel_mask(u32 a, u32 b, unsigned long long mask) {
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+    return r;
+}
+
+// grid (N/512, batch*(ell + k)): the coefficient pair (2m, 2m+1) per thread.  In the bit-reversed evaluation order an
+// automorphism map satisfies map[2m+1] = map[2m] ^ 1 (the two slots differ by psi^N = -1 in the evaluation point, which
+// multiplication of the exponent by the odd g preserves): a pair is gathered with ONE 16-byte load and swapped in
+// registers when map[2m] is odd.  The keys come pre-permuted (KsShape::evk_rot): their loads are contiguous.
 __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsShape sh, u64* __restrict__ accQ, u64* __restrict__ accP,
                                                              const u64* __restrict__ ext, const u64* __restrict__ c_ntt) {
     const int nt = sh.ell + sh.k;
     const int bi = blockIdx.y % sh.batch, tt = blockIdx.y / sh.batch;
     const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
-    const size_t N = (size_t)1 << t.log_n;
+    const size_t N = (size_t)1 << t.log_n, row = N >> 1;
     ext += (size_t)bi * sh.beta * nt * N;
     c_ntt += (size_t)bi * sh.c_stride;
     const int own = tt < sh.ell ? tt / sh.alpha : -1;
     accQ += (size_t)bi * 2 * sh.ell * N;
     accP += (size_t)bi * 2 * sh.k * N;
     const Barrett br = load_barrett(t, limb);
-    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t kstride = (size_t)(sh.L1 + sh.k) * N;  // one evk component
-    u64 lo[2] = {0, 0}, hi[2] = {0, 0};                 // b, a
-    Acc30 b = {0, 0, 0}, a = {0, 0, 0};
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t kstride = (size_t)(sh.L1 + sh.k) * row;  // one evk component, in u64x2 units
+    u64 lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};      // b.x, b.y, a.x, a.y
+    Acc30 b0 = {0, 0, 0}, b1 = {0, 0, 0}, a0 = {0, 0, 0}, a1 = {0, 0, 0};
     int pending = 0, folded = 0;
     for (int r = 0; r < sh.n_rot; ++r) {
-        const size_t m = sh.map_rot[r] ? (size_t)sh.map_rot[r][n] : n;
-        const u64* __restrict__ K = sh.evk_rot[r] + (size_t)limb * N + m;
-        const u64* __restrict__ er = ext + (size_t)r * sh.rot_ext_stride;
-        const u64* __restrict__ cr = c_ntt + (size_t)r * sh.rot_input_stride;
+        const u32 m0 = sh.map_rot[r] ? sh.map_rot[r][2 * n2] : (u32)(2 * n2);
+        const size_t mp = m0 >> 1;
+        const unsigned long long swp = __ballot((m0 & 1) != 0);
+        const u64x2* __restrict__ K = reinterpret_cast<const u64x2*>(sh.evk_rot[r]) + (size_t)limb * row + n2;
+        const u64x2* __restrict__ er = reinterpret_cast<const u64x2*>(ext + (size_t)r * sh.rot_ext_stride);
+        const u64x2* __restrict__ cr = reinterpret_cast<const u64x2*>(c_ntt + (size_t)r * sh.rot_input_stride);
         for (int j = 0; j < sh.beta; ++j) {
-            const u64 d = j == own ? cr[(size_t)tt * N + m] : er[((size_t)j * nt + tt) * N + m];
-            u32 d0, d1, k0, k1;
-            split30(d, d0, d1);
-            split30(K[(size_t)(2 * j) * kstride], k0, k1);
-            mac30(b, d0, d1, k0, k1);
-            split30(K[(size_t)(2 * j + 1) * kstride], k0, k1);
-            mac30(a, d0, d1, k0, k1);
+            const u64x2 d = j == own ? cr[(size_t)tt * row + mp] : er[((size_t)j * nt + tt) * row + mp];
+            const u64x2 kb = K[(size_t)(2 * j) * kstride], ka = K[(size_t)(2 * j + 1) * kstride];
+            u32 p0, p1, q0, q1, k0, k1;
+            split30(d.x, p0, p1);
+            split30(d.y, q0, q1);
+            // element 2m of the rotated digit is d.x, or d.y when the map sends 2m to an odd position
+            const u32 dx0 = sel_mask(p0, q0, swp), dx1 = sel_mask(p1, q1, swp), dy0 = sel_mask(q0, p0, swp), dy1 = sel_mask(q1, p1, swp);
+            split30(kb.x, k0, k1);
+            mac30(b0, dx0, dx1, k0, k1);
+            split30(kb.y, k0, k1);
+            mac30(b1, dy0, dy1, k0, k1);
+            split30(ka.x, k0, k1);
+            mac30(a0, dx0, dx1, k0, k1);
+            split30(ka.y, k0, k1);
+            mac30(a1, dy0, dy1, k0, k1);
             if (++pending == 8) {  // at most 8 products of 60-bit halves fit the 64-bit columns
-                acc30_flush(b, lo[0], hi[0]);
-                acc30_flush(a, lo[1], hi[1]);
-                b = Acc30{0, 0, 0};
-                a = Acc30{0, 0, 0};
+                acc30_flush(b0, lo[0], hi[0]);
+                acc30_flush(b1, lo[1], hi[1]);
+                acc30_flush(a0, lo[2], hi[2]);
+                acc30_flush(a1, lo[3], hi[3]);
+                b0 = b1 = a0 = a1 = Acc30{0, 0, 0};
                 pending = 0;
                 // barrett_reduce128 needs a sum below q * 2^64: 16 products of operands below 2^60 (special limbs:
                 // canonical digits and keys, 16 p^2 < p * 2^64; scaling limbs: digits below 86q, 16 * 86 q^2 < q * 2^64
                 // for q < 2^53) plus one carried residue.  R * beta can reach 28 (giant steps): fold every 16.
                 if (++folded == 2) {
-                    lo[0] = barrett_reduce128(lo[0], hi[0], br);
-                    lo[1] = barrett_reduce128(lo[1], hi[1], br);
-                    hi[0] = hi[1] = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        lo[i] = barrett_reduce128(lo[i], hi[i], br);
+                        hi[i] = 0;
+                    }
                     folded = 0;
                 }
             }
         }
     }
-    acc30_flush(b, lo[0], hi[0]);
-    acc30_flush(a, lo[1], hi[1]);
-    const u64 rb = barrett_reduce128(lo[0], hi[0], br), ra = barrett_reduce128(lo[1], hi[1], br);
+    acc30_flush(b0, lo[0], hi[0]);
+    acc30_flush(b1, lo[1], hi[1]);
+    acc30_flush(a0, lo[2], hi[2]);
+    acc30_flush(a1, lo[3], hi[3]);
+    u64x2 rb, ra;
+    rb.x = barrett_reduce128(lo[0], hi[0], br);
+    rb.y = barrett_reduce128(lo[1], hi[1], br);
+    ra.x = barrett_reduce128(lo[2], hi[2], br);
+    ra.y = barrett_reduce128(lo[3], hi[3], br);
     if (tt < sh.ell) {
-        accQ[(size_t)tt * N + n] = rb;
-        accQ[(size_t)(sh.ell + tt) * N + n] = ra;
+        u64x2* O = reinterpret_cast<u64x2*>(accQ);
+        O[(size_t)tt * row + n2] = rb;
+        O[(size_t)(sh.ell + tt) * row + n2] = ra;
     } else {
+        u64x2* O = reinterpret_cast<u64x2*>(accP);
         const int pj = tt - sh.ell;
-        accP[(size_t)pj * N + n] = rb;
-        accP[(size_t)(sh.k + pj) * N + n] = ra;
+        O[(size_t)pj * row + n2] = rb;
+        O[(size_t)(sh.k + pj) * row + n2] = ra;
     }
 }
 
@@ -324,8 +355,10 @@ __global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsS
         for (int rr = 0; rr < sh.n_rot; ++rr) {
             const u64* __restrict__ gr = g + (size_t)rr * sh.rot_input_stride;
             const u32* __restrict__ mr = sh.map_rot[rr];
-            r.x = add_mod(r.x, gr[mr ? (size_t)mr[j] : j], q);
-            r.y = add_mod(r.y, gr[mr ? (size_t)mr[j + 1] : j + 1], q);
+            const u32 m0 = mr ? mr[j] : (u32)j;                          // map[j + 1] = map[j] ^ 1: one 16-byte load per pair
+            const u64x2 gp = reinterpret_cast<const u64x2*>(gr)[m0 >> 1];
+            r.x = add_mod(r.x, (m0 & 1) ? gp.y : gp.x, q);
+            r.y = add_mod(r.y, (m0 & 1) ? gp.x : gp.y, q);
         }
     }
     reinterpret_cast<u64x2*>(out)[((size_t)v * N + j) >> 1] = r;
@@ -351,7 +384,7 @@ void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* a
 }
 void launch_ks_inner_multi(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* c_ntt,
                            hipStream_t s) {
-    dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * (sh.ell + sh.k)));
+    dim3 g((1u << t.log_n) / 512, (unsigned)(sh.batch * (sh.ell + sh.k)));
     hipLaunchKernelGGL(ks_inner_multi_kernel, g, dim3(256), 0, s, t, sh, accQ, accP, ext, c_ntt);
 }
 void launch_gather_sum(const DeviceTables& t, const KsShape& sh, u64* out, const u64* in, size_t in_stride, hipStream_t s) {
