@@ -14,6 +14,7 @@ static bool env_flag(const char* name) {  // unset or non-zero = on
 Composite::Composite(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {
     early_rescale_ = env_flag("FHELIN_EARLY_RESCALE");  // read per context, so that one process can hold both kinds
     merge_rot_ = env_flag("FHELIN_MERGE_ROT");
+    if (const char* e = std::getenv("FHELIN_ROW_LANES")) row_lanes_ = std::atoi(e) != 0;
     if (const char* b = std::getenv("FHELIN_BATCH")) {
         int v = std::atoi(b);
         if (v >= 1 && v <= 256) ev_.batch_limit = v;
@@ -189,7 +190,7 @@ CtVec Composite::tree_batch(const CtVec& in_raw, int slots, int step_sign, int p
     }
     Context& c = ev_.ctx();
     const size_t B = (size_t)std::max(1, ev_.batch_limit);
-    const bool lanes = c.n_lanes > 0 && in.size() > B;
+    const bool lanes = row_lanes_ && c.n_lanes > 0 && in.size() > B;
     if (lanes) c.fork_lanes();
     int k = 0;
     for (size_t lo = 0; lo < in.size(); lo += B, ++k) {

@@ -75,6 +75,7 @@ private:
     std::map<std::string, PtPtr> mask_cache_;
     bool early_rescale_ = true;   // FHELIN_EARLY_RESCALE: rescale a fresh product before its rotation tree
     bool merge_rot_ = true;       // FHELIN_MERGE_ROT: two tree steps as one merged key switch when the 3s key exists
+    bool row_lanes_ = false;      // FHELIN_ROW_LANES: row chunks of a tree on separate streams (off: measured slower)
     PtPtr mask_plain(const std::string& key, const std::vector<double>& v);
 };
 
