@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["forward", "ntt", "ops"], default="forward")
     ap.add_argument("--batch", type=int, default=0, help="samples per step over ALL ranks (0: one per rank per step)")
+    ap.add_argument("--shard-rows", action="store_true", help="batch-1 latency mode: ONE sample per step, the rows inside its matmul / "
+                    "unwrap loops split over the ranks (all-gather of ciphertext rows over RCCL/xGMI per row loop)")
     ap.add_argument("--no-ops", action="store_true", help="skip the short leaf-op section of a forward run")
     ap.add_argument("--forward-only", action="store_true", help="profiling runs: only the timed forward passes (no eager comparison, "
                     "no NTT / op sections, no CPU leg); prints a reduced line without `roofline`")
@@ -307,6 +309,9 @@ def main():
         w = pf.synthetic_model(1234)
         S = args.tokens
         ctl = lf.GpuController(eng)
+        row_mode = bool(args.shard_rows and dist)
+        if row_mode:
+            ctl = shard.RowShardedController(ctl, dist, shard.EngineTransport(eng, device=args.dist_backend == "nccl"))
         if dist:
             # keys replicated: every rank must hold the same secret (same seed -> same ChaCha20 stream -> same keys)
             sk = np.frombuffer(eng.secret_seed(), dtype=np.uint8).astype(np.float64).reshape(1, -1)
@@ -318,7 +323,7 @@ def main():
         t_client = time.perf_counter()
         for i in range(n_samples):                           # every step gets its own samples (seeded per rank)
             timed_idx = i - args.warmup * per_rank
-            x = pf.synthetic_tokens(S, 4321 + 100000 * rank + max(0, timed_idx))
+            x = pf.synthetic_tokens(S, 4321 + (0 if row_mode else 100000 * rank) + max(0, timed_idx))   # row mode: every rank, same sample
             x_in, X_E, X_F = pf.client_inputs(w, x)
             samples.append((x, lf.encrypt_inputs(ctl, x_in, X_E, X_F)))   # client side: resident in HBM before timing
         eng.sync()
@@ -435,16 +440,18 @@ def main():
                     "algorithmic_bytes_per_limb_ntt": alg_bytes,
                     "note": "64-bit modular-integer butterflies: bound by VALU issue slots (88 % busy, 15 instr/butterfly), ceiling ~2.3 TB/s algorithmic at the sustained clock (DESIGN.md §6)"}
         if args.workload == "forward":
-            value = fwd["elapsed"] * 1e3 / (args.steps * per_rank * world)
+            value = fwd["elapsed"] * 1e3 / (args.steps * per_rank * (1 if row_mode else world))
             line = {
                 "metric": "encrypted Linformer-d128 forward ms/sample", "value": round(value, 2), "unit": "ms/sample",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(fwd["elapsed"] * 1e3 / args.steps, 2), "higher_is_better": False,
-                "scaling": "strong" if args.batch > 0 else "weak",
+                "scaling": "strong" if (args.batch > 0 or row_mode) else "weak",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                 "config": {"workload": f"forward: {per_rank} sample(s)/GPU/step, S={args.tokens}+CLS tokens, d=128, k=32, FFN 512, 20 classes, "
                                        f"N=2^{eng.log_n}, 16384 slots, {eng.n_q}+{eng.n_p} limbs, dnum 4, 8 bootstraps",
-                           "ops_per_sample": fwd["stats"], "parallelism": f"independent samples x{world}, keys replicated (one key seed)",
+                           "ops_per_sample": fwd["stats"],
+                           "parallelism": (f"ONE sample per step, rows of its matmul / unwrap loops over {world} ranks, keys replicated"
+                                           if row_mode else f"independent samples x{world}, keys replicated (one key seed)"),
                            "logit_err_vs_circuit_oracle": round(fwd["logit_err_vs_circuit_oracle"], 5),
                            "samples_checked_vs_circuit_oracle": fwd["samples_checked"],
                            "deferred_rows": "on: rows of matmulRE / unwrapExpanded that no later call reads are not evaluated "

@@ -112,6 +112,10 @@ def load_library():
         "fhelin_ct_import": (i32, [vp, vp, i32, i32, i32, C.c_double, i32, C.POINTER(vp)]),
         "fhelin_ct_export": (i32, [vp, vp, vp, C.c_size_t]),
         "fhelin_ct_info": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(i32)]),
+        "fhelin_ct_export_device": (i32, [vp, vp, vp, C.c_size_t]),
+        "fhelin_ct_import_device": (i32, [vp, vp, i32, i32, i32, C.c_double, C.c_double, i32, C.POINTER(vp)]),
+        "fhelin_ct_scale": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "fhelin_fc_unwrapRepeatedLarge_range": (i32, [vp, C.POINTER(vp), i32, i32, i32, i32, C.POINTER(vp)]),
         "fhelin_ct_clone": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_ct_free": (None, [vp]),
         "fhelin_add": (i32, [vp, vp, vp, C.POINTER(vp)]),
@@ -636,6 +640,17 @@ class Engine:
         flat = self._cts(outs, 4 * input_number)
         return [flat[4 * i: 4 * i + 4] for i in range(input_number)]
 
+    def unwrapRepeatedLarge_range(self, containers, input_number, first, count):
+        outs = self._outs(4 * count)
+        self._ck(self.lib.fhelin_fc_unwrapRepeatedLarge_range(self.h, self._harr(containers), len(containers), input_number, first, count, outs))
+        flat = self._cts(outs, 4 * count)
+        return [flat[4 * i: 4 * i + 4] for i in range(count)]
+
+    def ct_import_device(self, dptr, npoly, ell, deg, scale_hi, scale_lo, slots):
+        h = C.c_void_p()
+        self._ck(self.lib.fhelin_ct_import_device(self.h, C.c_void_p(dptr), npoly, ell, deg, scale_hi, scale_lo, slots, C.byref(h)))
+        return Ct(self, h)
+
     def generate_containers(self, inputs, bias=None):
         cap = (len(inputs) + 31) // 32
         outs = self._outs(cap)
@@ -685,6 +700,14 @@ class Ct:
         out = np.empty((inf["npoly"], inf["ell"], self.eng.N), dtype=np.uint64)
         self.eng._ck(self.eng.lib.fhelin_ct_export(self.eng.h, self.h, out.ctypes.data_as(C.c_void_p), out.size))
         return out
+
+    def scale_parts(self):
+        hi, lo = C.c_double(), C.c_double()
+        self.eng._ck(self.eng.lib.fhelin_ct_scale(self.h, C.byref(hi), C.byref(lo)))
+        return hi.value, lo.value
+
+    def export_device(self, dptr, cap_words):
+        self.eng._ck(self.eng.lib.fhelin_ct_export_device(self.eng.h, self.h, C.c_void_p(dptr), cap_words))
 
     def clone(self):
         return self.eng._un(self.eng.lib.fhelin_ct_clone, self)

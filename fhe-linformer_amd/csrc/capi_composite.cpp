@@ -244,6 +244,14 @@ int fhelin_fc_unwrapRepeatedLarge(fhelin_ctx* c, const fhelin_ct* const* contain
     for (size_t i = 0; i < r.size(); ++i) emit(r[i], outs + 4 * i);
     FHELIN_CATCH
 }
+int fhelin_fc_unwrapRepeatedLarge_range(fhelin_ctx* c, const fhelin_ct* const* containers, int32_t nc, int32_t input_number,
+                                        int32_t first, int32_t count, fhelin_ct** outs) {
+    NEED(c && containers && outs);
+    FHELIN_TRY
+    auto r = c->comp.unwrapRepeatedLarge(vec_of(c, containers, nc), input_number, first, count);
+    for (size_t i = 0; i < r.size(); ++i) emit(r[i], outs + 4 * i);
+    FHELIN_CATCH
+}
 int fhelin_fc_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs, int32_t n, const fhelin_pt* bias,
                                   fhelin_ct** outs, int32_t* n_out) {
     NEED(c && inputs && outs);

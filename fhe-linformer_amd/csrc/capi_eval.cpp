@@ -157,6 +157,39 @@ int fhelin_ct_export(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* out, size_t c
     c->ctx.sync();
     FHELIN_CATCH
 }
+int fhelin_ct_export_device(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* d_out, size_t cap) {
+    NEED(c && ct && d_out);
+    FHELIN_TRY
+    const CtPtr& p = ct_in(c, ct);
+    if (cap < p->words()) throw Error(FHELIN_ERR_ARG, "buffer too small");
+    hip_check(hipMemcpyAsync(d_out, p->d, p->words() * 8, hipMemcpyDeviceToDevice, c->ctx.stream), "ct export (device)");
+    c->ctx.sync();   // the caller's framework reads the buffer on its own stream next
+    FHELIN_CATCH
+}
+int fhelin_ct_import_device(fhelin_ctx* c, const uint64_t* d_limbs, int32_t npoly, int32_t ell, int32_t deg, double scale_hi,
+                            double scale_lo, int32_t slots, fhelin_ct** out) {
+    NEED(c && d_limbs && out);
+    FHELIN_TRY
+    CtPtr p = c->ev.new_ct(npoly, ell, deg, (long double)scale_hi + (long double)scale_lo, slots);
+    hip_check(hipMemcpyAsync(p->d, d_limbs, p->words() * 8, hipMemcpyDeviceToDevice, c->ctx.stream), "ct import (device)");
+    c->ctx.sync();
+    *out = wrap(p);
+    FHELIN_CATCH
+}
+int fhelin_ct_scale(const fhelin_ct* ct, double* scale_hi, double* scale_lo) {
+    NEED(ct && scale_hi && scale_lo);
+    if (!ct->p && ct->lazy) {
+        try {
+            force(ct->owner, ct);
+        } catch (const std::exception& e) {
+            return capi_fail(FHELIN_ERR_INTERNAL, e.what());
+        }
+    }
+    const long double s = ct->p->scale;
+    *scale_hi = (double)s;
+    *scale_lo = (double)(s - (long double)*scale_hi);
+    return FHELIN_OK;
+}
 int fhelin_ct_info(const fhelin_ct* ct, int32_t* npoly, int32_t* ell, int32_t* level, int32_t* deg, double* scale, int32_t* slots) {
     NEED(ct);
     if (!ct->p && ct->lazy) {  // a deferred row: its shape is known only once evaluated

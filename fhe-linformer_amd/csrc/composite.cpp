@@ -408,7 +408,9 @@ CtVec Composite::unwrap_512_in_4_128(const CtPtr& c, int index) {
     return result;
 }
 
-std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int input_number) {
+std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int input_number, int first, int count) {
+    if (count < 0) count = input_number - first;
+    if (first < 0 || first + count > input_number) throw Error(FHELIN_ERR_ARG, "unwrapRepeatedLarge: token range out of bounds");
     std::vector<int> quantities;
     for (int i = 0; i < input_number / 32.0; ++i) {
         int q = 32;
@@ -420,11 +422,14 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
     CtVec src;
     std::vector<PtPtr> masks;
     for (size_t i = 0; i < containers.size() && i < quantities.size(); ++i)
-        for (int j = 0; j < quantities[i]; ++j)
+        for (int j = 0; j < quantities[i]; ++j) {
+            const int token = (int)i * 32 + j;
+            if (token < first || token >= first + count) continue;
             for (int k = 0; k < 4; ++k) {
                 src.push_back(containers[i]);
                 masks.push_back(block_mask(j * 512 + 128 * k, j * 512 + 128 * (k + 1), 1));
             }
+        }
     CtVec rep = repeat_batch(ev_.mult_plain_each(src, masks), 128, -128);
     std::vector<CtVec> out;
     for (size_t i = 0; i + 3 < rep.size(); i += 4) out.push_back(CtVec(rep.begin() + i, rep.begin() + i + 4));

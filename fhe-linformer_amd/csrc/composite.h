@@ -65,7 +65,8 @@ public:
     CtVec unwrapExpanded_rows(CtPtr c, int inputs_num, const std::vector<int>& idx);
     CtVec unwrapScoresExpanded(CtPtr c, int inputs_num);
     CtVec unwrap_512_in_4_128(const CtPtr& c, int index);
-    std::vector<CtVec> unwrapRepeatedLarge(const CtVec& containers, int input_number);
+    // tokens [first, first + count) only (count < 0: all)
+    std::vector<CtVec> unwrapRepeatedLarge(const CtVec& containers, int input_number, int first = 0, int count = -1);
     CtVec generate_containers(const CtVec& inputs, const PtPtr& bias);
     CtPtr wrap_containers(const CtVec& c, int inputs_number);
 

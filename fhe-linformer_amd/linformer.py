@@ -133,6 +133,9 @@ class GpuController:
     def unwrapRepeatedLarge(self, cs, n):
         return self.e.unwrapRepeatedLarge(cs, n)
 
+    def unwrapRepeatedLarge_range(self, cs, n, first, count):
+        return self.e.unwrapRepeatedLarge_range(cs, n, first, count)
+
     def generate_containers(self, inputs, bias=None):
         return self.e.generate_containers(inputs, bias)
 

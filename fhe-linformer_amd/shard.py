@@ -40,3 +40,184 @@ def max_over_ranks(dist, value):
     t = torch.tensor([float(value)], dtype=torch.float64, device=_device(dist))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- second sharding axis: the rows inside one sample's matmul / unwrap loops (batch-1 latency on several GPUs) ---------
+class SlotTransport:
+    """ciphertexts are plain slot vectors (oracle.circuit_sim.SlotSimController): what the gloo tests exchange"""
+
+    def pack(self, ct):
+        a = np.asarray(ct, dtype=np.float64).reshape(-1)
+        return a.view(np.uint8), np.zeros(8)
+
+    def unpack(self, payload, meta):
+        return payload.view(np.float64).copy()
+
+
+class EngineTransport:
+    """ciphertexts of fhe_linformer_amd.Engine: residues + (npoly, ell, deg, slots, scale hi/lo).  With the nccl backend the
+    residues go GPU -> GPU through device buffers (fhelin_ct_export_device / fhelin_ct_import_device, RCCL over xGMI);
+    with gloo (rehearsal, tests) through host arrays."""
+
+    def __init__(self, eng, device=False):
+        self.eng, self.device = eng, device
+
+    def pack(self, ct):
+        inf = ct.info()
+        hi, lo = ct.scale_parts()
+        meta = np.array([inf["npoly"], inf["ell"], inf["deg"], inf["slots"], hi, lo, 0, 0], dtype=np.float64)
+        if self.device:
+            import torch
+            words = inf["npoly"] * inf["ell"] * self.eng.N
+            t = torch.empty(words * 8, dtype=torch.uint8, device="cuda")
+            ct.export_device(t.data_ptr(), words)
+            return t, meta
+        return ct.export().reshape(-1).view(np.uint8), meta
+
+    def unpack(self, payload, meta):
+        npoly, ell, deg, slots = (int(meta[i]) for i in range(4))
+        words = npoly * ell * self.eng.N
+        if self.device:
+            return self.eng.ct_import_device(payload.data_ptr(), npoly, ell, deg, float(meta[4]), float(meta[5]), slots)
+        limbs = np.ascontiguousarray(payload[: words * 8]).view(np.uint64).reshape(npoly, ell, self.eng.N)
+        return self.eng.ct_import(limbs, deg=deg, scale=float(meta[4]), slots=slots)
+
+
+def all_gather_rows(dist, transport, local, n_rows, world):
+    """local: {row index: ciphertext} of this rank's rows (sample_ids partition) -> list of all n_rows ciphertexts, the
+    same objects on every rank (the owner re-imports its own rows too, so that every replica continues from identical
+    bytes).  One metadata all-gather and one payload all-gather (RCCL over xGMI with nccl)."""
+    import torch
+    rank = dist.get_rank()
+    per = -(-n_rows // world)
+    ids = sample_ids(n_rows, world, rank)
+    packed = [transport.pack(local[i]) for i in ids]
+    dev = _device(dist)
+    meta = torch.zeros((per, 8), dtype=torch.float64, device=dev)
+    size = torch.zeros(1, dtype=torch.int64, device=dev)
+    for k, (p, m) in enumerate(packed):
+        meta[k] = torch.as_tensor(m, dtype=torch.float64)
+        size[0] = max(int(size[0]), int(p.numel() if hasattr(p, "numel") else p.size))
+    dist.all_reduce(size, op=dist.ReduceOp.MAX)
+    row_bytes = int(size[0])
+    buf = torch.zeros((per, row_bytes), dtype=torch.uint8, device=dev)
+    for k, (p, _) in enumerate(packed):
+        t = p if hasattr(p, "numel") else torch.from_numpy(np.ascontiguousarray(p))
+        buf[k, : t.numel()] = t.to(dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    dist.all_gather(bufs, buf)
+    out = [None] * n_rows
+    for r in range(world):
+        for k, i in enumerate(sample_ids(n_rows, world, r)):
+            payload = bufs[r][k] if getattr(transport, "device", False) else bufs[r][k].cpu().numpy()
+            out[i] = transport.unpack(payload, metas[r][k].cpu().numpy())
+    return out
+
+
+class RowShardedController:
+    """Batch-1 latency on `world` GPUs: every rank holds the same keys and runs the same driver; the row loops of the
+    reference's matmul* / unwrap* methods (src/FHEController.cpp:872,888,904,918,949,963,985,1001,1089,1115) are split
+    over the ranks with `sample_ids`, each rank evaluates only its rows, and one all-gather per call puts all rows back on
+    every rank (the driver's next call — a wrapUp*, a bootstrap, the next matmul — is replicated).  With the engine's
+    deferred rows the split costs nothing extra: a rank simply never reads the rows it does not own.
+    Calls with fewer rows than `min_rows` stay replicated."""
+
+    def __init__(self, inner, dist, transport, min_rows=8):
+        self.c, self.dist, self.t = inner, dist, transport
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.min_rows = min_rows
+        self.gathers = 0
+
+    def __getattr__(self, name):            # everything that is not a row loop: replicated, as the inner controller does it
+        return getattr(self.c, name)
+
+    def _mine(self, n):
+        return sample_ids(n, self.world, self.rank)
+
+    def _gather(self, local, n):
+        self.gathers += 1
+        return all_gather_rows(self.dist, self.t, local, n, self.world)
+
+    def _rows(self, n, all_rows_fn, subset_fn=None):
+        """all_rows_fn() -> n row handles of which only the owned ones are read (deferred rows), or subset_fn(ids) -> the
+        owned rows only"""
+        if self.world == 1 or n < self.min_rows:
+            return all_rows_fn()
+        ids = self._mine(n)
+        if subset_fn is not None:
+            got = subset_fn(ids)
+            return self._gather(dict(zip(ids, got)), n)
+        rows = all_rows_fn()
+        return self._gather({i: rows[i] for i in ids}, n)
+
+    def matmulRE(self, rows, w, bias=None, row_size=128, padding=128):
+        if not _is_ct(w):       # plaintext weight: deferred rows, a rank reads (= evaluates) only the rows it owns
+            return self._rows(len(rows), lambda: self.c.matmulRE(rows, w, bias, row_size, padding))
+        return self._rows(len(rows), lambda: self.c.matmulRE(rows, w, bias, row_size, padding),
+                          lambda ids: self.c.matmulRE([rows[i] for i in ids], w, bias, row_size, padding))
+
+    def matmulCR(self, rows, w, bias=None):
+        return self._rows(len(rows), lambda: self.c.matmulCR(rows, w, bias))
+
+    def matmulRElarge(self, rows, weights, bias, mask_val=1.0):
+        return self._rows(len(rows), lambda: self.c.matmulRElarge(rows, weights, bias, mask_val),
+                          lambda ids: self.c.matmulRElarge([rows[i] for i in ids], weights, bias, mask_val))
+
+    def matmulCRlarge(self, rows, weights, bias):
+        return self._rows(len(rows), lambda: self.c.matmulCRlarge(rows, weights, bias),
+                          lambda ids: self.c.matmulCRlarge([rows[i] for i in ids], weights, bias))
+
+    def unwrapExpanded(self, c, n):
+        return self._rows(n, lambda: self.c.unwrapExpanded(c, n))
+
+    def unwrapRepeatedLarge(self, cs, n):
+        if self.world == 1 or n < self.min_rows:
+            return self.c.unwrapRepeatedLarge(cs, n)
+        ids = self._mine(n)
+        if hasattr(self.c, "unwrapRepeatedLarge_range"):
+            mine = self.c.unwrapRepeatedLarge_range(cs, n, ids[0], len(ids)) if ids else []
+        else:
+            allr = self.c.unwrapRepeatedLarge(cs, n)
+            mine = [allr[i] for i in ids]
+        flat = {4 * i + k: mine[j][k] for j, i in enumerate(ids) for k in range(4)}
+        # 4 ciphertexts per token: gather them as 4n rows owned in blocks of 4
+        out = all_gather_rows_blocked(self.dist, self.t, flat, n, self.world, 4)
+        self.gathers += 1
+        return [out[4 * i: 4 * i + 4] for i in range(n)]
+
+
+def _is_ct(x):
+    return x.__class__.__name__ == "Ct"
+
+
+def all_gather_rows_blocked(dist, transport, local, n_groups, world, group):
+    """like all_gather_rows for n_groups groups of `group` consecutive rows, ownership by group"""
+    import torch
+    rank = dist.get_rank()
+    per = -(-n_groups // world) * group
+    dev = _device(dist)
+    mine = [g * group + k for g in sample_ids(n_groups, world, rank) for k in range(group)]
+    packed = [transport.pack(local[i]) for i in mine]
+    size = torch.zeros(1, dtype=torch.int64, device=dev)
+    for p, _ in packed:
+        size[0] = max(int(size[0]), int(p.numel() if hasattr(p, "numel") else p.size))
+    dist.all_reduce(size, op=dist.ReduceOp.MAX)
+    meta = torch.zeros((per, 8), dtype=torch.float64, device=dev)
+    buf = torch.zeros((per, int(size[0])), dtype=torch.uint8, device=dev)
+    for k, (p, m) in enumerate(packed):
+        meta[k] = torch.as_tensor(m, dtype=torch.float64)
+        t = p if hasattr(p, "numel") else torch.from_numpy(np.ascontiguousarray(p))
+        buf[k, : t.numel()] = t.to(dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    dist.all_gather(bufs, buf)
+    out = [None] * (n_groups * group)
+    for r in range(world):
+        idx = [g * group + k for g in sample_ids(n_groups, world, r) for k in range(group)]
+        for k, i in enumerate(idx):
+            payload = bufs[r][k] if getattr(transport, "device", False) else bufs[r][k].cpu().numpy()
+            out[i] = transport.unpack(payload, metas[r][k].cpu().numpy())
+    return out

@@ -144,6 +144,12 @@ int fhelin_decrypt(fhelin_ctx* c, const fhelin_ct* ct, double* out, int32_t slot
 int fhelin_ct_import(fhelin_ctx* c, const uint64_t* limbs, int32_t npoly, int32_t ell, int32_t deg, double scale,
                      int32_t slots, fhelin_ct** out);
 int fhelin_ct_export(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* out, size_t cap_words);
+/* the same with DEVICE buffers (a torch / RCCL tensor): ciphertext rows exchanged between the GPUs of a node travel
+ * without a host round trip.  The scale is the library's 80-bit value as hi + lo doubles. */
+int fhelin_ct_export_device(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* d_out, size_t cap_words);
+int fhelin_ct_import_device(fhelin_ctx* c, const uint64_t* d_limbs, int32_t npoly, int32_t ell, int32_t deg, double scale_hi,
+                            double scale_lo, int32_t slots, fhelin_ct** out);
+int fhelin_ct_scale(const fhelin_ct* ct, double* scale_hi, double* scale_lo);
 int fhelin_ct_info(const fhelin_ct* ct, int32_t* npoly, int32_t* ell, int32_t* level, int32_t* deg, double* scale,
                    int32_t* slots);                                                     /* ct->GetLevel() / GetSlots()  */
 int fhelin_ct_clone(fhelin_ctx* c, const fhelin_ct* ct, fhelin_ct** out);                /* ct->Clone()  (main.cpp:223) */
@@ -219,6 +225,9 @@ int fhelin_fc_unwrap_512_in_4_128(fhelin_ctx* c, const fhelin_ct* a, int32_t ind
 /* outs: input_number x 4 handles, row-major */
 int fhelin_fc_unwrapRepeatedLarge(fhelin_ctx* c, const fhelin_ct* const* containers, int32_t nc, int32_t input_number,
                                   fhelin_ct** outs);                                                    /* :1102 */
+/* the tokens [first, first + count) only (rows partitioned over the GPUs of a node): outs = count x 4 handles */
+int fhelin_fc_unwrapRepeatedLarge_range(fhelin_ctx* c, const fhelin_ct* const* containers, int32_t nc, int32_t input_number,
+                                        int32_t first, int32_t count, fhelin_ct** outs);
 /* outs must hold ceil(n/32) handles; *n_out receives the count */
 int fhelin_fc_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs, int32_t n, const fhelin_pt* bias,
                                   fhelin_ct** outs, int32_t* n_out);                                    /* :1164 */

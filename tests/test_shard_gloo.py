@@ -60,3 +60,59 @@ def test_sample_partition_properties():
             assert got == list(range(total))
             sizes = [len(shard.sample_ids(total, world, r)) for r in range(world)]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _row_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from fhe_linformer_amd import shard, linformer as lf
+    from oracle import plain_forward as pf, circuit_sim as cs
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = pf.synthetic_model(1234)
+    x_in, X_E, X_F = pf.client_inputs(w, pf.synthetic_tokens(129, 4321))
+    ctl = shard.RowShardedController(cs.SlotSimController(), dist, shard.SlotTransport())
+    out = {}
+    for variant in ("main", "main_2"):
+        ctl.gathers = 0
+        out[variant] = (lf.logits_from_slots(lf.forward(ctl, w, x_in, X_E, X_F, None, variant)).tolist(), ctl.gathers)
+    # ragged row counts through the gather itself: 5 rows over 2 ranks, 4-row groups of 3 tokens
+    rows = {i: np.full(16, 10.0 * i) for i in shard.sample_ids(5, world, rank)}
+    got = shard.all_gather_rows(dist, shard.SlotTransport(), rows, 5, world)
+    blk = {4 * g + k: np.full(8, 100.0 * g + k) for g in shard.sample_ids(3, world, rank) for k in range(4)}
+    gotb = shard.all_gather_rows_blocked(dist, shard.SlotTransport(), blk, 3, world, 4)
+    dist.barrier()
+    q.put((rank, out, [float(g[0]) for g in got], [float(g[0]) for g in gotb]))
+    dist.destroy_process_group()
+
+
+def test_rows_of_one_sample_shard_over_two_ranks():
+    """the second sharding axis: the row loops inside matmul* / unwrap* of ONE sample are split over the
+    ranks and re-assembled by an all-gather per call; with the clear-text controller the logits must equal the unsharded
+    run exactly, on every rank, for both driver variants"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from fhe_linformer_amd import linformer as lf
+    from oracle import plain_forward as pf, circuit_sim as cs
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_row_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w = pf.synthetic_model(1234)
+    x_in, X_E, X_F = pf.client_inputs(w, pf.synthetic_tokens(129, 4321))
+    for variant in ("main", "main_2"):
+        ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, x_in, X_E, X_F, None, variant))
+        for rank, out, _, _ in res:
+            logits, gathers = out[variant]
+            assert np.array_equal(np.array(logits), ref), (variant, rank)
+            assert gathers >= 8                     # Q/K/V, W_O, both FFN matmuls, the unwraps: every row loop was split
+    for _, _, rows, blk in res:
+        assert rows == [0.0, 10.0, 20.0, 30.0, 40.0]
+        assert blk == [100.0 * g + k for g in range(3) for k in range(4)]
