@@ -243,19 +243,20 @@ CtVec Composite::matmul_ct(const CtVec& rows, const CtPtr& w, int slots, int pad
 }
 
 CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias, double mask_val) {
-    // per input the reference computes (:915-944) res = sum_j rot(mask(rotsum(x * W_j)), -128 (3-j)) + bias; inputs are
-    // independent, so each block j is evaluated for all inputs together
+    // per input the reference computes (:915-944) res = sum_j rot(mask_first_128(rotsum(x * W_j)), -128 (j-th shift)) + bias, the
+    // shifts as chains of two rotations by -64 (:934-935).  rotsum(., 128, 128) leaves a vector that repeats with period 128,
+    // so "mask the first block, then shift it to block j" selects the same slots as masking block j directly: the 3
+    // rotations per input are not needed at all (FHELIN_MERGE_ROT=0 keeps the reference's masks and shifts).  Inputs are
+    // independent: each block j is evaluated for all inputs together.
     CtVec res(inputs.size());
+    const bool direct = merge_rot_;
     for (int j = (int)weights.size() - 1; j >= 0; --j) {
         CtVec outs = rotsum_batch(ev_.mult_plain_batch(inputs, weights[j]), 128, 128);
-        CtVec masked = ev_.mult_plain_batch(outs, first_n_mask(128, mask_val));
+        CtVec masked = ev_.mult_plain_batch(outs, direct ? block_mask(128 * j, 128 * (j + 1), mask_val) : first_n_mask(128, mask_val));
         if (j == (int)weights.size() - 1) {
             res = masked;
         } else {
-            // the reference rotates by -64 twice (:934-935); one rotation by -128 moves the same slots
-            if (merge_rot_ && ev_.have_rotation_keys({-128}, res[0]->slots)) {
-                res = ev_.rotate_batch(res, -128);
-            } else {
+            if (!direct) {
                 res = ev_.rotate_batch(res, -64);
                 res = ev_.rotate_batch(res, -64);
             }

@@ -1,6 +1,6 @@
 """Residue-level restatement of the evaluator's LEVELED operations and of the composite circuit ops as the
 product runs them BY DEFAULT (merged rotate-and-sum steps, products rescaled before their rotation trees,
-log-depth shift trees, one rotation by -128).  TEST INFRASTRUCTURE (part of oracle/).
+log-depth shift trees, block masks in place of the -128 shifts of matmulRElarge).  TEST INFRASTRUCTURE (part of oracle/).
 
 Every function is an exact integer function of its inputs, composed from oracle/fhe_oracle.c (orc_mul, orc_add,
 orc_mul_scalar, orc_rescale, orc_rotate, orc_rotate_sum, ...): the GPU library must return the same residues bit for
@@ -248,19 +248,14 @@ class ResidueEvaluator:
             out = [self.add_plain(o, bias_enc) for o in out]
         return out
 
-    def matmulRElarge(self, rows, w_encs, bias_enc, mask_enc):
+    def matmulRElarge(self, rows, w_encs, bias_enc, mask_encs):
+        """sum_j mask_block_j(rotsum(x * W_j)) + bias: the rotsum output repeats with period 128, so masking block j directly
+        selects what the reference's mask-first-block-then-shift does (composite.cpp matmulRElarge); mask_encs[j] = block j"""
         res = None
         for j in range(len(w_encs) - 1, -1, -1):
             outs = [self.rotsum(self.mult_plain(r, w_encs[j]), 128, 128) for r in rows]
-            masked = [self.mult_plain(o, mask_enc) for o in outs]
-            if res is None:
-                res = masked
-            else:
-                if self.have([-128]):
-                    res = [self.rotate(r, -128) for r in res]
-                else:
-                    res = [self.rotate(self.rotate(r, -64), -64) for r in res]
-                res = [self.add(r, m) for r, m in zip(res, masked)]
+            masked = [self.mult_plain(o, mask_encs[j]) for o in outs]
+            res = masked if res is None else [self.add(r, m) for r, m in zip(res, masked)]
         if bias_enc is not None:
             res = [self.add_plain(r, bias_enc) for r in res]
         return res

@@ -1,8 +1,8 @@
 """The path the product runs BY DEFAULT, residue for residue against the oracle (through the C-ABI):
 merged rotate-and-sum key switches (ks_inner_multi + gather_sum, one ModDown), the shared-ModDown giant steps,
 ct x pt / scalar / ct + pt element-wise kernels, the FLEXIBLEAUTO level adjustment, ModRaise, the decryption phase,
-and the composites with every default-on knob (FHELIN_MERGE_ROT, FHELIN_EARLY_RESCALE, log-depth shift trees, the
-single rotation by -128) left ON.  All comparisons are bit-exact (integer functions); plaintext operands enter the
+and the composites with every default-on knob (FHELIN_MERGE_ROT, FHELIN_EARLY_RESCALE, log-depth shift trees, block
+masks in place of matmulRElarge's -128 shifts) left ON.  All comparisons are bit-exact (integer functions); plaintext operands enter the
 oracle as the residues the library's encoder produced (fhelin_pt_export; the encoder is the client-side row a16)."""
 import numpy as np
 import pytest
@@ -256,7 +256,7 @@ def test_rotsum_repeat_default_knobs_bit_exact(engine_factory, orc, preset, over
 
 def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
     """the log-depth forms of the reference's rotate-by-one chains (shift_sum in wrapUpExpanded / wrap_containers,
-    shift_fan in unwrapExpanded) and matmulRElarge with its single rotation by -128, composed on the oracle side in the
+    shift_fan in unwrapExpanded) and matmulRElarge with block masks in place of its -128 shifts, composed on the oracle side in the
     same tree order, at the reference's ring (N=2^15, 16384 slots) on a short chain"""
     eng = fa.Engine("reference", seed=3, n_q=6, n_p=2, dnum=3)
     try:
@@ -287,11 +287,14 @@ def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
         # matmulRElarge: 2 weight blocks, mask value 0.5, bias
         ws = [pt(rng.uniform(-1, 1, ns) / 8) for _ in range(2)]
         bias = pt(rng.uniform(-1, 1, ns))
-        first = np.zeros(ns)
-        first[:128] = 0.5
+        blocks = []
+        for j in range(2):
+            m = np.zeros(ns)
+            m[128 * j:128 * (j + 1)] = 0.5
+            blocks.append(enc_of(pt(m)))
         rows = cts[:2]
         outs = eng.matmulRElarge([c[0] for c in rows], ws, bias, 0.5)
-        want = rev.matmulRElarge([c[1] for c in rows], [enc_of(x) for x in ws], enc_of(bias), enc_of(pt(first)))
+        want = rev.matmulRElarge([c[1] for c in rows], [enc_of(x) for x in ws], enc_of(bias), blocks)
         for o, r in zip(outs, want):
             _same(o, r, "matmulRElarge")
     finally:
