@@ -39,13 +39,13 @@ def circuit_rotation_indices():
     """The rotation keys a client generates for the Linformer circuit: the +-2^i set the reference's composites rotate by
     (the shim's generate_rotation_keys extends main.cpp's list to it, quirk Q3), plus +-3*2^i, with which two steps of a
     rotate-and-sum tree run as one merged key switch (Evaluator::rotate_sum_batch), plus +-5s and +-7s for the tree units
-    s in {1, 8, 128, 1024}, with which three steps do."""
+    s in {1, 8, 128, 512, 1024}, with which three steps do."""
     r = set()
     for i in range(14):
         r.update((1 << i, -(1 << i)))
     for i in range(13):
         r.update((3 << i, -(3 << i)))
-    for s in (1, 8, 128, 1024):           # three tree steps as one merged key switch: the keys of s..7s (6s = 3*2s is above)
+    for s in (1, 8, 128, 512, 1024):      # three tree steps as one merged key switch: the keys of s..7s (6s = 3*2s is above)
         r.update((5 * s, -5 * s, 7 * s, -7 * s))
     return sorted(r)
 

@@ -100,6 +100,17 @@ PtPtr Composite::mod_n_mask(int n, int padding) {
 }
 CtPtr Composite::mask_mod_n(const CtPtr& c, int n, int padding) { return ev_.mult_plain(c, mod_n_mask(n, padding)); }
 
+PtPtr Composite::mod_range_mask(int period, int from, int to) {
+    const std::string key = mkey("modrange", period, (long)from * 100000 + to, 1.0);
+    if (!mask_cache_.count(key)) {
+        std::vector<double> m(num_slots(), 0.0);
+        for (int i = 0; i < num_slots(); ++i)
+            if (i % period >= from && i % period < to) m[i] = 1.0;
+        mask_plain(key, m);
+    }
+    return mask_cache_[key];
+}
+
 PtPtr Composite::first_n_mask(int n, double val) {
     const std::string key = mkey("first", n, 0, val);
     if (!mask_cache_.count(key)) {
@@ -418,8 +429,44 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
         if ((i + 1) * 32 > input_number) q = input_number - i * 32;
         quantities.push_back(q);
     }
-    // unwrap_512_in_4_128 (:1142-1162) for every (container, token): mask the four 128-slot blocks, then one batched
-    // repeat(128, -128) over all of them
+    const int ns = num_slots();
+    const bool shared = merge_rot_ && ns == 16384 &&
+                        ev_.have_rotation_keys({128, 256, 384, -128, -256, -384, 512, 1024, 2048, 4096, 8192}, containers.empty() ? 0 : containers[0]->slots);
+    if (!shared) {
+        // unwrap_512_in_4_128 (:1142-1162) for every (container, token): mask the four 128-slot blocks, then one batched
+        // repeat(128, -128) over all of them
+        CtVec src;
+        std::vector<PtPtr> masks;
+        for (size_t i = 0; i < containers.size() && i < quantities.size(); ++i)
+            for (int j = 0; j < quantities[i]; ++j) {
+                const int token = (int)i * 32 + j;
+                if (token < first || token >= first + count) continue;
+                for (int k = 0; k < 4; ++k) {
+                    src.push_back(containers[i]);
+                    masks.push_back(block_mask(j * 512 + 128 * k, j * 512 + 128 * (k + 1), 1));
+                }
+            }
+        CtVec rep = repeat_batch(ev_.mult_plain_each(src, masks), 128, -128);
+        std::vector<CtVec> out;
+        for (size_t i = 0; i + 3 < rep.size(); i += 4) out.push_back(CtVec(rep.begin() + i, rep.begin() + i + 4));
+        return out;
+    }
+    // The same slot values with the first two of the seven doubling steps SHARED by the 32 tokens of a container: the
+    // reference masks block k of token j and replicates it 128 times (7 steps per (token, block)).  Here
+    //   B_k = block k of EVERY token copied over that token's own 512 slots: one mask (slot mod 512 in [128k, 128k+128)) and
+    //         one merged key switch with the three rotations 128 (k - m), m != k, per (container, k);
+    //   out_{j,k} = (B_k masked to token j's 512 slots) replicated over the 32 token positions: 5 doubling steps by 512
+    //         (repeat(., 32, -512) in the reference's sign convention: left shifts, cyclic).
+    // One key switch fewer per output (2 instead of 3) at the price of one more plaintext mask level.
+    std::vector<CtVec> Bk(4);
+    for (int k = 0; k < 4; ++k) {
+        CtVec a = ev_.mult_plain_batch(containers, mod_range_mask(512, 128 * k, 128 * (k + 1)));
+        a = ev_.rescale_batch(a);
+        std::vector<int> idx;
+        for (int m = 0; m < 4; ++m)
+            if (m != k) idx.push_back(128 * (k - m));
+        Bk[k] = ev_.rotate_sum_batch(a, idx);
+    }
     CtVec src;
     std::vector<PtPtr> masks;
     for (size_t i = 0; i < containers.size() && i < quantities.size(); ++i)
@@ -427,11 +474,11 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
             const int token = (int)i * 32 + j;
             if (token < first || token >= first + count) continue;
             for (int k = 0; k < 4; ++k) {
-                src.push_back(containers[i]);
-                masks.push_back(block_mask(j * 512 + 128 * k, j * 512 + 128 * (k + 1), 1));
+                src.push_back(Bk[k][i]);
+                masks.push_back(block_mask(j * 512, (j + 1) * 512, 1));
             }
         }
-    CtVec rep = repeat_batch(ev_.mult_plain_each(src, masks), 128, -128);
+    CtVec rep = repeat_batch(ev_.mult_plain_each(src, masks), 32, -512);
     std::vector<CtVec> out;
     for (size_t i = 0; i + 3 < rep.size(); i += 4) out.push_back(CtVec(rep.begin() + i, rep.begin() + i + 4));
     return out;

@@ -283,7 +283,7 @@ public:
             all.push_back(3 << i);
             all.push_back(-(3 << i));
         }
-        for (int s : {1, 8, 128, 1024})  // with s..7s three tree steps run as one merged key switch (6s = 3 * 2s is above)
+        for (int s : {1, 8, 128, 512, 1024})  // with s..7s three tree steps run as one merged key switch (6s = 3 * 2s is above)
             for (int m : {5, 7}) {
                 all.push_back(m * s);
                 all.push_back(-m * s);

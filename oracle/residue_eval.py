@@ -260,6 +260,27 @@ class ResidueEvaluator:
             res = [self.add_plain(r, bias_enc) for r in res]
         return res
 
+    def unwrapRepeatedLarge(self, containers, n_tokens, enc_of_values):
+        """composite.cpp unwrapRepeatedLarge (shared form): per container and block k one mask (slot mod 512 in block k) and one
+        merged key switch copy block k of every token over the token's own 512 slots; per (token, k) a token mask and
+        repeat(., 32, -512).  enc_of_values(vector) -> enc callback for that plaintext vector."""
+        ns = self.slots
+        idx = np.arange(ns)
+        Bk = []
+        for k in range(4):
+            m = ((idx % 512 >= 128 * k) & (idx % 512 < 128 * (k + 1))).astype(np.float64)
+            rows = []
+            for c in containers:
+                a = self.rescale(self.mult_plain(c, enc_of_values(m)))
+                rows.append(self.rotate_sum(a, [128 * (k - mm) for mm in range(4) if mm != k]))
+            Bk.append(rows)
+        out = []
+        for t in range(n_tokens):
+            i, j = divmod(t, 32)
+            tm = ((idx >= 512 * j) & (idx < 512 * (j + 1))).astype(np.float64)
+            out.append([self.repeat(self.mult_plain(Bk[k][i], enc_of_values(tm)), 32, -512) for k in range(4)])
+        return out
+
     def wrap_containers(self, cts, n):
         terms = list(cts[:n])[::-1]
         return self.shift_sum(terms, -512)
