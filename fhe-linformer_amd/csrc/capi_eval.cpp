@@ -212,7 +212,9 @@ int fhelin_ct_info(const fhelin_ct* ct, int32_t* npoly, int32_t* ell, int32_t* l
 int fhelin_ct_clone(fhelin_ctx* c, const fhelin_ct* ct, fhelin_ct** out) {
     NEED(c && ct && out);
     FHELIN_TRY
-    *out = wrap(c->ev.clone(ct_in(c, ct)));
+    // ciphertext objects are immutable (every operation returns a new one), so Clone() is a new HANDLE to the same
+    // residues: no copy — and rows that are clones of one ciphertext can be recognised as identical (Composite::matmul_pt)
+    *out = wrap(ct_in(c, ct));
     FHELIN_CATCH
 }
 void fhelin_ct_free(fhelin_ct* ct) { delete ct; }

@@ -239,12 +239,30 @@ CtPtr Composite::add_many(const CtVec& v) {
     return cur[0];
 }
 
-CtVec Composite::matmul_pt(const CtVec& rows, const PtPtr& w, const PtPtr& bias, int slots, int padding) {
+CtVec Composite::matmul_pt(const CtVec& rows_in, const PtPtr& w, const PtPtr& bias, int slots, int padding) {
+    // rows that are the SAME ciphertext object (handles made by Clone(): the CLS-only driver feeds 129 clones of one
+    // encryption of zero through W_O, src/main.cpp:220-235) give the same result: evaluate each distinct row once
+    CtVec rows;
+    std::vector<size_t> pos(rows_in.size());
+    {
+        std::map<const Ciphertext*, size_t> seen;
+        for (size_t i = 0; i < rows_in.size(); ++i) {
+            auto it = seen.find(rows_in[i].get());
+            if (it == seen.end()) {
+                it = seen.emplace(rows_in[i].get(), rows.size()).first;
+                rows.push_back(rows_in[i]);
+            }
+            pos[i] = it->second;
+        }
+    }
     // rows are independent (reference loop :872,:888,:985): the same operation sequence, interchanged so that
     // every rotate-and-sum step runs over all rows at once
     CtVec out = rotsum_batch(ev_.mult_plain_batch(rows, w), slots, padding);
     if (bias) out = ev_.add_plain_batch(out, bias);
-    return out;
+    if (rows.size() == rows_in.size()) return out;
+    CtVec full(rows_in.size());
+    for (size_t i = 0; i < rows_in.size(); ++i) full[i] = out[pos[i]];
+    return full;
 }
 
 CtVec Composite::matmul_ct(const CtVec& rows, const CtPtr& w, int slots, int padding) {
@@ -253,12 +271,74 @@ CtVec Composite::matmul_ct(const CtVec& rows, const CtPtr& w, int slots, int pad
     return rotsum_batch(prod, slots, padding);
 }
 
+// W''_t (t = 0..3): block b (128 slots) of W''_t is block b of W_j with j = (b - t) mod 4 — see matmulRElarge
+std::vector<PtPtr> Composite::relarge_weights(const std::vector<PtPtr>& weights) {
+    char key[160];
+    snprintf(key, sizeof key, "%p:%p:%p:%p", (void*)weights[0].get(), (void*)weights[1].get(), (void*)weights[2].get(), (void*)weights[3].get());
+    auto it = relarge_cache_.find(key);
+    if (it != relarge_cache_.end()) return it->second;
+    const int ns = num_slots();
+    std::vector<PtPtr> out;
+    for (int t = 0; t < 4; ++t) {
+        std::vector<double> v(ns, 0.0);
+        for (int s = 0; s < ns; ++s) {
+            const int b = s / 128, j = ((b - t) % 4 + 4) % 4;
+            const auto& src = weights[j]->values;
+            v[s] = s < (int)src.size() ? src[s] : 0.0;
+        }
+        out.push_back(encode_vec(v, weights[0]->level));
+    }
+    if (relarge_cache_.size() > 16) relarge_cache_.clear();   // bounded: a driver uses one or two weight sets
+    relarge_cache_[key] = out;
+    return out;
+}
+
 CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias, double mask_val) {
-    // per input the reference computes (:915-944) res = sum_j rot(mask_first_128(rotsum(x * W_j)), -128 (j-th shift)) + bias, the
-    // shifts as chains of two rotations by -64 (:934-935).  rotsum(., 128, 128) leaves a vector that repeats with period 128,
-    // so "mask the first block, then shift it to block j" selects the same slots as masking block j directly: the 3
-    // rotations per input are not needed at all (FHELIN_MERGE_ROT=0 keeps the reference's masks and shifts).  Inputs are
-    // independent: each block j is evaluated for all inputs together.
+    // per input the reference computes (:915-944) res = sum_j shift_j(mask_first_128(rotsum(x * W_j, 128, 128))) + bias: four
+    // 7-step rotate-and-sum trees per input.  What it needs of tree j is ONE block: block j of out = the sum of all 128 blocks
+    // of P_j = x * W_j.  Re-associated (same slot values):
+    //   U = sum_{t<4} rot(x * W''_t, 128 t),  W''_t = block-wise re-arrangement of the four weights (relarge_weights):
+    //       block b of U holds sum_{t<4} P_j[block b + t] for j = b mod 4  (the tree steps 128, 256 of all four trees, with the
+    //       "keep blocks = j mod 4" masks folded into the plaintext weights: no extra level);
+    //   Z = U + its rotations by 512, 1024, ..., 8192 (5 doubling steps): block j of Z = sum of all blocks of P_j;
+    //   out = Z * (mask_val on slots [0, 512)) + bias.
+    // One shared-ModDown key switch of three terms and a 5-step tree instead of four 7-step trees per input.
+    const int ns = num_slots();
+    const bool shared = merge_rot_ && weights.size() == 4 && ns == 16384 && !inputs.empty() &&
+                        ev_.have_rotation_keys({128, 256, 384, 512, 1024, 2048, 4096, 8192}, inputs[0]->slots);
+    if (shared) {
+        const std::vector<PtPtr> w2 = relarge_weights(weights);
+        // rescale degree-2 inputs once (each product below would otherwise do it again)
+        CtVec x = inputs;
+        {
+            CtVec need;
+            std::vector<size_t> pos;
+            for (size_t i = 0; i < x.size(); ++i)
+                if (x[i]->deg >= 2) {
+                    need.push_back(x[i]);
+                    pos.push_back(i);
+                }
+            if (!need.empty()) {
+                CtVec r = ev_.rescale_batch(need);
+                for (size_t k = 0; k < pos.size(); ++k) x[pos[k]] = r[k];
+            }
+        }
+        std::vector<CtVec> y(4);
+        for (int t = 0; t < 4; ++t) {
+            y[t] = ev_.mult_plain_batch(x, w2[t]);
+            if (early_rescale_) y[t] = ev_.rescale_batch(y[t]);
+        }
+        std::vector<CtVec> rows(x.size(), CtVec(4));
+        for (size_t i = 0; i < x.size(); ++i)
+            for (int t = 0; t < 4; ++t) rows[i][t] = y[t][i];
+        CtVec u = ev_.rotate_each_sum_rows(rows, {0, 128, 256, 384});
+        CtVec z = rotsum_batch(u, 32, 512);
+        CtVec res = ev_.mult_plain_batch(z, block_mask(0, 512, mask_val));
+        if (bias) res = ev_.add_plain_batch(res, bias);
+        return res;
+    }
+    // the reference's formulation: one tree per weight block; a rotsum(., 128, 128) output repeats with period 128, so masking
+    // block j directly selects what "mask the first block, then shift it" does (FHELIN_MERGE_ROT=0: the reference's shifts)
     CtVec res(inputs.size());
     const bool direct = merge_rot_;
     for (int j = (int)weights.size() - 1; j >= 0; --j) {

@@ -410,6 +410,104 @@ CtPtr Evaluator::rotate_each_sum(const std::vector<CtPtr>& vin, const std::vecto
     return acc;
 }
 
+std::vector<CtPtr> Evaluator::rotate_each_sum_rows(const std::vector<std::vector<CtPtr>>& rows, const std::vector<int>& indices) {
+    if (rows.empty()) return {};
+    const int ns = rows[0][0]->slots > 0 ? rows[0][0]->slots : (1 << c_.prm.log_slots);
+    std::vector<int> rot_pos, plain_pos, ridx;
+    for (size_t r = 0; r < indices.size(); ++r) {
+        if (indices[r] % ns == 0) plain_pos.push_back((int)r);
+        else {
+            rot_pos.push_back((int)r);
+            ridx.push_back(indices[r]);
+        }
+    }
+    const int R = (int)rot_pos.size();
+    bool uniform = R >= 2 && R <= KsShape::MAX_ROT && have_rotation_keys(ridx, ns) && c_.K >= 1;
+    const CtPtr& f = rows[0][0];
+    for (const auto& row : rows) {
+        uniform = uniform && row.size() == indices.size();
+        for (const CtPtr& c : row)
+            uniform = uniform && c->npoly == 2 && c->ell == f->ell && c->deg == f->deg && fabsl(c->scale / f->scale - 1.0L) < 1e-9L;
+    }
+    std::vector<CtPtr> out(rows.size());
+    if (!uniform) {
+        for (size_t b = 0; b < rows.size(); ++b) out[b] = rotate_each_sum(rows[b], indices);
+        return out;
+    }
+    const size_t N = c_.N;
+    const int K = c_.K, L1 = c_.L + 1, ell = f->ell;
+    const size_t pn = (size_t)ell * N, ctw = 2 * pn;
+    const LevelTables& lt = c_.lvl[ell];
+    const int nt = ell + K;
+    hipStream_t s = c_.stream;
+    const size_t chunk_rows = (size_t)std::max(1, batch_limit / 2);   // rows x R polynomials go through one ModUp
+    for (size_t lo = 0; lo < rows.size(); lo += chunk_rows) {
+        const size_t hi = std::min(rows.size(), lo + chunk_rows);
+        const int B = (int)(hi - lo);
+        std::vector<CtPtr> flat;
+        for (size_t b = lo; b < hi; ++b)
+            for (int r : rot_pos) flat.push_back(rows[b][r]);
+        flat = make_contiguous(flat);
+        const u64* base = flat[0]->d;
+        KsShape up{ell, K, c_.alpha, lt.beta, L1, B * R, ctw, 0, 0, 0};
+        u64* cc = c_.dalloc<u64>((size_t)B * R * ell * N);
+        {
+            LimbBatch ib{cc, B * R * ell, nullptr, 0, ell, base + pn};
+            ib.src_group = ell;
+            ib.src_group_stride = ctw;
+            c_.ntt(ib, true);
+        }
+        u64* ext = c_.dalloc<u64>((size_t)B * R * lt.beta * nt * N);
+        launch_modup_conv(c_.dt, up, ext, cc, base + pn, lt.up_hatinv, lt.up_hatmod, s);
+        LimbBatch eb{ext, B * R * lt.beta * nt, lt.ext_limb_tab, 0, 1};
+        eb.tab_len = lt.beta * nt;
+        eb.lazy_out = true;
+        c_.ntt(eb, false, B * R * (lt.beta * nt - ell));
+        KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, (size_t)R * ctw, ctw, pn, 0};
+        sh.n_rot = R;
+        sh.rot_ext_stride = (size_t)lt.beta * nt * N;
+        sh.rot_input_stride = ctw;
+        sh.ext_batch_stride = (size_t)R * lt.beta * nt * N;
+        for (int r = 0; r < R; ++r) {
+            const u64 g = c_.galois_element(ridx[r]);
+            sh.map_rot[r] = c_.automorph_map(g);
+            sh.evk_rot[r] = permuted(*rot_keys.at(g), sh.map_rot[r]);
+        }
+        sh.gsrc = base;
+        sh.gsrc_stride = (size_t)R * ctw;
+        c_.stats.keyswitch += (u64)B * R;
+        c_.stats.keyswitch_limbs += (u64)B * R * ell;
+        u64* accQ = c_.dalloc<u64>((size_t)B * 2 * ell * N);
+        u64* accP = c_.dalloc<u64>((size_t)B * 2 * K * N);
+        launch_ks_inner_multi(c_.dt, sh, accQ, accP, ext, base + pn, s);
+        c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
+        u64* conv = c_.dalloc<u64>((size_t)B * 2 * ell * N);
+        launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
+        c_.ntt(LimbBatch{conv, B * 2 * ell, nullptr, 0, ell}, false);
+        std::vector<CtPtr> o = new_ct_batch(B, 2, ell, f->deg, f->scale, f->slots);
+        launch_moddown_finish(c_.dt, sh, o[0]->d, accQ, conv, c_.d_pinv, nullptr, nullptr, nullptr, nullptr, s);
+        launch_ok("rotate_each_sum_rows");
+        c_.pool.free(cc);
+        c_.pool.free(ext);
+        c_.pool.free(accQ);
+        c_.pool.free(accP);
+        c_.pool.free(conv);
+        for (int b = 0; b < B; ++b) out[lo + b] = o[b];
+    }
+    // unrotated terms are plain additions, in the order rotate_each_sum adds them: plain terms first, then the rotated sum
+    if (!plain_pos.empty()) {
+        std::vector<CtPtr> acc(rows.size());
+        for (size_t b = 0; b < rows.size(); ++b) acc[b] = rows[b][plain_pos[0]];
+        for (size_t k = 1; k < plain_pos.size(); ++k) {
+            std::vector<CtPtr> t(rows.size());
+            for (size_t b = 0; b < rows.size(); ++b) t[b] = rows[b][plain_pos[k]];
+            acc = add_batch(acc, t);
+        }
+        out = add_batch(acc, out);
+    }
+    return out;
+}
+
 // hoisted rotations of one ciphertext.  A rotation here is KeySwitch_{s -> sigma^-1(s)}(c1) + c0 followed by the NTT-domain
 // automorphism gather in the ModDown epilogue, so the ModUp of c1 does not depend on the rotation index: it is computed
 // once and every index runs only its own inner product + ModDown.  Bit-identical to rotate(a, i).

@@ -118,6 +118,10 @@ public:
     // sum_i rot(v[i], indices[i]) for up to 7 ciphertexts of identical shape (index 0 = unrotated term allowed): every
     // term has its own ModUp and key, the inner products are accumulated in QP and share ONE ModDown (giant steps)
     CtPtr rotate_each_sum(const std::vector<CtPtr>& v, const std::vector<int>& indices);
+    // the same for many independent rows that share one index list: out[b] = sum_r rot(rows[b][r], indices[r]), with the key
+    // switches of a chunk of rows batched (one ModUp over rows x terms, one inner-product launch, one ModDown over rows).
+    // Same residues as rotate_each_sum row by row (<= 7 rotated terms per row).
+    std::vector<CtPtr> rotate_each_sum_rows(const std::vector<std::vector<CtPtr>>& rows, const std::vector<int>& indices);
     // hoisted rotations: rot(a, i) for every i in `indices` with ONE ModUp of a (results identical to rotate(a, i))
     std::vector<CtPtr> rotate_many(const CtPtr& a, const std::vector<int>& indices);
     // rot(v[i], indices[i]) for ciphertexts of identical shape, one batched key switch per chunk of rows

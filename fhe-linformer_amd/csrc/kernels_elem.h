@@ -84,6 +84,7 @@ struct KsShape {
     // rot_input_stride): a sum of rotations of different ciphertexts (giant steps) shares the one ModDown
     size_t rot_ext_stride = 0;
     size_t rot_input_stride = 0;
+    size_t ext_batch_stride = 0;  // digits of batch row b at ext + b * ext_batch_stride (0: beta * (ell + k) * N, one input per row)
     // K8b epilogue of a merged rotation sum: component 0 additionally receives sum_r gsrc[bi][tt][map_rot[r][n]] (the rotated
     // c0 parts, gathered in place of a separate gather-and-sum pass); rotation r reads gsrc + r * rot_input_stride
     const u64* gsrc = nullptr;

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsS
     const int bi = blockIdx.y % sh.batch, tt = blockIdx.y / sh.batch;
     const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
     const size_t N = (size_t)1 << t.log_n, row = N >> 1;
-    ext += (size_t)bi * sh.beta * nt * N;
+    ext += (size_t)bi * (sh.ext_batch_stride ? sh.ext_batch_stride : (size_t)sh.beta * nt * N);
     c_ntt += (size_t)bi * sh.c_stride;
     const int own = tt < sh.ell ? tt / sh.alpha : -1;
     accQ += (size_t)bi * 2 * sh.ell * N;

@@ -248,17 +248,19 @@ class ResidueEvaluator:
             out = [self.add_plain(o, bias_enc) for o in out]
         return out
 
-    def matmulRElarge(self, rows, w_encs, bias_enc, mask_encs):
-        """sum_j mask_block_j(rotsum(x * W_j)) + bias: the rotsum output repeats with period 128, so masking block j directly
-        selects what the reference's mask-first-block-then-shift does (composite.cpp matmulRElarge); mask_encs[j] = block j"""
-        res = None
-        for j in range(len(w_encs) - 1, -1, -1):
-            outs = [self.rotsum(self.mult_plain(r, w_encs[j]), 128, 128) for r in rows]
-            masked = [self.mult_plain(o, mask_encs[j]) for o in outs]
-            res = masked if res is None else [self.add(r, m) for r, m in zip(res, masked)]
-        if bias_enc is not None:
-            res = [self.add_plain(r, bias_enc) for r in res]
-        return res
+    def matmulRElarge(self, rows, w2_encs, bias_enc, mask512_enc):
+        """composite.cpp matmulRElarge, shared form: U = sum_{t<4} rot(x * W''_t, 128 t) (one shared-ModDown key switch of three
+        rotated terms + the unrotated one), Z = rotsum(U, 32, 512), out = Z * mask[0,512) + bias.  w2_encs[t] encodes W''_t
+        (block b of W''_t = block b of W_((b - t) mod 4)); a degree-2 input is rescaled once, each product before its key switch"""
+        out = []
+        for r in rows:
+            x = self.rescale(r) if r.deg >= 2 else r
+            y = [self.rescale(self.mult_plain(x, w2_encs[t])) for t in range(4)]
+            u = self.rotate_each_sum(y, [0, 128, 256, 384])
+            z = self.rotsum(u, 32, 512)
+            o = self.mult_plain(z, mask512_enc)
+            out.append(self.add_plain(o, bias_enc) if bias_enc is not None else o)
+        return out
 
     def unwrapRepeatedLarge(self, containers, n_tokens, enc_of_values):
         """composite.cpp unwrapRepeatedLarge (shared form): per container and block k one mask (slot mod 512 in block k) and one

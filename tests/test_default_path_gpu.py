@@ -263,7 +263,8 @@ def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
         need = set()
         for u in (128, 512, 2048):
             need.update((u, 2 * u, 3 * u))
-        need.update((8192, -128))                                   # rotsum(128,128) + the -128 shift of matmulRElarge
+        need.update((8192, 1024, 4096, 12288))                      # rotsum(128,128); matmulRElarge's 5-step tree by 512 (pairs: no 5s/7s keys here)
+        need.update((1536, 3072, 6144))
         for u in (-1, -4, -16):
             need.update((u, 2 * u, 3 * u))
         need.update((-64, 1, 2, -512, -1024, -2048))                # repeat(128,1), fans, wrap_containers
@@ -284,17 +285,21 @@ def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
         _same(w, rw, "wrapUpExpanded")
         for o, r in zip(eng.unwrapExpanded(w, 3), rev.unwrapExpanded(rw, 3, menc)):
             _same(o, r, "unwrapExpanded")
-        # matmulRElarge: 2 weight blocks, mask value 0.5, bias
-        ws = [pt(rng.uniform(-1, 1, ns) / 8) for _ in range(2)]
+        # matmulRElarge (four weight blocks, shared form): W''_t block-wise re-arranged weights, mask value 0.5 on [0, 512), bias
+        wv = [rng.uniform(-1, 1, ns) / 8 for _ in range(4)]
+        ws = [pt(v) for v in wv]
         bias = pt(rng.uniform(-1, 1, ns))
-        blocks = []
-        for j in range(2):
-            m = np.zeros(ns)
-            m[128 * j:128 * (j + 1)] = 0.5
-            blocks.append(enc_of(pt(m)))
+        w2 = []
+        for t in range(4):
+            v = np.zeros(ns)
+            for b in range(128):
+                v[128 * b:128 * (b + 1)] = wv[(b - t) % 4][128 * b:128 * (b + 1)]
+            w2.append(enc_of(pt(v)))
+        m512 = np.zeros(ns)
+        m512[:512] = 0.5
         rows = cts[:2]
         outs = eng.matmulRElarge([c[0] for c in rows], ws, bias, 0.5)
-        want = rev.matmulRElarge([c[1] for c in rows], [enc_of(x) for x in ws], enc_of(bias), blocks)
+        want = rev.matmulRElarge([c[1] for c in rows], w2, enc_of(bias), enc_of(pt(m512)))
         for o, r in zip(outs, want):
             _same(o, r, "matmulRElarge")
     finally:
