@@ -64,7 +64,20 @@ void force_many(fhelin_ctx* c, const fhelin_ct* const* v, int n) {
         if (it == groups.end()) it = groups.insert(groups.end(), {g, {}});
         if (std::find(it->second.begin(), it->second.end(), h->lazy_idx) == it->second.end()) it->second.push_back(h->lazy_idx);
     }
-    for (auto& e : groups) force_rows(c, *e.first, e.second);
+    for (auto& e : groups) force_group(c, *e.first, e.second);
+}
+void force_group(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx) {
+    std::vector<int> rest;
+    for (int i = 0; i < (int)g.done.size(); ++i)
+        if (!g.done[i]) rest.push_back(i);
+    bool wanted = false, partial = false;
+    for (int i : idx) wanted |= !g.done[i];
+    if (!wanted) return;
+    for (int i : rest) partial |= std::find(idx.begin(), idx.end(), i) == idx.end();
+    if (partial && g.partial_reads++ == 0)
+        force_rows(c, g, idx);
+    else
+        force_rows(c, g, rest);
 }
 }  // namespace fhelin
 static void emit(const CtVec& v, fhelin_ct** outs) {

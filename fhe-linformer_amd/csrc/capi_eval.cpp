@@ -223,6 +223,8 @@ void fhelin_ct_free(fhelin_ct* ct) { delete ct; }
     int name(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b, fhelin_ct** out) {      \
         NEED(c && a && b && out);                                                           \
         FHELIN_TRY                                                                          \
+        const fhelin_ct* both[2] = {a, b};                                                  \
+        force_many(c, both, 2); /* deferred operands of one group: one batched call */      \
         *out = wrap(expr);                                                                  \
         FHELIN_CATCH                                                                        \
     }

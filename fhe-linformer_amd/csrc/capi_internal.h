@@ -34,6 +34,7 @@ struct LazyRows {
     CtPtr src;                  // UnwrapExpanded: the wrapped ciphertext
     int n = 0;
     std::vector<CtPtr> done;    // per row: null until evaluated
+    int partial_reads = 0;      // reads so far that asked for only some of the rows (force_group)
 };
 }
 struct fhelin_ct {
@@ -50,10 +51,15 @@ namespace fhelin {
 int capi_fail(int code, const std::string& msg);
 // evaluate the listed rows of a deferred group in ONE batched call (capi_composite.cpp)
 void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx);
+// A consumer asks for rows `idx` of a deferred group.  The first partial read evaluates just those rows (a driver that
+// uses Q[0] only); a second one means the driver is walking over the rows (for (i...) output[i] = add(output[i],
+// inputs[i]), src/main.cpp:237-239): everything that is left is evaluated in one batched call instead of row by row.
+void force_group(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx);
 inline void force(fhelin_ctx* c, const fhelin_ct* h) {
     if (h->p || !h->lazy) return;
-    if (!h->lazy->done[h->lazy_idx]) force_rows(c, *h->lazy, std::vector<int>{h->lazy_idx});
-    h->p = h->lazy->done[h->lazy_idx];
+    LazyRows& g = *h->lazy;
+    if (!g.done[h->lazy_idx]) force_group(c, g, std::vector<int>{h->lazy_idx});
+    h->p = g.done[h->lazy_idx];
     h->lazy.reset();
 }
 // the deferred rows among v[0..n) are evaluated together, one batched call per group
