@@ -8,6 +8,8 @@ preset = sys.argv[1] if len(sys.argv) > 1 else "bench"
 kw = {}
 if len(sys.argv) > 2:
     kw["n_q"] = int(sys.argv[2])
+if len(sys.argv) > 3:
+    kw["n_p"] = int(sys.argv[3])
 e = fa.Engine(preset, seed=5, **kw)
 t0 = time.time(); e.keygen(); e.gen_relin_key(); print("keygen s", round(time.time() - t0, 2))
 t0 = time.time(); e.bootstrap_setup(3, 3, 1 << e.params.log_slots); print("setup s", round(time.time() - t0, 2))
