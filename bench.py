@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--shard-rows", action="store_true", help="batch-1 latency mode: ONE sample per step, the rows inside its matmul / "
                     "unwrap loops split over the ranks (all-gather of ciphertext rows over RCCL/xGMI per row loop)")
     ap.add_argument("--no-ops", action="store_true", help="skip the short leaf-op section of a forward run")
+    ap.add_argument("--no-level-plan", action="store_true", help="run every pass at the levels the driver asks for (no recorded level plan)")
     ap.add_argument("--forward-only", action="store_true", help="profiling runs: only the timed forward passes (no eager comparison, "
                     "no NTT / op sections, no CPU leg); prints a reduced line without `roofline`")
     ap.add_argument("--key-seed", type=int, default=2024, help="deterministic key seed, the same on every rank (replicated keys)")
@@ -319,17 +320,39 @@ def main():
             assert all(np.array_equal(a, allsk[0]) for a in allsk), "ranks hold different keys"
         samples = []
         n_samples = (args.warmup + args.steps) * per_rank
+        # level plan (include/fhelin.h fhelin_level_plan_*): ONE untimed pass of the same driver is recorded; every later pass
+        # - the client's encryptions and the server's evaluation - starts each fresh encryption / bootstrap output with the
+        # limbs the recording shows its consumers read.  Row-sharded runs exchange ciphertexts between ranks: not planned.
+        use_plan = not args.no_level_plan and not row_mode
+        n_client_sources = 0
+        plan = []
+        if use_plan:
+            x = pf.synthetic_tokens(S, 999)
+            eng.level_plan_begin("record")
+            enc_rec = lf.encrypt_inputs(ctl, *pf.client_inputs(w, x))
+            n_client_sources = sum(len(v) for v in enc_rec.values())      # the client's encryptions are the pass's first sources
+            eng.decrypt(lf.forward_encrypted(ctl, w, enc_rec))
+            plan = eng.level_plan_end()
+            del enc_rec
+
+        def server_pass(enc):
+            if use_plan:
+                eng.level_plan_begin("apply", first_source=n_client_sources)
+            return lf.forward_encrypted(ctl, w, enc)
+
         eng.sync()
         t_client = time.perf_counter()
         for i in range(n_samples):                           # every step gets its own samples (seeded per rank)
             timed_idx = i - args.warmup * per_rank
             x = pf.synthetic_tokens(S, 4321 + (0 if row_mode else 100000 * rank) + max(0, timed_idx))   # row mode: every rank, same sample
             x_in, X_E, X_F = pf.client_inputs(w, x)
+            if use_plan:
+                eng.level_plan_begin("apply")
             samples.append((x, lf.encrypt_inputs(ctl, x_in, X_E, X_F)))   # client side: resident in HBM before timing
         eng.sync()
         client_ms = (time.perf_counter() - t_client) * 1e3 / max(1, n_samples)   # plaintext prep + encode + encrypt of 194 inputs
         for i in range(args.warmup * per_rank):
-            lf.forward_encrypted(ctl, w, samples[i][1])
+            server_pass(samples[i][1])
         eng.sync()
         torch.cuda.synchronize()
         eng.stats(reset=True)
@@ -340,7 +363,7 @@ def main():
         host_enqueue = 0.0
         for i in range(args.warmup * per_rank, n_samples):
             th = time.perf_counter()
-            out = lf.forward_encrypted(ctl, w, samples[i][1])
+            out = server_pass(samples[i][1])
             host_enqueue += time.perf_counter() - th           # host time to ISSUE the pass (the GPU runs behind asynchronously)
             logits.append(lf.logits_from_slots(eng.decrypt(out)))
         eng.sync()
@@ -373,27 +396,42 @@ def main():
         # region, for the record: the reference's CLS-only driver computes 129 query projections and 129 final token
         # expansions that nothing reads (src/main.cpp:183,:196,:416-424)
         eager_ms = float("nan")
+        unplanned_ms = float("nan")
         if not args.forward_only:
             eng.set_lazy_rows(False)
             eng.sync()
             t1 = time.perf_counter()
             for _ in range(2):
-                eng.decrypt(lf.forward_encrypted(ctl, w, samples[-1][1]))
+                eng.decrypt(server_pass(samples[-1][1]))
             eng.sync()
             eager_ms = (time.perf_counter() - t1) * 1e3 / 2
             eng.set_lazy_rows(True)
+            # and the pass at the levels the driver asks for (no plan), on inputs encrypted at level 0 as the driver does
+            if use_plan:
+                eng.level_plan_begin("off")
+                enc_full = lf.encrypt_inputs(ctl, *pf.client_inputs(w, samples[-1][0]))
+                eng.decrypt(lf.forward_encrypted(ctl, w, enc_full))
+                eng.sync()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    eng.decrypt(lf.forward_encrypted(ctl, w, enc_full))
+                eng.sync()
+                unplanned_ms = (time.perf_counter() - t1) * 1e3 / 2
+                del enc_full
         else:
             if rank == 0:
                 print(json.dumps({"metric": "encrypted Linformer-d128 forward ms/sample (profiling run)",
                                   "value": round(elapsed * 1e3 / (n_timed * world), 2), "unit": "ms/sample", "n_gpus": world,
                                   "steps": args.steps, "warmup": args.warmup, "log_n": args.log_n,
-                                  "host_issue_ms_per_sample": round(host_enqueue * 1e3 / n_timed, 2), "ops_per_sample": stats}))
+                                  "host_issue_ms_per_sample": round(host_enqueue * 1e3 / n_timed, 2), "ops_per_sample": stats,
+                                  "level_plan": bool(plan)}))
             eng.close()
             if dist:
                 dist.destroy_process_group()
             return
         fwd = {"elapsed": elapsed, "stats": stats, "logit_err_vs_circuit_oracle": err, "pred": int(np.argmax(logits[-1])),
-               "samples_checked": len(logits), "eager_ms": eager_ms, "client_ms": client_ms}
+               "samples_checked": len(logits), "eager_ms": eager_ms, "client_ms": client_ms, "unplanned_ms": unplanned_ms,
+               "plan": plan, "n_client_sources": n_client_sources}
         for _, enc in samples:
             del enc
         samples = None
@@ -461,6 +499,14 @@ def main():
                            "deferred_rows": "on: rows of matmulRE / unwrapExpanded that no later call reads are not evaluated "
                                             "(results unchanged); ops_per_sample counts what was executed",
                            "ms_per_sample_with_every_row_evaluated": round(fwd["eager_ms"], 2),
+                           "level_plan": ("off" if not fwd["plan"] else
+                                          "on: one untimed pass of the same driver was recorded; fresh encryptions and bootstrap outputs start with "
+                                          "the limbs their consumers read (values unchanged up to noise; every timed sample is checked)"),
+                           "level_plan_limbs_per_source": ({} if not fwd["plan"] else {
+                               "client_encryptions": {str(k): fwd["plan"][:fwd["n_client_sources"]].count(k)
+                                                      for k in sorted(set(fwd["plan"][:fwd["n_client_sources"]]))},
+                               "server_sources_in_call_order": fwd["plan"][fwd["n_client_sources"]:]}),
+                           "ms_per_sample_without_level_plan": round(fwd["unplanned_ms"], 2),
                            "client_ingest_ms_per_sample": round(fwd["client_ms"], 2)},
                 "ntt": {"metric": "NTT/s at N=2^16", "value": round(ntt_rate, 1), "unit": "limb-NTT/s",
                         "workload": f"fwd+inv NTT of {args.ntt_batch} ciphertexts x 2 polys x {nq} limbs per GPU"},

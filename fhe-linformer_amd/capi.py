@@ -80,6 +80,11 @@ def load_library():
         "fhelin_ctx_scaling_factors": (i32, [vp, C.POINTER(C.c_double), i32]),
         "fhelin_ctx_set_stream": (i32, [vp, vp]),
         "fhelin_ctx_set_lazy_rows": (i32, [vp, i32]),
+        "fhelin_level_plan_begin": (i32, [vp, i32]),
+        "fhelin_level_plan_seek": (i32, [vp, i32]),
+        "fhelin_level_plan_end": (i32, [vp, C.POINTER(i32)]),
+        "fhelin_level_plan_get": (i32, [vp, C.POINTER(i32), i32, C.POINTER(i32)]),
+        "fhelin_level_plan_set": (i32, [vp, C.POINTER(i32), i32]),
         "fhelin_sync": (i32, [vp]),
         "fhelin_timer_start": (i32, [vp]),
         "fhelin_timer_stop": (i32, [vp, f32p]),
@@ -255,6 +260,31 @@ class Engine:
     def set_lazy_rows(self, on):
         """deferred evaluation of the rows of matmul_pt / unwrapExpanded (default on)"""
         self._ck(self.lib.fhelin_ctx_set_lazy_rows(self.h, 1 if on else 0))
+
+    # level plan (include/fhelin.h fhelin_level_plan_*): record one pass of a straight-line driver, apply to later ones
+    def level_plan_begin(self, mode, first_source=0):
+        """mode: "record", "apply" or "off"; the pass starts at the program's first source unless first_source says otherwise
+        (apply only: a server pass that starts after the client's encryptions)"""
+        self._ck(self.lib.fhelin_level_plan_begin(self.h, {"off": 0, "record": 1, "apply": 2}[mode]))
+        if first_source:
+            self._ck(self.lib.fhelin_level_plan_seek(self.h, int(first_source)))
+
+    def level_plan_end(self):
+        """ends the pass (a recording pass derives the plan); returns the plan: limbs per source, -1 = as asked"""
+        n = C.c_int32(0)
+        self._ck(self.lib.fhelin_level_plan_end(self.h, C.byref(n)))
+        return self.level_plan()
+
+    def level_plan(self):
+        n = C.c_int32(0)
+        self._ck(self.lib.fhelin_level_plan_get(self.h, None, 0, C.byref(n)))
+        buf = (C.c_int32 * max(1, n.value))()
+        self._ck(self.lib.fhelin_level_plan_get(self.h, buf, n.value, C.byref(n)))
+        return list(buf[:n.value])
+
+    def set_level_plan(self, target):
+        arr = (C.c_int32 * len(target))(*[int(t) for t in target])
+        self._ck(self.lib.fhelin_level_plan_set(self.h, arr, len(target)))
 
     def secret_seed(self):
         out = (C.c_uint8 * 32)()

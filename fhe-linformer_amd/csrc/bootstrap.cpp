@@ -218,8 +218,15 @@ CtPtr Bootstrapper::apply(const LinStage& st, const CtPtr& xin) {
         groups[t.giant].first.push_back(babies[t.baby]);
         groups[t.giant].second.push_back(t.diag);
     }
+    // an input whose scale is not its level's own (the first stage after a ModRaise to fewer limbs than the chain has:
+    // run(drop > 0)) takes the diagonals at the scale that makes the product land on the next level's scale again
+    Context& c = ev_.ctx();
+    long double pt_scale = 0;
+    const int lvl = x->level();
+    if (x->ell >= 2 && fabsl(x->scale / c.sf_real[lvl] - 1.0L) > 1e-12L)
+        pt_scale = c.sf_real[lvl + 1] * (long double)c.chain.q[x->ell - 1] / x->scale;
     std::map<int, CtPtr> inner;
-    for (auto& g : groups) inner[g.first] = ev_.dot_plain(g.second.first, g.second.second);
+    for (auto& g : groups) inner[g.first] = ev_.dot_plain(g.second.first, g.second.second, pt_scale);
     // giant steps: different inputs, different keys, same shape
     std::vector<CtPtr> gin;
     std::vector<int> gidx;
@@ -231,7 +238,7 @@ CtPtr Bootstrapper::apply(const LinStage& st, const CtPtr& xin) {
     return ev_.rotate_each_sum(gin, gidx);
 }
 
-CtPtr Bootstrapper::mod_raise(const CtPtr& ct, long double& rho) {
+CtPtr Bootstrapper::mod_raise(const CtPtr& ct, long double& rho, int top_ell) {
     Context& c = ev_.ctx();
     CtPtr x = ct->deg >= 2 ? ev_.rescale(ct) : ct;
     if (x->npoly != 2) throw Error(FHELIN_ERR_STATE, "bootstrap: ciphertext must be relinearised");
@@ -246,9 +253,9 @@ CtPtr Bootstrapper::mod_raise(const CtPtr& ct, long double& rho) {
     rho = x->scale * (long double)(1ull << correction) / q0;
 
     c.stats.bootstrap += 1;
-    CtPtr up = ev_.raw_modraise(x, c.L + 1);
+    CtPtr up = ev_.raw_modraise(x, top_ell);
     up->deg = 1;
-    up->scale = c.sf_real[0];
+    up->scale = c.sf_real[0];   // the scale the CoeffsToSlots constants were built for (setup), whatever the start level
     up->slots = slots_;
     // SubSum: project onto the subring of X^{N/(2 slots)} (sparse packing)
     const int gapN = (c.N / 2) / slots_;
@@ -273,10 +280,12 @@ std::vector<CtPtr> Bootstrapper::eval_mod(const std::vector<CtPtr>& xs) {
     return u;
 }
 
-CtPtr Bootstrapper::run(const CtPtr& ct, int stop_after) {
+CtPtr Bootstrapper::run(const CtPtr& ct, int stop_after, int drop) {
     if (!ready()) throw Error(FHELIN_ERR_STATE, "EvalBootstrapSetup has not been called");
+    Context& c = ev_.ctx();
+    if (drop < 0 || c.L + 1 - drop - depth_ < 1) throw Error(FHELIN_ERR_ARG, "bootstrap: level plan leaves no limb for the result");
     long double rho = 1;
-    CtPtr w = mod_raise(ct, rho);
+    CtPtr w = mod_raise(ct, rho, c.L + 1 - drop);
     if (stop_after == 1) return w;
     for (const auto& st : c2s_) w = apply(st, w);
     CtPtr wc = ev_.conjugate(w);
@@ -295,7 +304,7 @@ CtPtr Bootstrapper::run(const CtPtr& ct, int stop_after) {
     return v;
 }
 
-CtPtr Bootstrapper::bootstrap(const CtPtr& ct) { return run(ct, 0); }
+CtPtr Bootstrapper::bootstrap(const CtPtr& ct, int drop) { return run(ct, 0, drop); }
 CtPtr Bootstrapper::partial(const CtPtr& ct, int stage) { return run(ct, stage); }
 
 }  // namespace fhelin

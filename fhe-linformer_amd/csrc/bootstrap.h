@@ -32,10 +32,13 @@ public:
     ~Bootstrapper();
     void setup(int budget_enc, int budget_dec, int slots);
     bool ready() const { return slots_ > 0; }
-    CtPtr bootstrap(const CtPtr& ct);
+    // drop: raise to L+1-drop limbs only, so that the result has `drop` limbs fewer (level plan: the caller knows that the
+    // circuit up to the next bootstrap leaves that many unused)
+    CtPtr bootstrap(const CtPtr& ct, int drop = 0);
     // debug / test hook: stop after stage 1 (ModRaise+SubSum), 2 (CoeffsToSlots, real part), 3 (EvalMod, real part)
     CtPtr partial(const CtPtr& ct, int stage);
     int depth() const { return depth_; }
+    int out_ell() const { return ev_.ctx().L + 1 - depth_; }   // limbs of the result when nothing is dropped
 
     // parameters (DESIGN.md "Bootstrapping")
     int K = 28;            // bound on |I|: t = Delta m + q0 I
@@ -55,9 +58,9 @@ private:
     LinStage prepare(const DiagMap& m);
     CtPtr apply(const LinStage& st, const CtPtr& x);
     CtPtr mult_i(const CtPtr& x);
-    CtPtr mod_raise(const CtPtr& ct, long double& rho);
+    CtPtr mod_raise(const CtPtr& ct, long double& rho, int top_ell);
     std::vector<CtPtr> eval_mod(const std::vector<CtPtr>& xs);
-    CtPtr run(const CtPtr& ct, int stop_after);
+    CtPtr run(const CtPtr& ct, int stop_after, int drop = 0);
 };
 
 }  // namespace fhelin

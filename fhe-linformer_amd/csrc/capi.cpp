@@ -22,6 +22,39 @@ fhelin_ctx::fhelin_ctx(const fhelin::Params& p) : ctx(p), ev(ctx), cl(ev, ctx.pr
     if (const char* e = std::getenv("FHELIN_LAZY_ROWS")) lazy_rows = std::atoi(e) != 0;
 }
 
+#define NEED(x) if (!(x)) return capi_fail(FHELIN_ERR_ARG, "null argument")
+
+namespace fhelin {
+std::vector<int>& plan_inputs() {
+    static thread_local std::vector<int> v;
+    return v;
+}
+// Back to front over the recording: a value that some chain of consumers needs with `need` effective limbs asks of each of its
+// producers' inputs need + (limbs the producing call consumed); an input that sat above the lowest one at recording time
+// keeps one limb more than that, so that the level adjustment it went through (integer scalar x rescale) still has its limb.
+void LevelPlan::finish() {
+    target.assign(next_ordinal, -1);
+    for (int n = (int)nodes.size() - 1; n >= 0; --n) {
+        Node& nd = nodes[n];
+        if (nd.need < 0 || nd.eff < 0) continue;
+        if (nd.ordinal >= 0) {
+            if (nd.ordinal < (int)target.size()) target[nd.ordinal] = std::min(nd.eff, std::max(nd.need, 1));
+            continue;
+        }
+        int lo = 1 << 30;
+        for (int i : nd.in)
+            if (nodes[i].eff >= 0) lo = std::min(lo, nodes[i].eff);
+        if (lo == 1 << 30) continue;
+        const int used = std::max(0, lo - nd.eff);
+        for (int i : nd.in) {
+            Node& src = nodes[i];
+            if (src.eff < 0) continue;
+            src.need = std::max(src.need, std::min(src.eff, nd.need + used + (src.eff > lo ? 1 : 0)));
+        }
+    }
+}
+}  // namespace fhelin
+
 extern "C" {
 
 const char* fhelin_last_error(void) { return g_last_error.c_str(); }
@@ -127,6 +160,40 @@ int fhelin_ctx_set_lazy_rows(fhelin_ctx* c, int32_t on) {
     return FHELIN_OK;
 }
 
+int fhelin_level_plan_begin(fhelin_ctx* c, int32_t mode) {
+    NEED(c);
+    if (mode < 0 || mode > 2) return capi_fail(FHELIN_ERR_ARG, "level plan: mode is 0 (off), 1 (record) or 2 (apply)");
+    if (mode == 2 && c->plan.target.empty()) return capi_fail(FHELIN_ERR_STATE, "level plan: nothing recorded or loaded to apply");
+    c->plan.begin(mode);
+    return FHELIN_OK;
+}
+int fhelin_level_plan_seek(fhelin_ctx* c, int32_t source) {
+    NEED(c);
+    if (source < 0) return capi_fail(FHELIN_ERR_ARG, "level plan: negative source index");
+    if (c->plan.mode == 1) return capi_fail(FHELIN_ERR_STATE, "level plan: a recording pass runs from its first source");
+    c->plan.next_ordinal = source;
+    return FHELIN_OK;
+}
+int fhelin_level_plan_end(fhelin_ctx* c, int32_t* n_sources) {
+    NEED(c);
+    FHELIN_TRY
+    if (c->plan.mode == 1) c->plan.finish();
+    if (n_sources) *n_sources = (int32_t)c->plan.target.size();
+    c->plan.begin(0);
+    FHELIN_CATCH
+}
+int fhelin_level_plan_get(fhelin_ctx* c, int32_t* target, int32_t cap, int32_t* n) {
+    NEED(c && n && (target || cap <= 0));
+    *n = (int32_t)c->plan.target.size();
+    for (int32_t i = 0; i < cap && i < *n; ++i) target[i] = c->plan.target[i];
+    return FHELIN_OK;
+}
+int fhelin_level_plan_set(fhelin_ctx* c, const int32_t* target, int32_t n) {
+    NEED(c && (target || n == 0));
+    if (n < 0) return capi_fail(FHELIN_ERR_ARG, "level plan: negative length");
+    c->plan.target.assign(target, target + n);
+    return FHELIN_OK;
+}
 int fhelin_sync(fhelin_ctx* c) {
     if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
     FHELIN_TRY

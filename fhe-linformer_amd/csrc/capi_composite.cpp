@@ -7,11 +7,6 @@ using namespace fhelin;
 
 #define NEED(x) if (!(x)) return capi_fail(FHELIN_ERR_ARG, "null argument")
 
-static fhelin_ct* wrap(const CtPtr& p) {
-    auto* h = new fhelin_ct;
-    h->p = p;
-    return h;
-}
 static CtVec vec_of(fhelin_ctx* c, const fhelin_ct* const* v, int n) {
     for (int i = 0; i < n; ++i)
         if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext handle in array");
@@ -28,6 +23,10 @@ static void emit_lazy(fhelin_ctx* c, const std::shared_ptr<LazyRows>& g, int n, 
         h->lazy = g;
         h->lazy_idx = i;
         h->owner = c;
+        if (c->plan.mode == 1) {
+            h->node = c->plan.add_node(plan_inputs(), -1);   // level known once the row is evaluated (force_rows)
+            g->node.push_back(h->node);
+        }
         outs[i] = h;
     }
 }
@@ -46,7 +45,10 @@ void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx) {
     } else {
         r = c->comp.unwrapExpanded_rows(g.src, g.n, todo);
     }
-    for (size_t k = 0; k < todo.size(); ++k) g.done[todo[k]] = r[k];
+    for (size_t k = 0; k < todo.size(); ++k) {
+        g.done[todo[k]] = r[k];
+        if (c->plan.mode == 1 && !g.node.empty()) c->plan.nodes[g.node[todo[k]]].eff = LevelPlan::eff_of(*r[k]);
+    }
     bool all = true;
     for (const CtPtr& d : g.done) all = all && d;
     if (all) {  // nothing left to evaluate: release the inputs
@@ -80,8 +82,8 @@ void force_group(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx) {
         force_rows(c, g, rest);
 }
 }  // namespace fhelin
-static void emit(const CtVec& v, fhelin_ct** outs) {
-    for (size_t i = 0; i < v.size(); ++i) outs[i] = wrap(v[i]);
+static void emit(fhelin_ctx* c, const CtVec& v, fhelin_ct** outs) {
+    for (size_t i = 0; i < v.size(); ++i) outs[i] = wrap(c, v[i]);
 }
 static PtPtr opt(const fhelin_pt* p) { return p ? p->p : PtPtr(); }
 
@@ -90,48 +92,48 @@ extern "C" {
 int fhelin_rotate_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t index, fhelin_ct** outs) {
     NEED(c && v && outs && n >= 0);
     FHELIN_TRY
-    emit(c->ev.rotate_batch(vec_of(c, v, n), index), outs);
+    emit(c, c->ev.rotate_batch(vec_of(c, v, n), index), outs);
     FHELIN_CATCH
 }
 int fhelin_rescale_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** outs) {
     NEED(c && v && outs && n >= 0);
     FHELIN_TRY
-    emit(c->ev.rescale_batch(vec_of(c, v, n)), outs);
+    emit(c, c->ev.rescale_batch(vec_of(c, v, n)), outs);
     FHELIN_CATCH
 }
 int fhelin_mult_plain_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const fhelin_pt* p, fhelin_ct** outs) {
     NEED(c && v && p && outs && n >= 0);
     FHELIN_TRY
-    emit(c->ev.mult_plain_batch(vec_of(c, v, n), p->p), outs);
+    emit(c, c->ev.mult_plain_batch(vec_of(c, v, n), p->p), outs);
     FHELIN_CATCH
 }
 int fhelin_mult_batch(fhelin_ctx* c, const fhelin_ct* const* a, const fhelin_ct* const* b, int32_t n, fhelin_ct** outs) {
     NEED(c && a && b && outs && n >= 0);
     FHELIN_TRY
-    emit(c->ev.mult_batch(vec_of(c, a, n), vec_of(c, b, n)), outs);
+    emit(c, c->ev.mult_batch(vec_of(c, a, n), vec_of(c, b, n)), outs);
     FHELIN_CATCH
 }
 int fhelin_add_batch(fhelin_ctx* c, const fhelin_ct* const* a, const fhelin_ct* const* b, int32_t n, fhelin_ct** outs) {
     NEED(c && a && b && outs && n >= 0);
     FHELIN_TRY
-    emit(c->ev.add_batch(vec_of(c, a, n), vec_of(c, b, n)), outs);
+    emit(c, c->ev.add_batch(vec_of(c, a, n), vec_of(c, b, n)), outs);
     FHELIN_CATCH
 }
 int fhelin_fc_mult_const(fhelin_ctx* c, const fhelin_ct* a, double d, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->comp.mult_const(ct_in(c, a), d));
+    *out = wrap(c, c->comp.mult_const(ct_in(c, a), d));
     FHELIN_CATCH
 }
 int fhelin_fc_mask(fhelin_ctx* c, const fhelin_ct* a, int32_t kind, int32_t x, int32_t y, double v, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
     switch (kind) {
-        case 0: *out = wrap(c->comp.mask_block(ct_in(c, a), x, y, v)); break;
-        case 1: *out = wrap(c->comp.mask_heads(ct_in(c, a), v)); break;
-        case 2: *out = wrap(c->comp.mask_heads_128(ct_in(c, a), v)); break;
-        case 3: *out = wrap(c->comp.mask_mod_n(ct_in(c, a), x, y)); break;
-        case 4: *out = wrap(c->comp.mask_first_n(ct_in(c, a), x, v)); break;
+        case 0: *out = wrap(c, c->comp.mask_block(ct_in(c, a), x, y, v)); break;
+        case 1: *out = wrap(c, c->comp.mask_heads(ct_in(c, a), v)); break;
+        case 2: *out = wrap(c, c->comp.mask_heads_128(ct_in(c, a), v)); break;
+        case 3: *out = wrap(c, c->comp.mask_mod_n(ct_in(c, a), x, y)); break;
+        case 4: *out = wrap(c, c->comp.mask_first_n(ct_in(c, a), x, v)); break;
         default: throw Error(FHELIN_ERR_ARG, "unknown mask kind");
     }
     FHELIN_CATCH
@@ -139,19 +141,19 @@ int fhelin_fc_mask(fhelin_ctx* c, const fhelin_ct* a, int32_t kind, int32_t x, i
 int fhelin_fc_rotsum(fhelin_ctx* c, const fhelin_ct* a, int32_t slots, int32_t padding, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->comp.rotsum(ct_in(c, a), slots, padding));
+    *out = wrap(c, c->comp.rotsum(ct_in(c, a), slots, padding));
     FHELIN_CATCH
 }
 int fhelin_fc_repeat(fhelin_ctx* c, const fhelin_ct* a, int32_t slots, int32_t padding, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->comp.repeat(ct_in(c, a), slots, padding));
+    *out = wrap(c, c->comp.repeat(ct_in(c, a), slots, padding));
     FHELIN_CATCH
 }
 int fhelin_fc_add_many(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
     NEED(c && v && out);
     FHELIN_TRY
-    *out = wrap(c->comp.add_many(vec_of(c, v, n)));
+    *out = wrap(c, c->comp.add_many(vec_of(c, v, n)));
     FHELIN_CATCH
 }
 int fhelin_fc_matmul_pt(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* w, const fhelin_pt* bias,
@@ -168,7 +170,7 @@ int fhelin_fc_matmul_pt(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, 
         g->padding = padding;
         emit_lazy(c, g, n, outs);
     } else {
-        emit(c->comp.matmul_pt(vec_of(c, rows, n), w->p, opt(bias), slots, padding), outs);
+        emit(c, c->comp.matmul_pt(vec_of(c, rows, n), w->p, opt(bias), slots, padding), outs);
     }
     FHELIN_CATCH
 }
@@ -176,7 +178,7 @@ int fhelin_fc_matmul_ct(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, 
                         int32_t padding, fhelin_ct** outs) {
     NEED(c && rows && w && outs);
     FHELIN_TRY
-    emit(c->comp.matmul_ct(vec_of(c, rows, n), ct_in(c, w), slots, padding), outs);
+    emit(c, c->comp.matmul_ct(vec_of(c, rows, n), ct_in(c, w), slots, padding), outs);
     FHELIN_CATCH
 }
 int fhelin_fc_matmulRElarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* const* weights, int32_t nw,
@@ -188,7 +190,7 @@ int fhelin_fc_matmulRElarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t
         if (!weights[i]) throw Error(FHELIN_ERR_ARG, "null weight");
         w.push_back(weights[i]->p);
     }
-    emit(c->comp.matmulRElarge(vec_of(c, rows, n), w, opt(bias), mask_val), outs);
+    emit(c, c->comp.matmulRElarge(vec_of(c, rows, n), w, opt(bias), mask_val), outs);
     FHELIN_CATCH
 }
 int fhelin_fc_matmulCRlarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* const* weights,
@@ -202,25 +204,25 @@ int fhelin_fc_matmulCRlarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t
     }
     std::vector<CtVec> r;
     for (int i = 0; i < n; ++i) r.push_back(vec_of(c, rows + 4 * i, 4));
-    emit(c->comp.matmulCRlarge(r, w, opt(bias)), outs);
+    emit(c, c->comp.matmulCRlarge(r, w, opt(bias)), outs);
     FHELIN_CATCH
 }
 int fhelin_fc_matmulScores(fhelin_ctx* c, const fhelin_ct* const* queries, int32_t n, const fhelin_ct* key, fhelin_ct** out) {
     NEED(c && queries && key && out);
     FHELIN_TRY
-    *out = wrap(c->comp.matmulScores(vec_of(c, queries, n), ct_in(c, key)));
+    *out = wrap(c, c->comp.matmulScores(vec_of(c, queries, n), ct_in(c, key)));
     FHELIN_CATCH
 }
 int fhelin_fc_wrapUpRepeated(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
     NEED(c && v && out);
     FHELIN_TRY
-    *out = wrap(c->comp.wrapUpRepeated(vec_of(c, v, n)));
+    *out = wrap(c, c->comp.wrapUpRepeated(vec_of(c, v, n)));
     FHELIN_CATCH
 }
 int fhelin_fc_wrapUpExpanded(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
     NEED(c && v && out);
     FHELIN_TRY
-    *out = wrap(c->comp.wrapUpExpanded(vec_of(c, v, n)));
+    *out = wrap(c, c->comp.wrapUpExpanded(vec_of(c, v, n)));
     FHELIN_CATCH
 }
 int fhelin_fc_unwrapExpanded(fhelin_ctx* c, const fhelin_ct* a, int32_t n, fhelin_ct** outs) {
@@ -233,20 +235,20 @@ int fhelin_fc_unwrapExpanded(fhelin_ctx* c, const fhelin_ct* a, int32_t n, fheli
         g->n = n;
         emit_lazy(c, g, n, outs);
     } else {
-        emit(c->comp.unwrapExpanded(ct_in(c, a), n), outs);
+        emit(c, c->comp.unwrapExpanded(ct_in(c, a), n), outs);
     }
     FHELIN_CATCH
 }
 int fhelin_fc_unwrapScoresExpanded(fhelin_ctx* c, const fhelin_ct* a, int32_t n, fhelin_ct** outs) {
     NEED(c && a && outs);
     FHELIN_TRY
-    emit(c->comp.unwrapScoresExpanded(ct_in(c, a), n), outs);
+    emit(c, c->comp.unwrapScoresExpanded(ct_in(c, a), n), outs);
     FHELIN_CATCH
 }
 int fhelin_fc_unwrap_512_in_4_128(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** outs4) {
     NEED(c && a && outs4);
     FHELIN_TRY
-    emit(c->comp.unwrap_512_in_4_128(ct_in(c, a), index), outs4);
+    emit(c, c->comp.unwrap_512_in_4_128(ct_in(c, a), index), outs4);
     FHELIN_CATCH
 }
 int fhelin_fc_unwrapRepeatedLarge(fhelin_ctx* c, const fhelin_ct* const* containers, int32_t nc, int32_t input_number,
@@ -254,7 +256,7 @@ int fhelin_fc_unwrapRepeatedLarge(fhelin_ctx* c, const fhelin_ct* const* contain
     NEED(c && containers && outs);
     FHELIN_TRY
     auto r = c->comp.unwrapRepeatedLarge(vec_of(c, containers, nc), input_number);
-    for (size_t i = 0; i < r.size(); ++i) emit(r[i], outs + 4 * i);
+    for (size_t i = 0; i < r.size(); ++i) emit(c, r[i], outs + 4 * i);
     FHELIN_CATCH
 }
 int fhelin_fc_unwrapRepeatedLarge_range(fhelin_ctx* c, const fhelin_ct* const* containers, int32_t nc, int32_t input_number,
@@ -262,7 +264,7 @@ int fhelin_fc_unwrapRepeatedLarge_range(fhelin_ctx* c, const fhelin_ct* const* c
     NEED(c && containers && outs);
     FHELIN_TRY
     auto r = c->comp.unwrapRepeatedLarge(vec_of(c, containers, nc), input_number, first, count);
-    for (size_t i = 0; i < r.size(); ++i) emit(r[i], outs + 4 * i);
+    for (size_t i = 0; i < r.size(); ++i) emit(c, r[i], outs + 4 * i);
     FHELIN_CATCH
 }
 int fhelin_fc_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs, int32_t n, const fhelin_pt* bias,
@@ -270,53 +272,53 @@ int fhelin_fc_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs,
     NEED(c && inputs && outs);
     FHELIN_TRY
     auto r = c->comp.generate_containers(vec_of(c, inputs, n), opt(bias));
-    emit(r, outs);
+    emit(c, r, outs);
     if (n_out) *n_out = (int)r.size();
     FHELIN_CATCH
 }
 int fhelin_fc_wrap_containers(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t inputs_number, fhelin_ct** out) {
     NEED(c && v && out);
     FHELIN_TRY
-    *out = wrap(c->comp.wrap_containers(vec_of(c, v, n), inputs_number));
+    *out = wrap(c, c->comp.wrap_containers(vec_of(c, v, n), inputs_number));
     FHELIN_CATCH
 }
 
 int fhelin_mult_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.mult_real(ct_in(c, a), k));
+    *out = wrap(c, c->ev.mult_real(ct_in(c, a), k));
     FHELIN_CATCH
 }
 int fhelin_add_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.add_real(ct_in(c, a), k));
+    *out = wrap(c, c->ev.add_real(ct_in(c, a), k));
     FHELIN_CATCH
 }
 int fhelin_mult_many(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** out) {
     NEED(c && v && out);
     FHELIN_TRY
-    *out = wrap(c->ev.mult_many(vec_of(c, v, n)));
+    *out = wrap(c, c->ev.mult_many(vec_of(c, v, n)));
     FHELIN_CATCH
 }
 int fhelin_lincomb(fhelin_ctx* c, const fhelin_ct* const* v, const double* coeffs, int32_t n, double c0, fhelin_ct** out) {
     NEED(c && v && coeffs && out && n >= 1);
     FHELIN_TRY
-    *out = wrap(c->ev.lincomb(vec_of(c, v, n), std::vector<double>(coeffs, coeffs + n), c0));
+    *out = wrap(c, c->ev.lincomb(vec_of(c, v, n), std::vector<double>(coeffs, coeffs + n), c0));
     FHELIN_CATCH
 }
 int fhelin_eval_poly(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, int32_t n, fhelin_ct** out) {
     NEED(c && x && coeffs && out);
     FHELIN_TRY
     const std::vector<double> cf(coeffs, coeffs + n);
-    *out = wrap(run_heavy(c, x, [&](const CtPtr& in) { return c->ev.eval_poly(in, cf); }));
+    *out = wrap(c, run_heavy(c, x, [&](const CtPtr& in) { return c->ev.eval_poly(in, cf); }));
     FHELIN_CATCH
 }
 int fhelin_eval_chebyshev(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, int32_t n, double a, double b, fhelin_ct** out) {
     NEED(c && x && coeffs && out);
     FHELIN_TRY
     const std::vector<double> cf(coeffs, coeffs + n);
-    *out = wrap(run_heavy(c, x, [&](const CtPtr& in) { return c->ev.eval_chebyshev(in, cf, a, b); }));
+    *out = wrap(c, run_heavy(c, x, [&](const CtPtr& in) { return c->ev.eval_chebyshev(in, cf, a, b); }));
     FHELIN_CATCH
 }
 int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t budget_enc, int32_t budget_dec, int32_t slots) {
@@ -328,13 +330,21 @@ int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t budget_enc, int32_t budget_dec
 int fhelin_bootstrap(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(run_heavy(c, a, [&](const CtPtr& in) { return c->boot.bootstrap(in); }));
+    // a bootstrap is a terminal for its input (two limbs are all it reads) and a source of the level plan for its output
+    const int drop = c->plan.next_drop(c->boot.out_ell());
+    if (a->node >= 0) c->plan.terminal(a->node, 2);
+    *out = wrap(c, run_heavy(c, a, [&](const CtPtr& in) { return c->boot.bootstrap(in, drop); }));
+    if ((*out)->node >= 0) {
+        LevelPlan::Node& nd = c->plan.nodes[(*out)->node];
+        nd.in.clear();
+        nd.ordinal = c->plan.next_ordinal - 1;
+    }
     FHELIN_CATCH
 }
 int fhelin_bootstrap_partial(fhelin_ctx* c, const fhelin_ct* a, int32_t stage, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->boot.partial(ct_in(c, a), stage));
+    *out = wrap(c, c->boot.partial(ct_in(c, a), stage));
     FHELIN_CATCH
 }
 int fhelin_bootstrap_config(fhelin_ctx* c, int32_t K, int32_t R, int32_t cheb_degree, int32_t correction) {

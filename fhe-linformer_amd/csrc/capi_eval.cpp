@@ -8,11 +8,6 @@ using namespace fhelin;
 
 #define NEED(x) if (!(x)) return capi_fail(FHELIN_ERR_ARG, "null argument")
 
-static fhelin_ct* wrap(const CtPtr& p) {
-    auto* h = new fhelin_ct;
-    h->p = p;
-    return h;
-}
 
 static KeyPtr& key_slot(fhelin_ctx* c, int kind, int index) {
     if (kind == 0) return c->ev.relin_key;
@@ -108,14 +103,42 @@ int fhelin_pt_export(fhelin_ctx* c, const fhelin_pt* p, int32_t ell, double scal
 int fhelin_encrypt(fhelin_ctx* c, const fhelin_pt* p, fhelin_ct** out) {
     NEED(c && p && out);
     FHELIN_TRY
-    *out = wrap(c->cl.encrypt(p->p));
+    *out = wrap(c, c->cl.encrypt(p->p, c->plan.next_drop(c->ctx.L + 1 - p->p->level)));
+    if ((*out)->node >= 0) c->plan.nodes[(*out)->node].ordinal = c->plan.next_ordinal - 1;
     FHELIN_CATCH
 }
 int fhelin_encrypt_batch(fhelin_ctx* c, const double* vals, int32_t n_vec, int32_t n_per, int32_t level, int32_t slots, fhelin_ct** outs) {
     NEED(c && (vals || n_vec == 0) && outs);
     FHELIN_TRY
-    std::vector<CtPtr> r = c->cl.encrypt_batch(vals, n_vec, n_per, level, slots);
-    for (int i = 0; i < n_vec; ++i) outs[i] = wrap(r[i]);
+    // every vector is a source of the level plan of its own: vectors that the plan starts at the same level go through
+    // the batched encryptor together
+    std::vector<int> drop(n_vec);
+    for (int i = 0; i < n_vec; ++i) drop[i] = std::min(c->ctx.L - level, c->plan.next_drop(c->ctx.L + 1 - level));
+    const int first_ordinal = c->plan.next_ordinal - n_vec;
+    std::vector<CtPtr> r(n_vec);
+    std::vector<char> seen(n_vec, 0);
+    for (int i = 0; i < n_vec; ++i) {
+        if (seen[i]) continue;
+        std::vector<int> pick;
+        for (int j = i; j < n_vec; ++j)
+            if (!seen[j] && drop[j] == drop[i]) {
+                pick.push_back(j);
+                seen[j] = 1;
+            }
+        if ((int)pick.size() == n_vec) {
+            r = c->cl.encrypt_batch(vals, n_vec, n_per, level + drop[i], slots);
+            break;
+        }
+        std::vector<double> sub((size_t)pick.size() * n_per);
+        for (size_t k = 0; k < pick.size(); ++k)
+            std::memcpy(sub.data() + k * n_per, vals + (size_t)pick[k] * n_per, (size_t)n_per * sizeof(double));
+        std::vector<CtPtr> part = c->cl.encrypt_batch(sub.data(), (int)pick.size(), n_per, level + drop[i], slots);
+        for (size_t k = 0; k < pick.size(); ++k) r[pick[k]] = part[k];
+    }
+    for (int i = 0; i < n_vec; ++i) {
+        outs[i] = wrap(c, r[i]);
+        if (outs[i]->node >= 0) c->plan.nodes[outs[i]->node].ordinal = first_ordinal + i;
+    }
     FHELIN_CATCH
 }
 int fhelin_ctx_set_host_encode(fhelin_ctx* c, int32_t on) {
@@ -134,6 +157,8 @@ int fhelin_debug_sample(fhelin_ctx* c, int32_t kind, int32_t n_poly, int64_t* ou
 int fhelin_decrypt(fhelin_ctx* c, const fhelin_ct* ct, double* out, int32_t slots) {
     NEED(c && ct && out);
     FHELIN_TRY
+    c->plan.terminal(ct->node, 2);
+    c->plan.check_terminal(*ct_in(c, ct), 2);
     auto v = c->cl.decrypt(ct_in(c, ct), slots);
     std::memcpy(out, v.data(), v.size() * sizeof(double));
     FHELIN_CATCH
@@ -145,13 +170,15 @@ int fhelin_ct_import(fhelin_ctx* c, const uint64_t* limbs, int32_t npoly, int32_
     CtPtr p = c->ev.new_ct(npoly, ell, deg, scale, slots);
     hip_check(hipMemcpyAsync(p->d, limbs, p->words() * 8, hipMemcpyHostToDevice, c->ctx.stream), "ct import");
     c->ctx.sync();
-    *out = wrap(p);
+    *out = wrap(c, p);
     FHELIN_CATCH
 }
 int fhelin_ct_export(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* out, size_t cap) {
     NEED(c && ct && out);
     FHELIN_TRY
+    c->plan.terminal(ct->node, 2);
     const CtPtr& p = ct_in(c, ct);
+    c->plan.check_terminal(*p, 2);
     if (cap < p->words()) throw Error(FHELIN_ERR_ARG, "buffer too small");
     hip_check(hipMemcpyAsync(out, p->d, p->words() * 8, hipMemcpyDeviceToHost, c->ctx.stream), "ct export");
     c->ctx.sync();
@@ -160,7 +187,9 @@ int fhelin_ct_export(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* out, size_t c
 int fhelin_ct_export_device(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* d_out, size_t cap) {
     NEED(c && ct && d_out);
     FHELIN_TRY
+    c->plan.terminal(ct->node, 2);
     const CtPtr& p = ct_in(c, ct);
+    c->plan.check_terminal(*p, 2);
     if (cap < p->words()) throw Error(FHELIN_ERR_ARG, "buffer too small");
     hip_check(hipMemcpyAsync(d_out, p->d, p->words() * 8, hipMemcpyDeviceToDevice, c->ctx.stream), "ct export (device)");
     c->ctx.sync();   // the caller's framework reads the buffer on its own stream next
@@ -173,7 +202,7 @@ int fhelin_ct_import_device(fhelin_ctx* c, const uint64_t* d_limbs, int32_t npol
     CtPtr p = c->ev.new_ct(npoly, ell, deg, (long double)scale_hi + (long double)scale_lo, slots);
     hip_check(hipMemcpyAsync(p->d, d_limbs, p->words() * 8, hipMemcpyDeviceToDevice, c->ctx.stream), "ct import (device)");
     c->ctx.sync();
-    *out = wrap(p);
+    *out = wrap(c, p);
     FHELIN_CATCH
 }
 int fhelin_ct_scale(const fhelin_ct* ct, double* scale_hi, double* scale_lo) {
@@ -214,7 +243,7 @@ int fhelin_ct_clone(fhelin_ctx* c, const fhelin_ct* ct, fhelin_ct** out) {
     FHELIN_TRY
     // ciphertext objects are immutable (every operation returns a new one), so Clone() is a new HANDLE to the same
     // residues: no copy — and rows that are clones of one ciphertext can be recognised as identical (Composite::matmul_pt)
-    *out = wrap(ct_in(c, ct));
+    *out = wrap(c, ct_in(c, ct));
     FHELIN_CATCH
 }
 void fhelin_ct_free(fhelin_ct* ct) { delete ct; }
@@ -225,7 +254,7 @@ void fhelin_ct_free(fhelin_ct* ct) { delete ct; }
         FHELIN_TRY                                                                          \
         const fhelin_ct* both[2] = {a, b};                                                  \
         force_many(c, both, 2); /* deferred operands of one group: one batched call */      \
-        *out = wrap(expr);                                                                  \
+        *out = wrap(c, expr);                                                                  \
         FHELIN_CATCH                                                                        \
     }
 BINOP(fhelin_add, c->ev.add(ct_in(c, a), ct_in(c, b)))
@@ -237,32 +266,32 @@ BINOP(fhelin_raw_mult_relin, (c->ev.relin_key ? c->ev.raw_mult_relin(ct_in(c, a)
 int fhelin_negate(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.negate(ct_in(c, a)));
+    *out = wrap(c, c->ev.negate(ct_in(c, a)));
     FHELIN_CATCH
 }
 int fhelin_add_plain(fhelin_ctx* c, const fhelin_ct* a, const fhelin_pt* p, fhelin_ct** out) {
     NEED(c && a && p && out);
     FHELIN_TRY
-    *out = wrap(c->ev.add_plain(ct_in(c, a), p->p));
+    *out = wrap(c, c->ev.add_plain(ct_in(c, a), p->p));
     FHELIN_CATCH
 }
 int fhelin_mult_plain(fhelin_ctx* c, const fhelin_ct* a, const fhelin_pt* p, fhelin_ct** out) {
     NEED(c && a && p && out);
     FHELIN_TRY
-    *out = wrap(c->ev.mult_plain(ct_in(c, a), p->p));
+    *out = wrap(c, c->ev.mult_plain(ct_in(c, a), p->p));
     FHELIN_CATCH
 }
 int fhelin_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.rotate(ct_in(c, a), index));
+    *out = wrap(c, c->ev.rotate(ct_in(c, a), index));
     FHELIN_CATCH
 }
 int fhelin_rotate_many(fhelin_ctx* c, const fhelin_ct* a, const int32_t* indices, int32_t n, fhelin_ct** outs) {
     NEED(c && a && indices && outs && n >= 0);
     FHELIN_TRY
     std::vector<CtPtr> r = c->ev.rotate_many(ct_in(c, a), std::vector<int>(indices, indices + n));
-    for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
+    for (int i = 0; i < n; ++i) outs[i] = wrap(c, r[i]);
     FHELIN_CATCH
 }
 int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* indices, int32_t n, fhelin_ct** outs) {
@@ -274,7 +303,7 @@ int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* 
     force_many(c, v, n);
     for (int i = 0; i < n; ++i) in.push_back(ct_in(c, v[i]));
     std::vector<CtPtr> r = c->ev.rotate_each(in, std::vector<int>(indices, indices + n));
-    for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
+    for (int i = 0; i < n; ++i) outs[i] = wrap(c, r[i]);
     FHELIN_CATCH
 }
 int fhelin_rotate_sum(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const int32_t* indices, int32_t n_rot, fhelin_ct** outs) {
@@ -286,7 +315,7 @@ int fhelin_rotate_sum(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const
     force_many(c, v, n);
     for (int i = 0; i < n; ++i) in.push_back(ct_in(c, v[i]));
     std::vector<CtPtr> r = c->ev.rotate_sum_batch(in, std::vector<int>(indices, indices + n_rot));
-    for (int i = 0; i < n; ++i) outs[i] = wrap(r[i]);
+    for (int i = 0; i < n; ++i) outs[i] = wrap(c, r[i]);
     FHELIN_CATCH
 }
 int fhelin_rotate_each_sum(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* indices, int32_t n, fhelin_ct** out) {
@@ -297,38 +326,38 @@ int fhelin_rotate_each_sum(fhelin_ctx* c, const fhelin_ct* const* v, const int32
         if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext in array");
     force_many(c, v, n);
     for (int i = 0; i < n; ++i) in.push_back(ct_in(c, v[i]));
-    *out = wrap(c->ev.rotate_each_sum(in, std::vector<int>(indices, indices + n)));
+    *out = wrap(c, c->ev.rotate_each_sum(in, std::vector<int>(indices, indices + n)));
     FHELIN_CATCH
 }
 int fhelin_raw_modraise(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.raw_modraise(ct_in(c, a), new_ell));
+    *out = wrap(c, c->ev.raw_modraise(ct_in(c, a), new_ell));
     FHELIN_CATCH
 }
 int fhelin_raw_phase(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
     const CtPtr& p = ct_in(c, a);
-    *out = wrap(c->cl.phase(p, p->ell));
+    *out = wrap(c, c->cl.phase(p, p->ell));
     FHELIN_CATCH
 }
 int fhelin_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.rescale(ct_in(c, a)));
+    *out = wrap(c, c->ev.rescale(ct_in(c, a)));
     FHELIN_CATCH
 }
 int fhelin_level_reduce(fhelin_ctx* c, const fhelin_ct* a, int32_t new_ell, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.level_reduce(ct_in(c, a), new_ell));
+    *out = wrap(c, c->ev.level_reduce(ct_in(c, a), new_ell));
     FHELIN_CATCH
 }
 int fhelin_raw_rescale(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     NEED(c && a && out);
     FHELIN_TRY
-    *out = wrap(c->ev.raw_rescale(ct_in(c, a)));
+    *out = wrap(c, c->ev.raw_rescale(ct_in(c, a)));
     FHELIN_CATCH
 }
 int fhelin_raw_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_ct** out) {
@@ -337,7 +366,7 @@ int fhelin_raw_rotate(fhelin_ctx* c, const fhelin_ct* a, int32_t index, fhelin_c
     const u64 g = c->ctx.galois_element(index);
     auto it = c->ev.rot_keys.find(g);
     if (it == c->ev.rot_keys.end() || !it->second) throw Error(FHELIN_ERR_KEY, "no rotation key for this index");
-    *out = wrap(c->ev.raw_rotate(ct_in(c, a), g, *it->second));
+    *out = wrap(c, c->ev.raw_rotate(ct_in(c, a), g, *it->second));
     FHELIN_CATCH
 }
 

@@ -8,6 +8,57 @@
 #include "composite.h"
 #include "bootstrap.h"
 
+namespace fhelin {
+// Profile-guided level planning (include/fhelin.h fhelin_level_plan_*).
+// The drivers are straight-line programs: which ciphertext meets which, and how many limbs each operation consumes, does
+// not depend on the data.  A RECORDING pass notes, for every handle the boundary gives out, the handles the producing call
+// read and the result's effective limb count (limbs minus a pending rescale).  From that the planner derives, back to
+// front, the fewest limbs each value may have without any terminal (a bootstrap input, a decryption, an export) running
+// short, and so by how many limbs every SOURCE - a fresh encryption, a bootstrap output - can start lower.  An APPLYING pass
+// of the same program then encrypts at that level and raises bootstrap inputs to fewer limbs, so that limbs nobody would
+// ever use are not carried through the key switches in between.  Sources are identified by their order in the pass.
+struct LevelPlan {
+    int mode = 0;  // 0 off, 1 record, 2 apply
+    struct Node {
+        std::vector<int> in;
+        int eff = -1;       // limbs - (deg >= 2): -1 while a deferred row is unevaluated
+        int ordinal = -1;   // >= 0: a source
+        int need = -1;      // fewest effective limbs any consumer chain requires (-1: reaches no terminal)
+    };
+    std::vector<Node> nodes;
+    int next_ordinal = 0;
+    std::vector<int> target;    // the plan, per source ordinal: effective limbs the source should start with (-1: as asked)
+
+    static int eff_of(const Ciphertext& c) { return c.ell - (c.deg >= 2 ? 1 : 0); }
+    int add_node(const std::vector<int>& in, int eff) {
+        nodes.push_back(Node{in, eff, -1, -1});
+        return (int)nodes.size() - 1;
+    }
+    void terminal(int node, int need) {
+        if (mode == 1 && node >= 0) nodes[node].need = std::max(nodes[node].need, need);
+    }
+    // applying: a terminal that is short of limbs means the pass is not the recorded program
+    void check_terminal(const Ciphertext& c, int need) const {
+        if (mode == 2 && eff_of(c) < need)
+            throw Error(FHELIN_ERR_STATE, "level plan: a value reached a decryption / export with fewer limbs than it needs - this pass does not follow the recorded program");
+    }
+    // the next source of the pass would start with `ell` limbs: how many of them to leave out (0 unless applying)
+    int next_drop(int ell) {
+        const int k = next_ordinal++;
+        if (mode != 2 || k >= (int)target.size() || target[k] < 1) return 0;
+        return std::max(0, ell - target[k]);
+    }
+    void begin(int m) {
+        mode = m;
+        next_ordinal = 0;
+        nodes.clear();
+    }
+    void finish();  // record mode: derive `target` from the recording (capi.cpp)
+};
+// handles read by the C-ABI call in progress on this thread (node ids of the recording context)
+std::vector<int>& plan_inputs();
+}  // namespace fhelin
+
 // opaque handle behind include/fhelin.h's `fhelin_ctx`
 struct fhelin_ctx {
     fhelin::Context ctx;
@@ -16,6 +67,7 @@ struct fhelin_ctx {
     fhelin::Composite comp;
     fhelin::Bootstrapper boot;
     bool lazy_rows = true;      // FHELIN_LAZY_ROWS
+    fhelin::LevelPlan plan;
     explicit fhelin_ctx(const fhelin::Params& p);
 };
 // Rows of a batched composite whose evaluation is DEFERRED until a row is consumed (fhelin_fc_matmul_pt,
@@ -35,6 +87,7 @@ struct LazyRows {
     int n = 0;
     std::vector<CtPtr> done;    // per row: null until evaluated
     int partial_reads = 0;      // reads so far that asked for only some of the rows (force_group)
+    std::vector<int> node;      // level-plan recording: the rows' node ids
 };
 }
 struct fhelin_ct {
@@ -42,6 +95,7 @@ struct fhelin_ct {
     mutable std::shared_ptr<fhelin::LazyRows> lazy;
     int lazy_idx = 0;
     fhelin_ctx* owner = nullptr;
+    int node = -1;                                    // level-plan recording: this value's node
 };
 struct fhelin_pt {
     fhelin::PtPtr p;
@@ -67,7 +121,18 @@ void force_many(fhelin_ctx* c, const fhelin_ct* const* v, int n);
 
 // The main stream is about to consume `h`: if a worker lane is still producing it, order the main stream behind the
 // producing op (no host wait) and drop the holds that op needed.
+inline void note_input(fhelin_ctx* c, const fhelin_ct* h) {
+    if (c->plan.mode == 1 && h->node >= 0) plan_inputs().push_back(h->node);
+}
+// a new handle for a result of the call in progress
+inline fhelin_ct* wrap(fhelin_ctx* c, const CtPtr& p) {
+    auto* h = new fhelin_ct;
+    h->p = p;
+    if (c->plan.mode == 1) h->node = c->plan.add_node(plan_inputs(), LevelPlan::eff_of(*p));
+    return h;
+}
 inline const CtPtr& ct_in(fhelin_ctx* c, const fhelin_ct* h) {
+    note_input(c, h);
     force(c, h);
     Ciphertext& ct = *h->p;
     if (ct.async_pending) {
@@ -86,6 +151,7 @@ inline const CtPtr& ct_in(fhelin_ctx* c, const fhelin_ct* h) {
 template <class F>
 CtPtr run_heavy(fhelin_ctx* c, const fhelin_ct* in, F&& f) {
     Context& x = c->ctx;
+    note_input(c, in);
     force(c, in);               // a deferred input is evaluated on the main stream, before the lane is entered
     if (x.n_lanes < 2 || !x.async_lanes || x.stream != x.main_stream) return f(ct_in(c, in));
     Ciphertext& ci = *in->p;
@@ -110,7 +176,7 @@ CtPtr run_heavy(fhelin_ctx* c, const fhelin_ct* in, F&& f) {
 }
 }
 
-#define FHELIN_TRY try {
+#define FHELIN_TRY try { fhelin::plan_inputs().clear();
 #define FHELIN_CATCH                                                          \
     return FHELIN_OK;                                                         \
     }                                                                         \

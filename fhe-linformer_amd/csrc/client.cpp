@@ -500,10 +500,11 @@ void Client::encrypt_encoded(const u64* enc, size_t enc_stride, int n_vec, int e
     for (auto& ct : cts) out.push_back(ct);
 }
 
-CtPtr Client::encrypt(const PtPtr& p) {
+CtPtr Client::encrypt(const PtPtr& p, int drop) {
     if (!pk) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
-    const int ell = c_.L + 1 - p->level;
-    auto enc = p->at(ell, c_.sf_real[p->level]);
+    const int level = std::min(c_.L, p->level + std::max(0, drop));   // level plan: start `drop` limbs lower
+    const int ell = c_.L + 1 - level;
+    auto enc = p->at(ell, c_.sf_real[level]);
     std::vector<CtPtr> out;
     encrypt_encoded(enc->d, 0, 1, ell, enc->scale, p->slots, out);
     return out[0];

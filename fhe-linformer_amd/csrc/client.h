@@ -42,7 +42,7 @@ public:
     KeyPtr make_switch_key(const u64* s_from_all, const u64* s_to_all);  // device [L+1+k][N] NTT form
 
     PtPtr encode(const double* vals, int n, int level, int slots);
-    CtPtr encrypt(const PtPtr& p);
+    CtPtr encrypt(const PtPtr& p, int drop = 0);   // drop: limbs left out below the plaintext's level (level plan)
     // n_vec real vectors of n_per values each (row-major) -> n_vec fresh ciphertexts at `level`: encoding (special FFT, scaling,
     // rounding), sampling of (u, e0, e1) and the dyadic combination all on the GPU, in batched launches
     std::vector<CtPtr> encrypt_batch(const double* vals, int n_vec, int n_per, int level, int slots);

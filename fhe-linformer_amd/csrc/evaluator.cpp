@@ -788,7 +788,7 @@ std::vector<CtPtr> Evaluator::mult_plain_each(const std::vector<CtPtr>& vin, con
     return out;
 }
 
-CtPtr Evaluator::dot_plain(const std::vector<CtPtr>& vin, const std::vector<PtPtr>& p) {
+CtPtr Evaluator::dot_plain(const std::vector<CtPtr>& vin, const std::vector<PtPtr>& p, long double pt_scale) {
     if (vin.size() != p.size() || vin.empty()) throw Error(FHELIN_ERR_ARG, "dot_plain: one plaintext per ciphertext, at least one term");
     // degree-2 operands are rescaled first, every distinct ciphertext once (as mult_plain does)
     std::vector<CtPtr> x = vin;
@@ -810,13 +810,14 @@ CtPtr Evaluator::dot_plain(const std::vector<CtPtr>& vin, const std::vector<PtPt
     for (const CtPtr& c : x)
         uniform = uniform && c->npoly == x[0]->npoly && c->ell == x[0]->ell && c->deg == x[0]->deg && fabsl(c->scale / x[0]->scale - 1.0L) < 1e-9L;
     if (!uniform) {
+        if (pt_scale > 0) throw Error(FHELIN_ERR_ARG, "dot_plain: an explicit plaintext scale needs uniform operands");
         std::vector<CtPtr> prod = mult_plain_each(x, p);
         CtPtr acc = prod[0];
         for (size_t i = 1; i < prod.size(); ++i) acc = add(acc, prod[i]);
         return acc;
     }
     const CtPtr& f = x[0];
-    const long double sf = c_.sf_real[f->level()];
+    const long double sf = pt_scale > 0 ? pt_scale : c_.sf_real[f->level()];
     CtPtr acc;
     for (size_t lo = 0; lo < x.size(); lo += EwItems::MAX_ITEMS) {
         const size_t hi = std::min(x.size(), lo + (size_t)EwItems::MAX_ITEMS);

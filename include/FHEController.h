@@ -166,7 +166,10 @@ public:
     int num_slots = 0;
 
     FHEController() {}
-    ~FHEController() { fhelin_ctx_destroy(context); }
+    ~FHEController() {
+        save_level_plan();
+        fhelin_ctx_destroy(context);
+    }
     FHEController(const FHEController&) = delete;
     FHEController& operator=(const FHEController&) = delete;
 
@@ -258,6 +261,7 @@ public:
         fhelin_ctx_destroy(context);
         context = nullptr;
         fhelin_shim::check(fhelin_ctx_create_seeded(&p, seed, &context), "GenCryptoContext");
+        start_level_plan();
         fhelin_shim::check(fhelin_keygen(context), "KeyGen");
         fhelin_shim::check(fhelin_gen_relin_key(context), "EvalMultKeyGen");
         if (verbose) cout << "CtoS: " << level_budget[0] << ", StoC: " << level_budget[1] << endl;
@@ -741,6 +745,45 @@ private:
         fhelin_ctx_destroy(context);
         context = nullptr;
         fhelin_shim::check(fhelin_ctx_create(&p, &context), "GenCryptoContext");
+        start_level_plan();
+    }
+    /* Level plan (include/fhelin.h fhelin_level_plan_*), opt-in: FHELIN_LEVEL_PLAN=<file>.  A driver process is ONE pass of a
+     * straight-line program (src/main.cpp:145-475): the first run with the variable set records the pass and writes the plan
+     * when the controller goes away; later runs of the same driver find the file and apply it — fresh encryptions and
+     * bootstrap outputs then start with the limbs their consumers read.  Delete the file when the driver changes. */
+    string level_plan_file;
+    bool level_plan_recording = false;
+    void start_level_plan() {
+        const char* f = std::getenv("FHELIN_LEVEL_PLAN");
+        if (!f || !*f) return;
+        level_plan_file = f;
+        ifstream in(level_plan_file);
+        string magic;
+        int n = 0;
+        if (in.is_open() && (in >> magic >> n) && magic == "fhelin-level-plan" && n >= 0) {
+            vector<int32_t> t(n);
+            for (int i = 0; i < n; i++) in >> t[i];
+            if (in) {
+                fhelin_shim::check(fhelin_level_plan_set(context, t.data(), n), "level plan (load)");
+                fhelin_shim::check(fhelin_level_plan_begin(context, 2), "level plan (apply)");
+                cout << "Level plan " << level_plan_file << " applied (" << n << " sources)." << endl;
+                return;
+            }
+        }
+        fhelin_shim::check(fhelin_level_plan_begin(context, 1), "level plan (record)");
+        level_plan_recording = true;
+    }
+    void save_level_plan() {
+        if (!context || !level_plan_recording) return;
+        level_plan_recording = false;
+        int32_t n = 0;
+        if (fhelin_level_plan_end(context, &n) != FHELIN_OK || n <= 0) return;
+        vector<int32_t> t(n);
+        if (fhelin_level_plan_get(context, t.data(), n, &n) != FHELIN_OK) return;
+        ofstream out(level_plan_file);
+        out << "fhelin-level-plan " << n << '\n';
+        for (int i = 0; i < n; i++) out << t[i] << (i + 1 < n ? ' ' : '\n');
+        cout << "Level plan recorded to " << level_plan_file << " (" << n << " sources)." << endl;
     }
     Ctxt wrap(fhelin_ct* h) { return std::make_shared<fhelin_shim::CiphertextImpl>(context, h); }
     vector<Ctxt> wrap_all(const vector<fhelin_ct*>& hs) {

@@ -81,6 +81,25 @@ int fhelin_ctx_set_stream(fhelin_ctx* c, void* hip_stream);                     
  * operation takes) and never if nobody reads them: the reference's drivers compute whole row sets and then use one row
  * (src/main.cpp:183,:196; :416-424).  A forced row holds exactly the residues eager evaluation gives. */
 int fhelin_ctx_set_lazy_rows(fhelin_ctx* c, int32_t on);
+/* Level plan (profile-guided; off unless asked for).  The reference's drivers are straight-line programs (src/main.cpp:145-475):
+ * which ciphertext meets which, and how many limbs every call consumes, does not depend on the data.  A pass run with
+ * fhelin_level_plan_begin(ctx, 1) RECORDS, for every handle this boundary gives out, the handles the producing call read
+ * and the result's limb count; fhelin_level_plan_end then derives, back to front from the terminals (the input of a
+ * bootstrap needs two limbs, as does a decryption / export), the fewest limbs every value may have, and from that the limb
+ * count each SOURCE of the pass - the k-th fhelin_encrypt / fhelin_encrypt_batch vector / fhelin_bootstrap call, in call
+ * order - should start with.  A later pass of the same program run with fhelin_level_plan_begin(ctx, 2) APPLIES the plan:
+ * encryptions are made at the planned level and bootstraps raise to fewer limbs, so that limbs nothing downstream reads
+ * (the reference carries e.g. 20 through the V projection, src/main.cpp:212-215, and 4 from the GELU bootstraps to the
+ * pooler's, :354-420) are not dragged through the key switches in between.  Values are unchanged up to the noise; a pass
+ * that does not follow the recorded program fails loudly at the first bootstrap / decryption that is short of limbs.
+ * get/set move the plan (one int32 per source: limbs to start with, -1 = as asked) so that a driver process can keep it
+ * next to its keys.  fhelin_ct_import / _import_device values are never lowered; exporting is a terminal. */
+int fhelin_level_plan_begin(fhelin_ctx* c, int32_t mode);            /* 0 off, 1 record, 2 apply; resets the source counter */
+int fhelin_level_plan_seek(fhelin_ctx* c, int32_t source);           /* apply: the next source is the source-th of the program
+                                                                        (a server picking up after the client's encryptions) */
+int fhelin_level_plan_end(fhelin_ctx* c, int32_t* n_sources);        /* record: derive the plan; back to mode 0 */
+int fhelin_level_plan_get(fhelin_ctx* c, int32_t* target, int32_t cap, int32_t* n);   /* *n = length; fills min(cap, *n) */
+int fhelin_level_plan_set(fhelin_ctx* c, const int32_t* target, int32_t n);
 int fhelin_sync(fhelin_ctx* c);
 /* HIP-event timer on the context's stream (bench.py measures kernel time with these) */
 int fhelin_timer_start(fhelin_ctx* c);

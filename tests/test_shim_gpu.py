@@ -103,9 +103,11 @@ def _write_model(root, w, x_in, X_E, X_F):
         _write(os.path.join(root, "tokens", f"input_{i - 1}.txt"), x_in[i])
 
 
-def _run(cmd, cwd, timeout=900):
+def _run(cmd, cwd, timeout=900, extra_env=None):
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "fhe-linformer_amd") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     env.pop("FHELIN_SEED", None)            # keys from OS entropy, persisted through ../keys/secret-key.txt
+    env.pop("FHELIN_LEVEL_PLAN", None)
+    env.update(extra_env or {})
     r = subprocess.run(cmd, cwd=cwd, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, (cmd, r.stdout[-3000:], r.stderr[-3000:])
     return r.stdout
@@ -153,3 +155,31 @@ def test_full_forward_through_cpp_shim_and_reference_binary(tmp_path, variant):
         e = np.exp(lg - lg.max())
         assert probs.shape == (20,) and np.max(np.abs(probs - e / e.sum())) < 5e-3
         assert pred == [int(np.argmax(lg))]
+
+
+def test_cpp_driver_records_a_level_plan_and_later_runs_apply_it(tmp_path):
+    """FHELIN_LEVEL_PLAN=<file> (include/FHEController.h start_level_plan / save_level_plan): the first run of the C++ driver
+    records its pass and leaves the plan next to the keys, the second run of the same driver loads and applies it — same
+    logits (up to noise), the V-projection inputs and the GELU bootstraps start on fewer limbs."""
+    from fhe_linformer_amd import linformer as lf
+    from oracle import plain_forward as pf, circuit_sim as cs
+    assert os.path.exists(FWD), "tests/shim/shim_forward missing: run __graft_entry__.build()"
+    w = pf.synthetic_model(1234)
+    x_in, X_E, X_F = pf.client_inputs(w, pf.synthetic_tokens(129, 4321))
+    root = str(tmp_path)
+    _write_model(root, w, x_in, X_E, X_F)
+    build = os.path.join(root, "build")
+    plan_file = os.path.join(root, "keys", "level-plan.txt")
+    out1 = _run([FWD, root, "main", "generate"], build, extra_env={"FHELIN_LEVEL_PLAN": plan_file})
+    assert "Level plan recorded" in out1
+    head, body = open(plan_file).read().split("\n", 1)
+    assert head.split()[0] == "fhelin-level-plan"
+    plan = [int(t) for t in body.split()]
+    assert len(plan) == int(head.split()[1]) and min(t for t in plan if t > 0) < 28
+    lg1 = lf.logits_from_slots(_read(os.path.join(root, "out", "logits.out")))
+    out2 = _run([FWD, root, "main"], build, extra_env={"FHELIN_LEVEL_PLAN": plan_file})
+    assert "applied" in out2 and "Level plan recorded" not in out2
+    lg2 = lf.logits_from_slots(_read(os.path.join(root, "out", "logits.out")))
+    ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, x_in, X_E, X_F, {}, "main"))
+    assert np.max(np.abs(lg1 - ref)) < 2e-2 and np.max(np.abs(lg2 - ref)) < 2e-2
+    assert int(np.argmax(lg2)) == int(np.argmax(ref))
