@@ -100,11 +100,12 @@ PtPtr Composite::mod_n_mask(int n, int padding) {
 }
 CtPtr Composite::mask_mod_n(const CtPtr& c, int n, int padding) { return ev_.mult_plain(c, mod_n_mask(n, padding)); }
 
-PtPtr Composite::mod_range_mask(int period, int from, int to) {
-    const std::string key = mkey("modrange", period, (long)from * 100000 + to, 1.0);
+PtPtr Composite::mod_range_mask(int period, int from, int to, int span_from, int span_to) {
+    if (span_to < 0) span_to = num_slots();
+    const std::string key = mkey("modrange", period, (long)from * 100000 + to, 1.0) + "/" + std::to_string(span_from) + "-" + std::to_string(span_to);
     if (!mask_cache_.count(key)) {
         std::vector<double> m(num_slots(), 0.0);
-        for (int i = 0; i < num_slots(); ++i)
+        for (int i = std::max(span_from, 0); i < span_to && i < num_slots(); ++i)
             if (i % period >= from && i % period < to) m[i] = 1.0;
         mask_plain(key, m);
     }
@@ -324,10 +325,9 @@ CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& we
             }
         }
         std::vector<CtVec> y(4);
-        for (int t = 0; t < 4; ++t) {
-            y[t] = ev_.mult_plain_batch(x, w2[t]);
-            if (early_rescale_) y[t] = ev_.rescale_batch(y[t]);
-        }
+        // the four products stay unrescaled through the key switch that sums them: ONE rescale of U (inside rotsum_batch) instead
+        // of four, at the price of running that one key switch a limb higher
+        for (int t = 0; t < 4; ++t) y[t] = ev_.mult_plain_batch(x, w2[t]);
         std::vector<CtVec> rows(x.size(), CtVec(4));
         for (size_t i = 0; i < x.size(); ++i)
             for (int t = 0; t < 4; ++t) rows[i][t] = y[t][i];
@@ -511,7 +511,8 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
     }
     const int ns = num_slots();
     const bool shared = merge_rot_ && ns == 16384 &&
-                        ev_.have_rotation_keys({128, 256, 384, -128, -256, -384, 512, 1024, 2048, 4096, 8192}, containers.empty() ? 0 : containers[0]->slots);
+                        ev_.have_rotation_keys({128, 256, 384, -128, -256, -384, 512, 1024, 1536, 2048, 2560, 3072, 3584, 4096, 8192, 12288},
+                                               containers.empty() ? 0 : containers[0]->slots);
     if (!shared) {
         // unwrap_512_in_4_128 (:1142-1162) for every (container, token): mask the four 128-slot blocks, then one batched
         // repeat(128, -128) over all of them
@@ -531,35 +532,62 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
         for (size_t i = 0; i + 3 < rep.size(); i += 4) out.push_back(CtVec(rep.begin() + i, rep.begin() + i + 4));
         return out;
     }
-    // The same slot values with the first two of the seven doubling steps SHARED by the 32 tokens of a container: the
-    // reference masks block k of token j and replicates it 128 times (7 steps per (token, block)).  Here
-    //   B_k = block k of EVERY token copied over that token's own 512 slots: one mask (slot mod 512 in [128k, 128k+128)) and
-    //         one merged key switch with the three rotations 128 (k - m), m != k, per (container, k);
-    //   out_{j,k} = (B_k masked to token j's 512 slots) replicated over the 32 token positions: 5 doubling steps by 512
-    //         (repeat(., 32, -512) in the reference's sign convention: left shifts, cyclic).
-    // One key switch fewer per output (2 instead of 3) at the price of one more plaintext mask level.
-    std::vector<CtVec> Bk(4);
+    // The same slot values with four of the seven doubling steps SHARED between tokens.  The reference masks block k of
+    // token j and replicates it 128 times: 7 steps per (token, block).  Here, per container, block k and range a (the 8 tokens
+    // 8a..8a+7 = slots [4096a, 4096a+4096)):
+    //   A   = container * (slot mod 512 in [128k, 128k+128) and slot in range a)                        one mask level
+    //   B   = A + its rotations by 128(k - m), m != k: block k of each of the 8 tokens copied over that token's own 512 slots
+    //         (ONE merged key switch of three rotations)
+    //   D   = B replicated over the four ranges (rotations by 4096, 8192, 12288: one merged key switch): 4096-periodic
+    //   out_{8a+b, k} = (D * (slot mod 4096 in [512b, 512b+512))) replicated by 512, 1024, ..., 3584      one mask level, ONE
+    //         merged key switch of seven rotations per output (the 32 shifts 512 i = the 4 x 8 shifts 4096 a' + 512 i')
+    // One key switch per output instead of three, 5 shared ones per (container, k, a); the same two mask levels as the
+    // one-stage shared form this replaces (which needed two key switches per output).
+    std::vector<CtVec> out;
+    // the (container, range) pairs that hold a wanted token
+    std::vector<std::pair<int, int>> groups;
+    for (size_t i = 0; i < containers.size() && i < quantities.size(); ++i)
+        for (int a = 0; a < 4; ++a) {
+            bool wanted = false;
+            for (int j = 8 * a; j < 8 * a + 8 && j < quantities[i]; ++j) {
+                const int token = (int)i * 32 + j;
+                wanted = wanted || (token >= first && token < first + count);
+            }
+            if (wanted) groups.push_back({(int)i, a});
+        }
+    // stage 1, batched over the groups: per block k one masked product, one rescale, one merged key switch; then ONE
+    // replication over the four ranges for all of them
+    CtVec Ball;
     for (int k = 0; k < 4; ++k) {
-        CtVec a = ev_.mult_plain_batch(containers, mod_range_mask(512, 128 * k, 128 * (k + 1)));
-        a = ev_.rescale_batch(a);
+        CtVec from;
+        std::vector<PtPtr> mk;
+        for (const auto& g : groups) {
+            from.push_back(containers[g.first]);
+            mk.push_back(mod_range_mask(512, 128 * k, 128 * (k + 1), 4096 * g.second, 4096 * (g.second + 1)));
+        }
+        CtVec A = ev_.rescale_batch(ev_.mult_plain_each(from, mk));
         std::vector<int> idx;
         for (int m = 0; m < 4; ++m)
             if (m != k) idx.push_back(128 * (k - m));
-        Bk[k] = ev_.rotate_sum_batch(a, idx);
+        CtVec B = ev_.rotate_sum_batch(A, idx);
+        Ball.insert(Ball.end(), B.begin(), B.end());
     }
+    const CtVec Dall = repeat_batch(Ball, 4, -4096);   // [k][group]
+    // stage 2: per wanted token and block, the token's 512 slots of D replicated over the 8 positions of a range
     CtVec src;
     std::vector<PtPtr> masks;
-    for (size_t i = 0; i < containers.size() && i < quantities.size(); ++i)
-        for (int j = 0; j < quantities[i]; ++j) {
-            const int token = (int)i * 32 + j;
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+        const int i = groups[gi].first, a = groups[gi].second;
+        for (int j = 8 * a; j < 8 * a + 8 && j < quantities[i]; ++j) {
+            const int token = i * 32 + j;
             if (token < first || token >= first + count) continue;
             for (int k = 0; k < 4; ++k) {
-                src.push_back(Bk[k][i]);
-                masks.push_back(block_mask(j * 512, (j + 1) * 512, 1));
+                src.push_back(Dall[(size_t)k * groups.size() + gi]);
+                masks.push_back(mod_range_mask(4096, 512 * (j - 8 * a), 512 * (j - 8 * a + 1)));
             }
         }
-    CtVec rep = repeat_batch(ev_.mult_plain_each(src, masks), 32, -512);
-    std::vector<CtVec> out;
+    }
+    CtVec rep = repeat_batch(ev_.mult_plain_each(src, masks), 8, -512);
     for (size_t i = 0; i + 3 < rep.size(); i += 4) out.push_back(CtVec(rep.begin() + i, rep.begin() + i + 4));
     return out;
 }

@@ -32,7 +32,7 @@ public:
     PtPtr first_n_mask(int n, double v);   // the cached mask plaintexts themselves (batched callers)
     PtPtr block_mask(int from, int to, double v);
     PtPtr mod_n_mask(int n, int padding);
-    PtPtr mod_range_mask(int period, int from, int to);   // 1 where from <= (slot mod period) < to
+    PtPtr mod_range_mask(int period, int from, int to, int span_from = 0, int span_to = -1);   // slot mod period in [from, to), slot in [span_from, span_to)
 
     // log-tree reductions                                                                     :829-867
     CtPtr rotsum(const CtPtr& in, int slots, int padding);

@@ -251,11 +251,12 @@ class ResidueEvaluator:
     def matmulRElarge(self, rows, w2_encs, bias_enc, mask512_enc):
         """composite.cpp matmulRElarge, shared form: U = sum_{t<4} rot(x * W''_t, 128 t) (one shared-ModDown key switch of three
         rotated terms + the unrotated one), Z = rotsum(U, 32, 512), out = Z * mask[0,512) + bias.  w2_encs[t] encodes W''_t
-        (block b of W''_t = block b of W_((b - t) mod 4)); a degree-2 input is rescaled once, each product before its key switch"""
+        (block b of W''_t = block b of W_((b - t) mod 4)); a degree-2 input is rescaled once, the four products go through the
+        key switch unrescaled and U is rescaled once (by rotsum)"""
         out = []
         for r in rows:
             x = self.rescale(r) if r.deg >= 2 else r
-            y = [self.rescale(self.mult_plain(x, w2_encs[t])) for t in range(4)]
+            y = [self.mult_plain(x, w2_encs[t]) for t in range(4)]
             u = self.rotate_each_sum(y, [0, 128, 256, 384])
             z = self.rotsum(u, 32, 512)
             o = self.mult_plain(z, mask512_enc)
@@ -263,24 +264,30 @@ class ResidueEvaluator:
         return out
 
     def unwrapRepeatedLarge(self, containers, n_tokens, enc_of_values):
-        """composite.cpp unwrapRepeatedLarge (shared form): per container and block k one mask (slot mod 512 in block k) and one
-        merged key switch copy block k of every token over the token's own 512 slots; per (token, k) a token mask and
-        repeat(., 32, -512).  enc_of_values(vector) -> enc callback for that plaintext vector."""
+        """composite.cpp unwrapRepeatedLarge (two-stage shared form): per container, block k and range a (8 tokens = 4096
+        slots) one mask (slot mod 512 in block k, slot in range a), one merged key switch copying block k of every token of
+        the range over the token's own 512 slots, and repeat(., 4, -4096); per (token, k) a mask (slot mod 4096 in the
+        token's 512 slots of its range) and repeat(., 8, -512).  enc_of_values(vector) -> enc callback for that vector."""
         ns = self.slots
         idx = np.arange(ns)
-        Bk = []
-        for k in range(4):
-            m = ((idx % 512 >= 128 * k) & (idx % 512 < 128 * (k + 1))).astype(np.float64)
-            rows = []
-            for c in containers:
-                a = self.rescale(self.mult_plain(c, enc_of_values(m)))
-                rows.append(self.rotate_sum(a, [128 * (k - mm) for mm in range(4) if mm != k]))
-            Bk.append(rows)
+        D = {}
+        for t in range(n_tokens):
+            i, j = divmod(t, 32)
+            D.setdefault((i, j // 8), None)
+        for (i, a) in D:
+            row = []
+            for k in range(4):
+                m = ((idx % 512 >= 128 * k) & (idx % 512 < 128 * (k + 1)) & (idx >= 4096 * a) & (idx < 4096 * (a + 1))).astype(np.float64)
+                A = self.rescale(self.mult_plain(containers[i], enc_of_values(m)))
+                B = self.rotate_sum(A, [128 * (k - mm) for mm in range(4) if mm != k])
+                row.append(self.repeat(B, 4, -4096))
+            D[(i, a)] = row
         out = []
         for t in range(n_tokens):
             i, j = divmod(t, 32)
-            tm = ((idx >= 512 * j) & (idx < 512 * (j + 1))).astype(np.float64)
-            out.append([self.repeat(self.mult_plain(Bk[k][i], enc_of_values(tm)), 32, -512) for k in range(4)])
+            a, b = divmod(j, 8)
+            tm = ((idx % 4096 >= 512 * b) & (idx % 4096 < 512 * (b + 1))).astype(np.float64)
+            out.append([self.repeat(self.mult_plain(D[(i, a)][k], enc_of_values(tm)), 8, -512) for k in range(4)])
         return out
 
     def wrap_containers(self, cts, n):

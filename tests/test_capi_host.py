@@ -117,3 +117,22 @@ def test_default_seed_is_os_entropy_and_test_seed_is_deterministic(fa):
     assert e.secret_seed() == sa
     for x in (a, b, c, d, e):
         x.close()
+
+
+def test_level_plan_bookkeeping_on_a_host_context(fa):
+    """fhelin_level_plan_* (include/fhelin.h): the plan is plain data on the context — it can be set, read back and a pass
+    can be opened on it without a device; applying with nothing loaded, bad modes and seeking inside a recording are refused"""
+    e = fa.Engine("toy", device=-1)
+    assert e.level_plan() == []
+    with pytest.raises(fa.FhelinError) as ei:
+        e.level_plan_begin("apply")
+    assert ei.value.code == 4
+    assert e.lib.fhelin_level_plan_begin(e.h, 3) == 1
+    e.set_level_plan([4, -1, 9, 2])
+    assert e.level_plan() == [4, -1, 9, 2]
+    e.level_plan_begin("apply", first_source=2)
+    assert e.level_plan_end() == [4, -1, 9, 2]               # ending an applying pass keeps the plan
+    e.level_plan_begin("record")
+    assert e.lib.fhelin_level_plan_seek(e.h, 1) == 4         # a recording runs from its first source
+    assert e.level_plan_end() == []                          # nothing was recorded: an empty plan replaces the old one
+    e.close()

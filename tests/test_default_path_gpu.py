@@ -427,8 +427,9 @@ def test_wrapUpRepeated_inner_product_bit_exact(engine_factory, orc, preset, ell
 
 
 def test_unwrapRepeatedLarge_shared_steps_bit_exact(fa, orc):
-    """unwrapRepeatedLarge (:1102-1123) in its shared form (block k of all 32 tokens of a container spread over each token's
-    512 slots by one merged key switch, then per token a mask and repeat(., 32, -512)) == the same composition on the oracle"""
+    """unwrapRepeatedLarge (:1102-1123) in its two-stage shared form (per range of 8 tokens: block k spread over each token's
+    512 slots by one merged key switch and replicated over the four ranges; per token a mask and repeat(., 8, -512)) == the
+    same composition on the oracle; 10 tokens = two ranges, the second one ragged"""
     eng = fa.Engine("reference", seed=3, n_q=6, n_p=2, dnum=3)
     try:
         need = [128, 256, 384, -128, -256, -384] + [512 * m for m in range(1, 8)] + [4096, 8192, 12288]
@@ -444,15 +445,15 @@ def test_unwrapRepeatedLarge_shared_steps_bit_exact(fa, orc):
             return lambda ell, sc: eng.pt_export(p, ell, sc)
 
         c, r = _imp(eng, rev, _ct(orc, eng, 61, 6))
-        got = eng.unwrapRepeatedLarge([c], 3)                     # one container holding 3 tokens
-        want = rev.unwrapRepeatedLarge([r], 3, enc_of_values)
-        assert len(got) == 3
-        for t in range(3):
+        got = eng.unwrapRepeatedLarge([c], 10)                    # one container holding 10 tokens
+        want = rev.unwrapRepeatedLarge([r], 10, enc_of_values)
+        assert len(got) == 10
+        for t in range(10):
             for k in range(4):
                 _same(got[t][k], want[t][k], ("unwrapRepeatedLarge", t, k))
-        part = eng.unwrapRepeatedLarge_range([c], 3, 1, 2)       # the token range form used by row sharding
-        for t in (1, 2):
+        part = eng.unwrapRepeatedLarge_range([c], 10, 7, 3)      # the token range form used by row sharding (spans both ranges)
+        for t in (7, 8, 9):
             for k in range(4):
-                _same(part[t - 1][k], want[t][k], ("range", t, k))
+                _same(part[t - 7][k], want[t][k], ("range", t, k))
     finally:
         eng.close()

@@ -40,12 +40,18 @@ for name in dir(ctl):
     fn = getattr(ctl, name)
     if callable(fn):
         setattr(ctl, name, wrap(name, fn))
-for _ in range(2):
+plan = os.environ.get("LEVEL_PLAN", "1") != "0"
+for it in range(3):
     agg.clear()
+    if plan:
+        e.level_plan_begin("record" if it == 0 else "apply")
     enc = lf.encrypt_inputs(ctl, x_in, X_E, X_F)
     e.sync(); t0 = time.time()
     out = lf.forward_encrypted(ctl, w, enc)
+    e.decrypt(out)
     e.sync(); total = (time.time() - t0) * 1e3
+    if plan:
+        e.level_plan_end()
 print(f"forward (synchronised per call) {total:.0f} ms")
 print(f"{'method':28s} {'calls':>6s} {'keyswitch':>10s} {'limb-NTT':>10s} {'ms':>8s} {'us/KS':>8s}")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][3]):
