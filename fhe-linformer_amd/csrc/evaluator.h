@@ -85,6 +85,7 @@ public:
     // base pointer of `v` if its members are consecutive views of one block (else nullptr)
     static u64* contiguous_base(const std::vector<CtPtr>& v);
     std::vector<CtPtr> make_contiguous(const std::vector<CtPtr>& v);
+    bool cheb_rounds = true;   // Paterson-Stockmeyer products in rounds (polyeval.cpp cheb_recurse); FHELIN_CHEB_ROUNDS=0: one at a time
     int batch_limit = 16;   // rows processed per batched key switch (FHELIN_BATCH overrides; 8 / 16 / 24 / 32 measured: DESIGN.md)
     CtPtr clone(const CtPtr& a);
     KeyPtr new_key();

@@ -141,30 +141,29 @@ CtPtr Evaluator::eval_poly(const CtPtr& x, const std::vector<double>& coeffs) {
 
 // Chebyshev evaluation over a ROW of ciphertexts (one value per input): every op below acts on all inputs at once, the
 // products through mult_batch (one batched relinearisation).
-Evaluator::CtRow Evaluator::cheb_recurse(const std::vector<double>& c, const std::vector<CtRow>& T, const std::map<int, CtRow>& G,
-                                         int baby) {
+//
+// The Paterson-Stockmeyer recursion p = q * T_m + r is a tree whose products are independent of one another except along
+// a q-chain: the tree is built first and then evaluated in ROUNDS - all products whose q operand is ready go through ONE
+// mult_batch (degree 47: 2 rounds instead of 5 dependent relinearisations, degree 119: 3 instead of 7, degree 300: 5 instead
+// of 18), then the sums that have become ready.  Each node computes exactly what the recursive form computed
+// (mult(q, T_m), then add(., r)), so the residues do not depend on the order.
+namespace {
+struct ChebNode {
+    std::vector<double> c;
+    int m = 0;           // 0: a leaf (degree < baby), evaluated as one linear combination of the baby powers
+    int q = -1, r = -1;
+    std::vector<CtPtr> val, prod;
+    bool has_prod = false, done = false;
+};
+int cheb_build(std::vector<ChebNode>& nodes, const std::vector<double>& c_in, int baby) {
+    std::vector<double> c = c_in;
     int n = (int)c.size() - 1;
     while (n > 0 && c[n] == 0.0) --n;
-    const size_t rows = T[1].size();
-    if (n < baby) {
-        bool any = false;
-        for (int k = 1; k <= n; ++k) any = any || c[k] != 0.0;
-        CtRow acc(rows);
-        if (!any) {  // constant polynomial: c0 as an encryption-free shift of 0 * T_1
-            for (size_t i = 0; i < rows; ++i) {
-                acc[i] = mult_real(T[1][i], 0.0);
-                if (c[0] != 0.0) acc[i] = add_real(acc[i], c[0]);
-            }
-            return acc;
-        }
-        // sum_k c_k T_k + c_0 in one pass per input (the babies share one level: align_deg1)
-        for (size_t i = 0; i < rows; ++i) {
-            std::vector<CtPtr> terms;
-            for (int k = 1; k <= n; ++k) terms.push_back(T[k][i]);
-            acc[i] = lincomb(terms, std::vector<double>(c.begin() + 1, c.begin() + n + 1), c[0]);
-        }
-        return acc;
-    }
+    c.resize(n + 1);
+    const int id = (int)nodes.size();
+    nodes.emplace_back();
+    nodes[id].c = c;
+    if (n < baby) return id;
     int m = baby;
     while (m * 2 <= n) m *= 2;
     std::vector<double> q(n - m + 1, 0.0), r(m, 0.0);
@@ -174,12 +173,81 @@ Evaluator::CtRow Evaluator::cheb_recurse(const std::vector<double>& c, const std
         q[i - m] = 2 * c[i];
         r[2 * m - i] -= c[i];
     }
-    CtRow qv = cheb_recurse(q, T, G, baby);
-    CtRow res = mult_batch(qv, G.at(m));
+    nodes[id].m = m;
+    const int qi = cheb_build(nodes, q, baby);
+    nodes[id].q = qi;
     bool r_zero = true;
     for (double v : r) r_zero = r_zero && v == 0.0;
-    if (r_zero) return res;
-    return add_batch(res, cheb_recurse(r, T, G, baby));
+    if (!r_zero) {
+        const int ri = cheb_build(nodes, r, baby);
+        nodes[id].r = ri;
+    }
+    return id;
+}
+}  // namespace
+
+Evaluator::CtRow Evaluator::cheb_recurse(const std::vector<double>& c, const std::vector<CtRow>& T, const std::map<int, CtRow>& G,
+                                         int baby) {
+    const size_t rows = T[1].size();
+    std::vector<ChebNode> nodes;
+    const int root = cheb_build(nodes, c, baby);
+    // leaves: sum_k c_k T_k + c_0 in one pass per input (the babies share one level: align_deg1)
+    for (ChebNode& nd : nodes) {
+        if (nd.m) continue;
+        const int n = (int)nd.c.size() - 1;
+        bool any = false;
+        for (int k = 1; k <= n; ++k) any = any || nd.c[k] != 0.0;
+        nd.val.resize(rows);
+        for (size_t i = 0; i < rows; ++i) {
+            if (!any) {  // constant polynomial: c0 as an encryption-free shift of 0 * T_1
+                nd.val[i] = mult_real(T[1][i], 0.0);
+                if (nd.c[0] != 0.0) nd.val[i] = add_real(nd.val[i], nd.c[0]);
+                continue;
+            }
+            std::vector<CtPtr> terms;
+            for (int k = 1; k <= n; ++k) terms.push_back(T[k][i]);
+            nd.val[i] = lincomb(terms, std::vector<double>(nd.c.begin() + 1, nd.c.begin() + n + 1), nd.c[0]);
+        }
+        nd.done = true;
+    }
+    while (!nodes[root].done) {
+        // one batched product for every node whose q operand is ready
+        std::vector<int> ready;
+        CtRow lhs, rhs;
+        for (int id = 0; id < (int)nodes.size(); ++id) {
+            ChebNode& nd = nodes[id];
+            if (!nd.m || nd.has_prod || !nodes[nd.q].done) continue;
+            if (!cheb_rounds && !ready.empty()) break;   // the dependent, one-product-at-a-time order (A/B and parity test)
+            ready.push_back(id);
+            const CtRow& g = G.at(nd.m);
+            for (size_t i = 0; i < rows; ++i) {
+                lhs.push_back(nodes[nd.q].val[i]);
+                rhs.push_back(g[i]);
+            }
+        }
+        if (ready.empty()) throw Error(FHELIN_ERR_INTERNAL, "chebyshev evaluation: no product is ready");
+        CtRow prod = mult_batch(lhs, rhs);
+        for (size_t k = 0; k < ready.size(); ++k) {
+            ChebNode& nd = nodes[ready[k]];
+            nd.prod.assign(prod.begin() + k * rows, prod.begin() + (k + 1) * rows);
+            nd.has_prod = true;
+            nodes[nd.q].val.clear();
+        }
+        // the sums that are ready now (a finished sum can complete its parent's: repeat until nothing moves)
+        for (bool moved = true; moved;) {
+            moved = false;
+            for (ChebNode& nd : nodes) {
+                if (nd.done || !nd.has_prod) continue;
+                if (nd.r >= 0 && !nodes[nd.r].done) continue;
+                nd.val = nd.r >= 0 ? add_batch(nd.prod, nodes[nd.r].val) : nd.prod;
+                if (nd.r >= 0) nodes[nd.r].val.clear();
+                nd.prod.clear();
+                nd.done = true;
+                moved = true;
+            }
+        }
+    }
+    return nodes[root].val;
 }
 
 CtPtr Evaluator::eval_chebyshev(const CtPtr& x, const std::vector<double>& coeffs_in, double a, double b) {

@@ -84,3 +84,31 @@ def test_chebyshev_functions_of_the_reference(eng):
     y = _x(eng, 5, 1.0, 16.0)
     got = eng.decrypt(eng.eval_chebyshev(eng.encrypt(y), ci, 1.0, 16.0))
     assert np.max(np.abs(got - 1.0 / y)) < 1e-4
+
+
+@pytest.mark.parametrize("degree", [47, 119, 300])
+def test_paterson_stockmeyer_rounds_give_the_residues_of_the_dependent_order(fa, monkeypatch, degree):
+    """polyeval.cpp cheb_recurse evaluates the products of the recursion p = q T_m + r in rounds (all products whose q operand
+    is ready in ONE batched relinearisation).  Every node still computes mult(q, T_m) then add(., r): the exported residues
+    must equal those of the one-product-at-a-time order (FHELIN_CHEB_ROUNDS=0) bit for bit — degrees of the bootstrap's
+    cosine fit (47), GELU / 1/x (119) and tanh (300)."""
+    rng = np.random.default_rng(degree)
+    c = rng.uniform(-1, 1, degree + 1) / np.arange(1, degree + 2)
+    outs = []
+    for rounds in ("1", "0"):
+        monkeypatch.setenv("FHELIN_CHEB_ROUNDS", rounds)
+        e = fa.Engine("toy13", seed=5, n_q=14, n_p=4, dnum=4)
+        try:
+            e.keygen()
+            e.gen_relin_key()
+            x = np.random.default_rng(3).uniform(-1, 1, 1 << e.params.log_slots)
+            ct = e.encrypt(x)
+            e.stats(reset=True)
+            out = e.eval_chebyshev(ct, c)
+            outs.append((out.export(), out.info(), e.stats()["keyswitch"]))
+            if rounds == "1":
+                assert np.max(np.abs(e.decrypt(out) - cheb_eval(c, x, -1, 1))) < 1e-4
+        finally:
+            e.close()
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    assert np.array_equal(outs[0][0], outs[1][0])

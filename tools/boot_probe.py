@@ -22,3 +22,12 @@ for it in range(int(os.environ.get("BOOT_REPS", "3"))):
     e.sync(); dt = time.time() - t0
     err = np.max(np.abs(e.decrypt(out) - m))
     print(f"bootstrap {it}: {dt*1e3:.1f} ms, out {out.info()}, max err {err:.3e}")
+# time per phase (each partial run repeats the earlier phases): ModRaise+SubSum | + CoeffsToSlots | + EvalMod (real half only)
+if os.environ.get("BOOT_PHASES"):
+    for stage in (1, 2, 3):
+        ts = []
+        for it in range(4):
+            e.sync(); t0 = time.time()
+            e.bootstrap_partial(ct, stage)
+            e.sync(); ts.append((time.time() - t0) * 1e3)
+        print(f"partial stage {stage}: {min(ts):.2f} ms")
