@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
 #include <set>
 
@@ -71,6 +72,44 @@ DiagMap compose(const DiagMap& B, const DiagMap& A, int n) {
     return C;
 }
 
+// Sparse packing (2 slots <= N/2): a ciphertext with n slots has room for 2n.  The LAST CoeffsToSlots stage written over 2n
+// slots with the diagonals [d_r | -i d_r] leaves w on the left half and -i w on the right one, so that after adding the
+// conjugate the left half holds the real parts (t_k) and the right half the imaginary parts (t_{k+n}): ONE ciphertext goes
+// through the modular reduction instead of two.
+DiagMap pack_last_c2s(const DiagMap& m, int n) {
+    DiagMap out;
+    for (const auto& e : m) {
+        std::vector<cplx> d(2 * n);
+        for (int j = 0; j < n; ++j) {
+            d[j] = e.second[j];
+            d[j + n] = cplx(0, -1) * e.second[j];
+        }
+        out[e.first] = d;
+    }
+    return out;
+}
+// ... and the FIRST SlotsToCoeffs stage takes u = [L | R] (2n real slots) in place of the n-slot vector z = L + i R it is
+// defined on: out_j = sum_r e_r[j mod n] z_{(j + r) mod n} for all 2n positions j (the result has period n again), with
+// z_q = u_q + i u_{q+n}: every diagonal r becomes two, at offsets r and r + n of the 2n-slot rotation group.
+DiagMap unpack_first_s2c(const DiagMap& m, int n) {
+    DiagMap out;
+    for (const auto& e : m) {
+        const int r = ((e.first % n) + n) % n;
+        std::vector<cplx> a(2 * n), b(2 * n);
+        for (int j = 0; j < 2 * n; ++j) {
+            const int jj = j % n;
+            const bool wraps = jj + r >= n;             // (jj + r) mod n came around: the halves of u trade places
+            const bool left = (j < n) != wraps;         // rot_r(u)_j is the L entry (else rot_{r+n}(u)_j is)
+            const cplx v = e.second[jj];
+            a[j] = left ? v : cplx(0, 1) * v;           // coefficient of rot_r(u)_j
+            b[j] = left ? cplx(0, 1) * v : v;           // coefficient of rot_{r+n}(u)_j
+        }
+        out[r] = a;
+        out[r + n] = b;
+    }
+    return out;
+}
+
 void scale_map(DiagMap& m, double f) {
     for (auto& e : m)
         for (auto& v : e.second) v *= f;
@@ -84,8 +123,7 @@ Bootstrapper::~Bootstrapper() {
     }
 }
 
-LinStage Bootstrapper::prepare(const DiagMap& m) {
-    const int n = slots_;
+LinStage Bootstrapper::prepare(const DiagMap& m, int n) {
     LinStage st;
     int g = n;
     for (const auto& e : m)
@@ -134,6 +172,8 @@ void Bootstrapper::setup(int budget_enc, int budget_dec, int slots) {
     ckks_fft_tables(n, rot, ksi);
 
     const int gapN = (c.N / 2) / n;
+    packed_ = gapN >= 2;
+    if (const char* e = std::getenv("FHELIN_BOOT_PACKED")) packed_ = packed_ && std::atoi(e) != 0;
     const double q0 = (double)c.chain.q[0];
     // CoeffsToSlots: inverse-FFT stages (len = n .. 2), total constant Delta_r / (gapN q0 K 2n) spread over the levels
     auto build = [&](bool inverse, int budget, double total_factor, std::vector<LinStage>& out) {
@@ -148,7 +188,9 @@ void Bootstrapper::setup(int budget_enc, int budget_dec, int slots) {
             for (int i = 1; i < cnt; ++i) m = compose(stage_map(n, lens[pos + i], inverse, rot, ksi), m, n);
             pos += cnt;
             scale_map(m, f);
-            out.push_back(prepare(m));
+            if (packed_ && inverse && g == budget - 1) out.push_back(prepare(pack_last_c2s(m, n), 2 * n));
+            else if (packed_ && !inverse && g == 0) out.push_back(prepare(unpack_first_s2c(m, n), 2 * n));
+            else out.push_back(prepare(m, n));
         }
     };
     c2s_.clear();
@@ -288,14 +330,24 @@ CtPtr Bootstrapper::run(const CtPtr& ct, int stop_after, int drop) {
     CtPtr w = mod_raise(ct, rho, c.L + 1 - drop);
     if (stop_after == 1) return w;
     for (const auto& st : c2s_) w = apply(st, w);
+    if (packed_) w->slots = 2 * slots_;          // the last stage wrote [w | -i w] over 2n slots
     CtPtr wc = ev_.conjugate(w);
-    CtPtr a = ev_.add(w, wc);                    // real parts  t_k       / (q0 K)   (1/2 folded into the DFT constants)
+    CtPtr a = ev_.add(w, wc);                    // real parts  t_k / (q0 K)  (1/2 folded into the DFT constants); packed: [t_k | t_{k+n}]
     if (stop_after == 2) return a;
-    CtPtr b = mult_i(ev_.sub(wc, w));            // imaginary   t_{k+n}   / (q0 K)
-    if (stop_after == 3) return eval_mod({a})[0];
-    std::vector<CtPtr> ab = eval_mod({a, b});
-    CtPtr v = ev_.add(ab[0], mult_i(ab[1]));
-    for (const auto& st : s2c_) v = apply(st, v);
+    CtPtr v;
+    if (packed_) {
+        v = eval_mod({a})[0];                    // one modular reduction for both halves
+        if (stop_after == 3) return v;
+    } else {
+        CtPtr b = mult_i(ev_.sub(wc, w));        // imaginary   t_{k+n}   / (q0 K)
+        if (stop_after == 3) return eval_mod({a})[0];
+        std::vector<CtPtr> ab = eval_mod({a, b});
+        v = ev_.add(ab[0], mult_i(ab[1]));
+    }
+    for (size_t i = 0; i < s2c_.size(); ++i) {
+        v = apply(s2c_[i], v);
+        if (packed_ && i == 0) v->slots = slots_;   // the first stage reads [L | R] over 2n slots and leaves an n-periodic vector
+    }
     // slots now hold m * rho / 2^correction: undo the correction exactly and absorb rho in the scale
     v = ev_.mult_int(v, 1ull << correction, false, v->scale);
     v->scale = v->scale * rho;

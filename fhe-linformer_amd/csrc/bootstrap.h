@@ -50,12 +50,13 @@ private:
     Evaluator& ev_;
     Client& cl_;
     int slots_ = 0;
+    bool packed_ = false;   // sparse packing: real and imaginary halves share one ciphertext through EvalMod (bootstrap.cpp)
     int depth_ = 0;
     std::vector<LinStage> c2s_, s2c_;
     std::vector<double> cheb_;
     u64* mono_i_ = nullptr;  // NTT of X^{N/2} over the Q limbs: multiplication by i
 
-    LinStage prepare(const DiagMap& m);
+    LinStage prepare(const DiagMap& m, int n);   // n: slots the stage's diagonals are written over
     CtPtr apply(const LinStage& st, const CtPtr& x);
     CtPtr mult_i(const CtPtr& x);
     CtPtr mod_raise(const CtPtr& ct, long double& rho, int top_ell);

@@ -36,9 +36,13 @@ def test_bootstrap_refreshes_levels_and_keeps_message(fa, log_slots):
         # stage 2: slots hold t_k / (q0 K) (bit-reversed order) with t = Delta' mu + q0 I
         a = eng.decrypt(eng.bootstrap_partial(ct, 2))
         frac = a * 28 - np.round(a * 28)
-        mu = _coeffs(m).real
-        got = np.sort(frac * 2 ** 10)
-        assert np.max(np.abs(got - np.sort(mu))) < 1e-3
+        w = _coeffs(m)
+        if len(a) == 2 * n:                                   # sparse packing: [t_k | t_{k+n}] share one ciphertext (2n slots)
+            assert np.max(np.abs(np.sort(frac[:n] * 2 ** 10) - np.sort(w.real))) < 1e-3
+            assert np.max(np.abs(np.sort(frac[n:] * 2 ** 10) - np.sort(w.imag))) < 1e-3
+        else:
+            assert len(a) == n
+            assert np.max(np.abs(np.sort(frac * 2 ** 10) - np.sort(w.real))) < 1e-3
         out = eng.bootstrap(ct)
         info = out.info()
         assert info["ell"] >= 4, info                         # strictly more limbs than before
@@ -94,3 +98,23 @@ def test_async_heavy_ops_match_the_synchronous_path(fa, monkeypatch):
     u = [np.polynomial.chebyshev.chebval(m, [cheb[0] / 2] + cheb[1:]) for m in ms]
     for d, w in zip(dec, u):
         assert np.max(np.abs(d - w)) < 5e-4
+
+
+def test_packed_and_two_ciphertext_modular_reduction_agree(fa, monkeypatch):
+    """sparse packing: the real and imaginary coefficient halves go through EvalMod in ONE ciphertext (last CoeffsToSlots stage
+    written over 2n slots as [d | -i d], first SlotsToCoeffs stage reading [L | R]); FHELIN_BOOT_PACKED=0 keeps the two-ciphertext
+    form.  Same message out of both, same level, and fewer key switches in the packed form's EvalMod."""
+    res = {}
+    for packed in ("1", "0"):
+        monkeypatch.setenv("FHELIN_BOOT_PACKED", packed)
+        eng = _engine(fa, 10)
+        try:
+            m = np.random.default_rng(3).uniform(-1, 1, 1 << 10)
+            ct = eng.encrypt(m, level=eng.n_q - 3)
+            out = eng.bootstrap(ct)
+            res[packed] = (eng.decrypt(out), out.info()["ell"], out.info()["slots"])
+        finally:
+            eng.close()
+    for packed in ("1", "0"):
+        assert np.max(np.abs(res[packed][0] - m)) < 2e-4, packed
+    assert res["1"][1:] == res["0"][1:]
