@@ -288,12 +288,25 @@ std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>
 }
 
 std::shared_ptr<Encoding> Plaintext::at(int ell, long double scale) {
-    for (auto& e : cache)
-        if (e->ell == ell && fabsl(e->scale / scale - 1.0L) < 1e-12L) return e;
+    for (size_t i = 0; i < cache.size(); ++i)
+        if (cache[i]->ell == ell && fabsl(cache[i]->scale / scale - 1.0L) < 1e-12L) {
+            if (i) std::rotate(cache.begin(), cache.begin() + i, cache.begin() + i + 1);   // most recently used first
+            return cache[0];
+        }
     auto e = encode_to_device(*ctx, values, imag, slots, ell, scale);
     // an encoding made on a worker lane is cached and may be read from any other stream next: finish it first
     if (ctx->stream != ctx->main_stream) hip_check(hipStreamSynchronize(ctx->stream), "encode sync (lane)");
-    cache.push_back(e);
+    cache.insert(cache.begin(), e);
+    // one entry per (limb count, scale) the plaintext has been used at: bounded by the chain length in principle, capped here
+    // so that a long-lived mask or bootstrap diagonal cannot pin more than MAX_ENCODINGS device copies (least recently used
+    // goes; callers hold their own reference while they enqueue work on it)
+    if (cache.size() > MAX_ENCODINGS) {
+        // the evicted copy may still be read by work in flight on any stream: its block must not go back to a pool before that
+        // work is done (rare: more than MAX_ENCODINGS distinct levels for one plaintext)
+        hip_check(hipStreamSynchronize(ctx->main_stream), "encoding eviction sync");
+        for (int k = 1; k <= ctx->n_lanes; ++k) hip_check(hipStreamSynchronize(ctx->lane_stream[k]), "encoding eviction sync (lane)");
+        cache.pop_back();
+    }
     return e;
 }
 

@@ -56,7 +56,8 @@ struct Plaintext {
     std::vector<double> imag;    // optional imaginary parts (bootstrapping's DFT diagonals); empty = real vector
     int slots = 0;
     int level = 0;               // level requested at encode time (reference encode(vec, level, slots))
-    std::vector<std::shared_ptr<Encoding>> cache;
+    static constexpr size_t MAX_ENCODINGS = 16;
+    std::vector<std::shared_ptr<Encoding>> cache;   // most recently used first (Plaintext::at)
     std::shared_ptr<Encoding> at(int ell, long double scale);
 };
 typedef std::shared_ptr<Plaintext> PtPtr;
