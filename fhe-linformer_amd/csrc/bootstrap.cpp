@@ -267,8 +267,19 @@ CtPtr Bootstrapper::apply(const LinStage& st, const CtPtr& xin) {
     const int lvl = x->level();
     if (x->ell >= 2 && fabsl(x->scale / c.sf_real[lvl] - 1.0L) > 1e-12L)
         pt_scale = c.sf_real[lvl + 1] * (long double)c.chain.q[x->ell - 1] / x->scale;
+    // the inner sums land in ONE block, in giant-step order: the shared-ModDown key switch below takes them as they stand
     std::map<int, CtPtr> inner;
-    for (auto& g : groups) inner[g.first] = ev_.dot_plain(g.second.first, g.second.second, pt_scale);
+    {
+        CtPtr f = groups.begin()->second.first[0];
+        const int ell_in = f->deg >= 2 ? f->ell - 1 : f->ell;
+        std::vector<CtPtr> slab = ev_.new_ct_batch((int)groups.size(), 2, ell_in, 2, 0, f->slots);
+        std::vector<CtPtr> unrot, rot;   // rotate_each_sum keeps the rotated terms' order: give them the block's tail in that order
+        size_t k = 0;
+        for (auto& g : groups)
+            if (g.first % f->slots == 0) inner[g.first] = ev_.dot_plain(g.second.first, g.second.second, pt_scale, slab[k++]);
+        for (auto& g : groups)
+            if (g.first % f->slots != 0) inner[g.first] = ev_.dot_plain(g.second.first, g.second.second, pt_scale, slab[k++]);
+    }
     // giant steps: different inputs, different keys, same shape
     std::vector<CtPtr> gin;
     std::vector<int> gidx;

@@ -328,10 +328,22 @@ CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& we
         std::vector<CtVec> y(4);
         // the four products stay unrescaled through the key switch that sums them: ONE rescale of U (inside rotsum_batch) instead
         // of four, at the price of running that one key switch a limb higher
-        for (int t = 0; t < 4; ++t) y[t] = ev_.mult_plain_batch(x, w2[t]);
-        std::vector<CtVec> rows(x.size(), CtVec(4));
+        // the three products of a row that get rotated are produced next to one another (one block, [row][t]): the key switch
+        // takes them where they are
+        CtVec xflat;
+        std::vector<PtPtr> wflat;
         for (size_t i = 0; i < x.size(); ++i)
-            for (int t = 0; t < 4; ++t) rows[i][t] = y[t][i];
+            for (int t = 1; t < 4; ++t) {
+                xflat.push_back(x[i]);
+                wflat.push_back(w2[t]);
+            }
+        const CtVec rotated = ev_.mult_plain_each(xflat, wflat);
+        y[0] = ev_.mult_plain_batch(x, w2[0]);
+        std::vector<CtVec> rows(x.size(), CtVec(4));
+        for (size_t i = 0; i < x.size(); ++i) {
+            rows[i][0] = y[0][i];
+            for (int t = 1; t < 4; ++t) rows[i][t] = rotated[3 * i + (t - 1)];
+        }
         CtVec u = ev_.rotate_each_sum_rows(rows, {0, 128, 256, 384});
         CtVec z = rotsum_batch(u, 32, 512);
         CtVec res = ev_.mult_plain_batch(z, block_mask(0, 512, mask_val));

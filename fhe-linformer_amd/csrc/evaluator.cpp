@@ -764,10 +764,17 @@ std::vector<CtPtr> Evaluator::mult_plain_each(const std::vector<CtPtr>& vin, con
         }
     }
     std::vector<CtPtr> out(x.size());
+    // operands of one shape: ONE output block for all products, so that any sub-range a later batched key switch takes is
+    // contiguous as it stands (no gather copies); the launches still go in runs of MAX_ITEMS
+    bool one_shape = x.size() > 1;
+    for (const CtPtr& c : x) one_shape = one_shape && c->npoly == x[0]->npoly && c->ell == x[0]->ell && c->deg == x[0]->deg;
+    std::vector<CtPtr> all;
+    if (one_shape) all = new_ct_batch((int)x.size(), x[0]->npoly, x[0]->ell, x[0]->deg + 1, x[0]->scale, x[0]->slots);
     for_runs(x.size(), [&](size_t a, size_t b) { return x[a]->npoly == x[b]->npoly && x[a]->ell == x[b]->ell && x[a]->deg == x[b]->deg; },
              [&](size_t lo, size_t hi) {
                  const CtPtr& f = x[lo];
-                 std::vector<CtPtr> o = new_ct_batch((int)(hi - lo), f->npoly, f->ell, f->deg + 1, f->scale, f->slots);
+                 std::vector<CtPtr> o = one_shape ? std::vector<CtPtr>(all.begin() + lo, all.begin() + hi)
+                                                  : new_ct_batch((int)(hi - lo), f->npoly, f->ell, f->deg + 1, f->scale, f->slots);
                  EwItems it;
                  it.n = (int)(hi - lo);
                  it.vecs = f->npoly * f->ell;
@@ -788,7 +795,7 @@ std::vector<CtPtr> Evaluator::mult_plain_each(const std::vector<CtPtr>& vin, con
     return out;
 }
 
-CtPtr Evaluator::dot_plain(const std::vector<CtPtr>& vin, const std::vector<PtPtr>& p, long double pt_scale) {
+CtPtr Evaluator::dot_plain(const std::vector<CtPtr>& vin, const std::vector<PtPtr>& p, long double pt_scale, const CtPtr& dest) {
     if (vin.size() != p.size() || vin.empty()) throw Error(FHELIN_ERR_ARG, "dot_plain: one plaintext per ciphertext, at least one term");
     // degree-2 operands are rescaled first, every distinct ciphertext once (as mult_plain does)
     std::vector<CtPtr> x = vin;
@@ -829,7 +836,14 @@ CtPtr Evaluator::dot_plain(const std::vector<CtPtr>& vin, const std::vector<PtPt
             it.a[i - lo] = x[i]->d;
             it.b[i - lo] = p[i]->at(f->ell, sf)->d;
         }
-        CtPtr o = new_ct(f->npoly, f->ell, f->deg + 1, f->scale * sf, f->slots);
+        // a caller that will hand several such sums to one batched key switch provides their common block (dest)
+        const bool into_dest = dest && x.size() <= (size_t)EwItems::MAX_ITEMS && dest->npoly == f->npoly && dest->ell == f->ell;
+        CtPtr o = into_dest ? dest : new_ct(f->npoly, f->ell, f->deg + 1, f->scale * sf, f->slots);
+        if (into_dest) {
+            o->deg = f->deg + 1;
+            o->scale = f->scale * sf;
+            o->slots = f->slots;
+        }
         launch_ew_dot(c_.dt, o->d, it, f->ell, c_.stream);
         c_.stats.ct_pt_mult += (u64)(hi - lo);
         c_.stats.ct_pt_limbs += (u64)(hi - lo) * f->ell;

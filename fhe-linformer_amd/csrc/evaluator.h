@@ -138,7 +138,9 @@ public:
     std::vector<CtPtr> mult_plain_each(const std::vector<CtPtr>& v, const std::vector<PtPtr>& p);  // v[i] * p[i]
     // sum_i v[i] * p[i]: the residues of add(...add(mult_plain(v0,p0), mult_plain(v1,p1))...) in one pass per 32 terms when the
     // operands share one shape after the usual pre-rescale (else that chain itself)
-    CtPtr dot_plain(const std::vector<CtPtr>& v, const std::vector<PtPtr>& p, long double pt_scale = 0);   // pt_scale > 0: encode the plaintexts at this scale instead of the level's own
+    CtPtr dot_plain(const std::vector<CtPtr>& v, const std::vector<PtPtr>& p, long double pt_scale = 0,
+                    const CtPtr& dest = CtPtr());   // pt_scale > 0: encode the plaintexts at this scale instead of the level's own;
+                                                    // dest: write the sum there (a slice of a caller's batch block)
     std::vector<CtPtr> add_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b);        // a[i] + b[i]
     std::vector<CtPtr> add_plain_batch(const std::vector<CtPtr>& v, const PtPtr& p);
     std::vector<CtPtr> sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b);        // a[i] - b[i]
