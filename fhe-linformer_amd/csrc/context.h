@@ -179,6 +179,7 @@ struct Context {
     // FHELIN_FUSE_GATHER=0: the rotated c0 parts of a merged rotation sum go through their own gather-and-sum kernel instead of
     // the ModDown epilogue (bit-identical; kept for A/B measurements)
     bool fuse_gather = true;
+    bool fuse_lift = true;      // rescale: centred lift formed in the NTT's first-pass load (FHELIN_FUSE_LIFT)
     struct FftDev {
         const u32* rot = nullptr;     // [slots]      5^j mod 4 slots
         const double* ksi = nullptr;  // [4 slots + 1][2]

@@ -597,6 +597,25 @@ std::vector<CtPtr> Evaluator::rotate_each(const std::vector<CtPtr>& vin, const s
 }
 
 // ------------------------------------------------------------------------------------------------ raw ops
+// K5 steps 2+3: NTT of the centred lift of `last` ([P][N], coefficients modulo q_{ell-1}) into the ell-1 remaining limbs of
+// each polynomial -> lifted [P][ell-1][N].  The lift rides in the load of the transform's first pass (LimbBatch::lift_qlm)
+// when the dropped modulus is below twice every remaining one (x mod q_j is then one conditional subtraction); otherwise,
+// or with FHELIN_FUSE_LIFT=0, the separate lift kernel runs first.  Same residues either way.
+void Evaluator::lift_and_ntt(u64* lifted, const u64* last, int P, int ell) {
+    const u64* qlm = c_.d_qlmod + (size_t)(ell - 1) * (c_.L + 1);
+    bool fuse = c_.fuse_lift;
+    for (int j = 0; j + 1 < ell && fuse; ++j) fuse = c_.chain.q[ell - 1] < 2 * c_.chain.q[j];
+    if (fuse) {
+        LimbBatch fb{lifted, P * (ell - 1), nullptr, 0, ell - 1, last};
+        fb.lift_qlm = qlm;
+        fb.lift_limb = ell - 1;
+        c_.ntt(fb, false);
+        return;
+    }
+    launch_rescale_lift(c_.dt, lifted, last, P, ell, qlm, c_.stream);
+    c_.ntt(LimbBatch{lifted, P * (ell - 1), nullptr, 0, ell - 1}, false);
+}
+
 CtPtr Evaluator::raw_rescale(const CtPtr& a) {
     const int ell = a->ell, P = a->npoly;
     if (ell < 2) throw Error(FHELIN_ERR_STATE, "rescale: no limb left to drop");
@@ -613,8 +632,7 @@ CtPtr Evaluator::raw_rescale(const CtPtr& a) {
         c_.ntt(lb, true);
     }
     u64* lifted = c_.dalloc<u64>((size_t)P * (ell - 1) * N);
-    launch_rescale_lift(c_.dt, lifted, last, P, ell, c_.d_qlmod + (size_t)(ell - 1) * (c_.L + 1), s);
-    c_.ntt(LimbBatch{lifted, P * (ell - 1), nullptr, 0, ell - 1}, false);
+    lift_and_ntt(lifted, last, P, ell);
     CtPtr o = new_ct(P, ell - 1, a->deg, a->scale, a->slots);
     launch_rescale_finish(c_.dt, o->d, a->d, lifted, P, ell, c_.d_qlinv + (size_t)(ell - 1) * (c_.L + 1) * 2, s);
     launch_ok("rescale");
@@ -707,8 +725,7 @@ std::vector<CtPtr> Evaluator::rescale_batch(const std::vector<CtPtr>& vin) {
         lb.src_group_stride = (size_t)ell * N;
         c_.ntt(lb, true);
         u64* lifted = c_.dalloc<u64>((size_t)P * (ell - 1) * N);
-        launch_rescale_lift(c_.dt, lifted, last, P, ell, c_.d_qlmod + (size_t)(ell - 1) * (c_.L + 1), s);
-        c_.ntt(LimbBatch{lifted, P * (ell - 1), nullptr, 0, ell - 1}, false);
+        lift_and_ntt(lifted, last, P, ell);
         std::vector<CtPtr> o = new_ct_batch(B, 2, ell - 1, 1, 0, chunk[0]->slots);
         launch_rescale_finish(c_.dt, o[0]->d, base, lifted, P, ell, c_.d_qlinv + (size_t)(ell - 1) * (c_.L + 1) * 2, s);
         launch_ok("rescale_batch");

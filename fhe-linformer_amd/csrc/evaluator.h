@@ -180,6 +180,7 @@ public:
 
     // raw, no bookkeeping (parity tests): exactly the residue functions of the oracle
     CtPtr raw_rescale(const CtPtr& a);
+    void lift_and_ntt(u64* lifted, const u64* last, int P, int ell);
     CtPtr raw_rotate(const CtPtr& a, u64 galois, const EvalKey& key, bool accumulate = false);
     CtPtr rotate_add(const CtPtr& a, int index);            // a + rot(a, index), one fused key switch (rotsum step :833)
     CtPtr raw_mult_relin(const CtPtr& a, const CtPtr& b, const EvalKey& key);

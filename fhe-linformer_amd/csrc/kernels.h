@@ -27,6 +27,11 @@ struct LimbBatch {
     // when the consumer takes any value below 2^60 (the evaluation-key inner product K7 splits its operands in 30-bit
     // halves and reduces the 128-bit sums once).  Saves the final reduction of the row pass.
     bool lazy_out = false;
+    // forward only, rescale (K5): the input of vector v is the CENTRED LIFT of the single coefficient-form limb
+    // src[v / limb_count][N] (modulus q_lift_limb) into limb v's modulus, formed in the first pass's load instead of by a
+    // separate kernel: r = x mod q_j, minus (q_lift mod q_j) where x > q_lift / 2.  lift_qlm[j] = q_lift mod q_j.
+    const u64* lift_qlm = nullptr;
+    int lift_limb = -1;
 };
 
 // Device-resident per-context tables.

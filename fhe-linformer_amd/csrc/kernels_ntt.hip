@@ -50,6 +50,8 @@ struct NttArgs {
     int lazy_out;             // forward: lazy-path limbs below 2^53 skip the final reduction (LimbBatch::lazy_out)
     int src_group;            // > 0: strided first-pass input (see LimbBatch)
     size_t src_group_stride;
+    const u64* lift_qlm;      // rescale: first-pass input = centred lift of src[vec / limb_count] (LimbBatch::lift_qlm)
+    int lift_limb;
 };
 
 __device__ __forceinline__ size_t src_offset(const NttArgs& a, int vec, int log_n) {
@@ -224,7 +226,7 @@ template <bool INVERSE> __device__ __forceinline__ bool lazy_prime(u64 q) { retu
 // pass A: column transforms over the high A bits of the index.  Tile = 2^A rows x CW columns.
 // tile-local index e = (row << LOGCW) | col ; global index j = (row << 8) | (tile*CW + col).
 // ------------------------------------------------------------------------------------------------
-template <int A, bool INVERSE, bool LAZY>
+template <int A, bool INVERSE, bool LAZY, bool LIFT>
 __device__ __forceinline__ void cols_body(const NttArgs& a, u64* lds, int vec, int tile, int limb, const LimbConst& c) {
     constexpr int LOGCW = 12 - A;
     constexpr int CW = 1 << LOGCW;
@@ -233,7 +235,7 @@ __device__ __forceinline__ void cols_body(const NttArgs& a, u64* lds, int vec, i
     constexpr int REM = A % 4;
     const u64x2* tw = reinterpret_cast<const u64x2*>(a.tw) + ((size_t)limb << LOGN);
     u64* base = a.data + ((size_t)vec << LOGN) + tile * CW;
-    const u64* sbase = a.src + src_offset(a, vec, LOGN) + tile * CW;
+    const u64* sbase = (LIFT ? a.src + ((size_t)(vec / a.limb_count) << LOGN) : a.src + src_offset(a, vec, LOGN)) + tile * CW;
     const int tau = threadIdx.x;
     u64 x[16];
 
@@ -245,6 +247,16 @@ __device__ __forceinline__ void cols_body(const NttArgs& a, u64* lds, int vec, i
         constexpr int P0 = LOGCW + A - 4;
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = sbase[goff(tile_index(tau, k, P0))];
+        if constexpr (LIFT) {
+            // rescale: x is a coefficient modulo q_lift < 2 q (checked by the host): x mod q is one conditional subtraction,
+            // the centred representative subtracts q_lift mod q where x > q_lift / 2  (== rescale_lift_kernel)
+            const u64 half = a.moduli[a.lift_limb] >> 1, qlm = a.lift_qlm[limb];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const u64 r = csub_mask(x[k], c.q);
+                x[k] = x[k] > half ? sub_mod(r, qlm, c.q) : r;
+            }
+        }
         RoundTw rt, rn;
         load_round_tw<0, 4>(rt, tw, LOGN, 8 + P0 - LOGCW, tau >> P0);
         fwd_round<0, 4, LAZY>(x, rt, c);
@@ -300,7 +312,7 @@ __device__ __forceinline__ void cols_body(const NttArgs& a, u64* lds, int vec, i
     }
 }
 
-template <int A, bool INVERSE>
+template <int A, bool INVERSE, bool LIFT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ntt_cols_kernel(NttArgs a) {
     constexpr int LOGTILES = A - 4;
     __shared__ u64 lds[LDS_WORDS];
@@ -310,9 +322,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
     if (limb < 0) return;
     const LimbConst c = limb_const(a, limb);
     if (lazy_prime<INVERSE>(c.q))
-        cols_body<A, INVERSE, true>(a, lds, vec, tile, limb, c);
+        cols_body<A, INVERSE, true, LIFT>(a, lds, vec, tile, limb, c);
     else
-        cols_body<A, INVERSE, false>(a, lds, vec, tile, limb, c);
+        cols_body<A, INVERSE, false, LIFT>(a, lds, vec, tile, limb, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -426,6 +438,8 @@ template <int A>
 void launch_cols(const NttArgs& a, bool inverse, int blocks, hipStream_t s) {
     if (inverse)
         hipLaunchKernelGGL((ntt_cols_kernel<A, true>), dim3(blocks), dim3(256), 0, s, a);
+    else if (a.lift_qlm)
+        hipLaunchKernelGGL((ntt_cols_kernel<A, false, true>), dim3(blocks), dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((ntt_cols_kernel<A, false>), dim3(blocks), dim3(256), 0, s, a);
 }
@@ -447,6 +461,8 @@ static void launch_ntt_impl(const DeviceTables& t, const LimbBatch& b, bool inve
     a.src_group = b.src ? b.src_group : 0;
     a.src_group_stride = b.src_group_stride;
     a.lazy_out = (!inverse && b.lazy_out) ? 1 : 0;
+    a.lift_qlm = (!inverse && b.src && b.lift_limb >= 0) ? b.lift_qlm : nullptr;
+    a.lift_limb = b.lift_limb;
     a.tw = inverse ? t.tw_inv : t.tw_fwd;
     a.tw_rows = inverse ? t.tw_rows_inv : t.tw_rows_fwd;
     a.moduli = t.moduli;

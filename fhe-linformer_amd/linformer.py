@@ -147,17 +147,22 @@ class GpuController:
         mask = np.where((i % 128 < inputs_number) & (i < 128 * inputs_number), 0.0, -1.0)
         return self.e.add(res, self.encode(mask, res.level))
 
-    def _cheb(self, f, c, a, b, degree):
-        return self.e.eval_chebyshev(c, cheb_coeffs(f, a, b, degree), a, b)
+    _fits = {}   # Chebyshev fits are data-independent: one fit per (function, interval, degree), as a C++ driver's static table
+
+    def _cheb(self, key, f, c, a, b, degree):
+        key = key + (a, b, degree)
+        if key not in GpuController._fits:
+            GpuController._fits[key] = cheb_coeffs(f, a, b, degree)
+        return self.e.eval_chebyshev(c, GpuController._fits[key], a, b)
 
     def eval_inverse_naive(self, c, lo, hi):
-        return self._cheb(lambda x: 1.0 / x, c, lo, hi, 119)
+        return self._cheb(("inv",), lambda x: 1.0 / x, c, lo, hi, 119)
 
     def eval_gelu_function(self, c, lo, hi, mult, degree):
-        return self._cheb(lambda x: 0.5 * (x / mult) * (1 + math.erf((x / mult) / 1.41421356237)), c, lo, hi, degree)
+        return self._cheb(("gelu", mult), lambda x: 0.5 * (x / mult) * (1 + math.erf((x / mult) / 1.41421356237)), c, lo, hi, degree)
 
     def eval_tanh_function(self, c, lo, hi, mult, degree):
-        return self._cheb(lambda x: math.tanh(x / mult), c, lo, hi, degree)
+        return self._cheb(("tanh", mult), lambda x: math.tanh(x / mult), c, lo, hi, degree)
 
 
 # ---- the circuit: reference src/main.cpp:145-475 (CLS-query variant, as built) -----------------------------
