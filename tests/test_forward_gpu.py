@@ -48,3 +48,50 @@ def test_encrypted_forward_matches_plaintext_circuit(fa, variant, preset, n_q):
         assert out.info()["ell"] >= 2
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("variant,preset", [("main", "bench"), ("main_2", "reference")])
+def test_forward_under_a_recorded_level_plan(fa, variant, preset):
+    """Level plan on the whole driver: one recorded pass, then the same driver on OTHER inputs with every fresh
+    encryption / bootstrap output started at the planned limbs: same logits as the clear-text circuit (tolerances of the test
+    above), every bootstrap reached with exactly the limbs it reads, strictly fewer limb-NTTs than the unplanned pass —
+    for the CLS-only driver at the headline ring (sparse packing) and the full-attention driver at the reference's ring."""
+    from fhe_linformer_amd import linformer as lf
+    from oracle import plain_forward as pf, circuit_sim as cs
+    S = 129
+    w = pf.synthetic_model(1234)
+    eng = fa.Engine(preset, seed=11, n_q=28, n_p=-1)
+    try:
+        eng.keygen()
+        eng.gen_relin_key()
+        eng.gen_rotation_keys(fa.circuit_rotation_indices())
+        eng.bootstrap_setup(3, 3, 16384)
+        ctl = lf.GpuController(eng)
+
+        def one(mode, seed):
+            ins = pf.client_inputs(w, pf.synthetic_tokens(S, seed))
+            if mode:
+                eng.level_plan_begin(mode)
+            eng.stats(reset=True)
+            out = lf.forward(ctl, w, *ins, None, variant)
+            lg = lf.logits_from_slots(eng.decrypt(out))
+            ntt = eng.stats()["limb_ntt"]
+            plan = eng.level_plan_end() if mode else None
+            ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, *ins, None, variant))
+            return lg, ref, ntt, plan
+
+        one(None, 4320)                                          # first pass: the masks are encoded (and cached) once
+        lg0, ref0, ntt_plain, _ = one(None, 4321)
+        lg1, ref1, ntt_rec, plan = one("record", 4322)
+        assert ntt_rec == ntt_plain                              # recording changes nothing
+        assert len(plan) >= 194 + 8 and min(t for t in plan if t > 0) < 28
+        assert sum(1 for t in plan[:64] if 0 < t < 28) >= 32     # the F-projected inputs (V path) start far below 28 limbs
+        lg2, ref2, ntt_plan, _ = one("apply", 4323)
+        assert ntt_plan < 0.9 * ntt_plain, (ntt_plan, ntt_plain)
+        for lg, ref in ((lg0, ref0), (lg1, ref1), (lg2, ref2)):
+            assert np.max(np.abs(lg - ref)) < 2e-2
+            top2 = np.sort(ref)[-2:]
+            if top2[1] - top2[0] > 4e-2:
+                assert int(np.argmax(lg)) == int(np.argmax(ref))
+    finally:
+        eng.close()
