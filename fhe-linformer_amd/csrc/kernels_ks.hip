@@ -87,13 +87,30 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
         modup_body<MAXA, false>(t, sh, ext, cc, hatinv, hatmod, j, lo, cnt, n);
 }
 
+// Block -> (coefficient tile, target limb, batch row).  The workgroups of a launch are dealt round-robin to the 8 XCDs (each
+// with its own L2) in linear block order; taking the linear id modulo 8 as the XCD and ordering each XCD's share as
+// (limb, tile, row) with the row fastest makes the B rows that share one key tile run back to back on ONE XCD (the tile is
+// fetched once instead of once per row and XCD), and keeps all gathers of one (limb, row) plane on one XCD.  Placement only.
+struct KsBlock {
+    int bx, bi, tt;
+};
+__device__ __forceinline__ KsBlock ks_block(const KsShape& sh) {
+    const unsigned nx = gridDim.x, nblk = gridDim.x * gridDim.y;
+    unsigned b = blockIdx.y * nx + blockIdx.x;
+    if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
+    KsBlock k;
+    k.bi = (int)(b % (unsigned)sh.batch);
+    k.bx = (int)((b / (unsigned)sh.batch) % nx);
+    k.tt = (int)(b / ((unsigned)sh.batch * nx));
+    return k;
+}
+
 // grid (N/512, ell + k)
 __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape sh, u64* __restrict__ accQ, u64* __restrict__ accP, const u64* __restrict__ ext,
                                                        const u64* __restrict__ evk, const u64* __restrict__ c_ntt) {
     const int nt = sh.ell + sh.k;
-    // batch row fastest: the blocks of one target limb's key slice (shared by all rows) are dispatched back to back and
-    // find it in L2 instead of streaming the key once per row
-    const int bi = blockIdx.y % sh.batch, tt = blockIdx.y / sh.batch;
+    const KsBlock kb_ = ks_block(sh);
+    const int bi = kb_.bi, tt = kb_.tt;
     const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
     if (!sh.shared_input) {
         ext += (size_t)bi * sh.beta * nt * ((size_t)1 << t.log_n);
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
     accP += (size_t)bi * 2 * sh.k * ((size_t)1 << t.log_n);
     const Barrett br = load_barrett(t, limb);
     const size_t row = ((size_t)1 << t.log_n) >> 1;
-    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n2 = (size_t)kb_.bx * 256 + threadIdx.x;
     const size_t kstride = (size_t)(sh.L1 + sh.k) * row;  // one evk component, in u64x2 units
     const u64x2* E = reinterpret_cast<const u64x2*>(ext);
     const u64x2* K = reinterpret_cast<const u64x2*>(evk);
@@ -165,7 +182,8 @@ __device__ __forceinline__ u32 sel_mask(u32 a, u32 b, unsigned long long mask) {
 __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsShape sh, u64* __restrict__ accQ, u64* __restrict__ accP,
                                                              const u64* __restrict__ ext, const u64* __restrict__ c_ntt) {
     const int nt = sh.ell + sh.k;
-    const int bi = blockIdx.y % sh.batch, tt = blockIdx.y / sh.batch;
+    const KsBlock kb_ = ks_block(sh);
+    const int bi = kb_.bi, tt = kb_.tt;
     const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
     const size_t N = (size_t)1 << t.log_n, row = N >> 1;
     ext += (size_t)bi * (sh.ext_batch_stride ? sh.ext_batch_stride : (size_t)sh.beta * nt * N);
@@ -174,7 +192,7 @@ __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsS
     accQ += (size_t)bi * 2 * sh.ell * N;
     accP += (size_t)bi * 2 * sh.k * N;
     const Barrett br = load_barrett(t, limb);
-    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n2 = (size_t)kb_.bx * 256 + threadIdx.x;
     const size_t kstride = (size_t)(sh.L1 + sh.k) * row;  // one evk component, in u64x2 units
     u64 lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};      // b.x, b.y, a.x, a.y
     Acc30 b0 = {0, 0, 0}, b1 = {0, 0, 0}, a0 = {0, 0, 0}, a1 = {0, 0, 0};
