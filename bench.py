@@ -252,8 +252,15 @@ def ops_section(eng, np, ells=(24, 16, 8), batch=8, reps=10, big_rows=128, short
         row_l = 5 * ell + rotsum_l + 3 * ell
         rec("matmulRE_row", ell, 1, timed(lambda: eng.matmulRE(xs[:1], w, bias), 1, reps), row_l)
         if not short or ell == ells[0]:
-            rows = [xs[i % batch] for i in range(big_rows)]
-            rec("matmulRE_rows", ell, big_rows, timed(lambda: eng.matmulRE(rows, w, bias), big_rows, max(2, reps // 4)), row_l)
+            # distinct ciphertexts (identical rows of one call are evaluated once) and eager evaluation (deferred rows would
+            # return handles without doing the work): every one of the big_rows trees is computed inside the timed region
+            rows = eng.encrypt_batch(rng.uniform(-1, 1, (big_rows, ns)), level=L1 - ell)
+            eng.set_lazy_rows(False)
+            try:
+                rec("matmulRE_rows", ell, big_rows, timed(lambda: eng.matmulRE(rows, w, bias), big_rows, max(2, reps // 4)), row_l)
+            finally:
+                eng.set_lazy_rows(True)
+            del rows
         del xs, ys, prods
     return recs
 
