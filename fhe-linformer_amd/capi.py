@@ -167,6 +167,7 @@ def load_library():
         "fhelin_lincomb": (i32, [vp, C.POINTER(vp), C.POINTER(C.c_double), i32, C.c_double, C.POINTER(vp)]),
         "fhelin_eval_poly": (i32, [vp, vp, C.POINTER(C.c_double), i32, C.POINTER(vp)]),
         "fhelin_eval_chebyshev": (i32, [vp, vp, C.POINTER(C.c_double), i32, C.c_double, C.c_double, C.POINTER(vp)]),
+        "fhelin_eval_chebyshev_batch": (i32, [vp, C.POINTER(vp), i32, C.POINTER(C.c_double), i32, C.c_double, C.c_double, C.POINTER(vp)]),
         "fhelin_bootstrap_setup": (i32, [vp, i32, i32, i32]),
         "fhelin_bootstrap": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_bootstrap_config": (i32, [vp, i32, i32, i32, i32]),
@@ -557,6 +558,13 @@ class Engine:
     def eval_chebyshev(self, x, coeffs, a=-1.0, b=1.0):
         cf = np.ascontiguousarray(coeffs, dtype=np.float64)
         return self._un(self.lib.fhelin_eval_chebyshev, x, cf.ctypes.data_as(C.POINTER(C.c_double)), cf.size, float(a), float(b))
+
+    def eval_chebyshev_batch(self, xs, coeffs, a=-1.0, b=1.0):
+        cf = np.ascontiguousarray(coeffs, dtype=np.float64)
+        outs = self._outs(len(xs))
+        self._ck(self.lib.fhelin_eval_chebyshev_batch(self.h, self._harr(xs), len(xs), cf.ctypes.data_as(C.POINTER(C.c_double)), cf.size,
+                                                      float(a), float(b), outs))
+        return self._cts(outs, len(xs))
 
     def bootstrap(self, a):
         return self._un(self.lib.fhelin_bootstrap, a)

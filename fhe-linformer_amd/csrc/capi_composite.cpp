@@ -321,6 +321,14 @@ int fhelin_eval_chebyshev(fhelin_ctx* c, const fhelin_ct* x, const double* coeff
     *out = wrap(c, run_heavy(c, x, [&](const CtPtr& in) { return c->ev.eval_chebyshev(in, cf, a, b); }));
     FHELIN_CATCH
 }
+int fhelin_eval_chebyshev_batch(fhelin_ctx* c, const fhelin_ct* const* xs, int32_t n, const double* coeffs, int32_t n_coeffs, double a,
+                                double b, fhelin_ct** outs) {
+    NEED(c && xs && coeffs && outs && n >= 0);
+    FHELIN_TRY
+    const std::vector<double> cf(coeffs, coeffs + n_coeffs);
+    emit(c, c->ev.eval_chebyshev_many(vec_of(c, xs, n), cf, a, b), outs);
+    FHELIN_CATCH
+}
 int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t budget_enc, int32_t budget_dec, int32_t slots) {
     NEED(c);
     FHELIN_TRY

@@ -265,6 +265,10 @@ int fhelin_eval_poly(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, in
 /* Chebyshev series coeffs[0]/2 + sum_{k>=1} coeffs[k] T_k(u), u = (2x-(a+b))/(b-a)     EvalChebyshevFunction :1319-1335
  * (the shim computes the coefficients from the C++ lambda exactly like EvalChebyshevCoefficients) */
 int fhelin_eval_chebyshev(fhelin_ctx* c, const fhelin_ct* x, const double* coeffs, int32_t n, double a, double b, fhelin_ct** out);
+/* the same series on n ciphertexts at once (EvalChebyshevFunction in a driver's loop over independent ciphertexts,
+ * src/main.cpp:354-358): every multiplication round is ONE batched relinearisation over all of them; residues identical to n calls */
+int fhelin_eval_chebyshev_batch(fhelin_ctx* c, const fhelin_ct* const* xs, int32_t n, const double* coeffs, int32_t n_coeffs, double a,
+                                double b, fhelin_ct** outs);
 /* CKKS bootstrapping: EvalBootstrapSetup/KeyGen :238-239 and EvalBootstrap :445 */
 int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t level_budget_enc, int32_t level_budget_dec, int32_t slots);
 int fhelin_bootstrap(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);

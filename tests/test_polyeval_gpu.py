@@ -112,3 +112,14 @@ def test_paterson_stockmeyer_rounds_give_the_residues_of_the_dependent_order(fa,
             e.close()
     assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
     assert np.array_equal(outs[0][0], outs[1][0])
+
+
+def test_chebyshev_batch_entry_point_matches_single_calls(eng):
+    """fhelin_eval_chebyshev_batch: n ciphertexts through one series together == n single calls, residue for residue"""
+    rng = np.random.default_rng(8)
+    c = rng.uniform(-1, 1, 32) / np.arange(1, 33)
+    cts = [eng.encrypt(_x(eng, 20 + i, -1, 1)) for i in range(3)]
+    single = [eng.eval_chebyshev(ct, c).export() for ct in cts]
+    batch = eng.eval_chebyshev_batch(cts, c)
+    for s, b in zip(single, batch):
+        assert np.array_equal(s, b.export())
