@@ -578,16 +578,16 @@ std::vector<double> Client::decrypt(const CtPtr& cin, int slots) {
     const u64 q0 = c_.chain.q[0];
     const size_t gap = (N / 2) / slots;
     std::vector<std::pair<double, double>> v(slots);
+    const u64 q1 = nl > 1 ? c_.chain.q[1] : 1;
+    const u64 inv = nl > 1 ? h_invmod(q0 % q1, q1) : 0;     // q0^-1 mod q1, once (not per coefficient)
+    const u128 Q = (u128)q0 * q1;
     auto lift = [&](size_t idx) -> long double {
         if (nl == 1) {
             u64 x = h[idx];
             return x > q0 / 2 ? -(long double)(q0 - x) : (long double)x;
         }
-        const u64 q1 = c_.chain.q[1];
         const u64 x0 = h[idx], x1 = h[N + idx];
-        const u64 inv = h_invmod(q0 % q1, q1);
         const u64 d = h_mulmod(sub_mod(x1, x0 % q1, q1), inv, q1);
-        const u128 Q = (u128)q0 * q1;
         const u128 x = (u128)x0 + (u128)q0 * d;
         if (x > Q / 2) {
             const u128 mag = Q - x;
