@@ -51,6 +51,23 @@ def main():
             gsum[b] += g / 1e3
         prev_e = e if prev_e is None else max(prev_e, e)
     print("  gaps:", {b: (gaps[b], round(gsum[b], 1)) for b in ['<10us', '<50us', '<500us', '<5ms', '>=5ms']})
+    # the largest gaps with the kernels on either side (what the host was doing while the GPU had nothing queued)
+    big = []
+    prev_e, prev_k = None, None
+    for r in win:
+        s_, e_ = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        if prev_e is not None and s_ > prev_e:
+            big.append(((s_ - prev_e) / 1e3, prev_k, short(r['Kernel_Name'])))
+        if prev_e is None or e_ > prev_e:
+            prev_e, prev_k = e_, short(r['Kernel_Name'])
+    pair = collections.defaultdict(lambda: [0, 0.0])
+    for g, a, b in big:
+        if g >= 30:
+            pair[(a, b)][0] += 1
+            pair[(a, b)][1] += g
+    print("  gaps >= 30 us by (kernel before -> kernel after), total us:")
+    for (a, b), (c, t) in sorted(pair.items(), key=lambda x: -x[1][1])[:14]:
+        print(f"    {a:32s} -> {b:32s} x{c:4d} {t:9.0f} us")
 
 
 main()
