@@ -267,18 +267,35 @@ CtPtr Bootstrapper::apply(const LinStage& st, const CtPtr& xin) {
     const int lvl = x->level();
     if (x->ell >= 2 && fabsl(x->scale / c.sf_real[lvl] - 1.0L) > 1e-12L)
         pt_scale = c.sf_real[lvl + 1] * (long double)c.chain.q[x->ell - 1] / x->scale;
-    // the inner sums land in ONE block, in giant-step order: the shared-ModDown key switch below takes them as they stand
+    // the inner sums land in ONE block, in giant-step order (the shared-ModDown key switch below takes them as they stand), and
+    // all of them come out of ONE pass over the rotated ciphertexts (Evaluator::dot_plain_groups); per-group passes otherwise
     std::map<int, CtPtr> inner;
     {
         CtPtr f = groups.begin()->second.first[0];
         const int ell_in = f->deg >= 2 ? f->ell - 1 : f->ell;
         std::vector<CtPtr> slab = ev_.new_ct_batch((int)groups.size(), 2, ell_in, 2, 0, f->slots);
-        std::vector<CtPtr> unrot, rot;   // rotate_each_sum keeps the rotated terms' order: give them the block's tail in that order
-        size_t k = 0;
+        std::vector<int> order;   // unrotated group first, then the rotated ones in ascending order (= rotate_each_sum's order)
         for (auto& g : groups)
-            if (g.first % f->slots == 0) inner[g.first] = ev_.dot_plain(g.second.first, g.second.second, pt_scale, slab[k++]);
+            if (g.first % f->slots == 0) order.push_back(g.first);
         for (auto& g : groups)
-            if (g.first % f->slots != 0) inner[g.first] = ev_.dot_plain(g.second.first, g.second.second, pt_scale, slab[k++]);
+            if (g.first % f->slots != 0) order.push_back(g.first);
+        std::vector<CtPtr> cts;
+        for (int b : bidx) cts.push_back(babies[b]);
+        std::vector<std::vector<PtPtr>> pts(order.size(), std::vector<PtPtr>(bidx.size()));
+        for (const auto& t : st.terms) {
+            const size_t gi = std::find(order.begin(), order.end(), t.giant) - order.begin();
+            const size_t bi = std::find(bidx.begin(), bidx.end(), t.baby) - bidx.begin();
+            pts[gi][bi] = t.diag;
+        }
+        if (ev_.dot_plain_groups(cts, pts, pt_scale, slab)) {
+            for (size_t k = 0; k < order.size(); ++k) inner[order[k]] = slab[k];
+        } else {
+            size_t k = 0;
+            for (int g : order) {
+                auto& grp = groups[g];
+                inner[g] = ev_.dot_plain(grp.first, grp.second, pt_scale, slab[k++]);
+            }
+        }
     }
     // giant steps: different inputs, different keys, same shape
     std::vector<CtPtr> gin;

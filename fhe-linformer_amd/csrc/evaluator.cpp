@@ -870,6 +870,41 @@ CtPtr Evaluator::dot_plain(const std::vector<CtPtr>& vin, const std::vector<PtPt
     return acc;
 }
 
+bool Evaluator::dot_plain_groups(const std::vector<CtPtr>& cts, const std::vector<std::vector<PtPtr>>& pts, long double pt_scale,
+                                 const std::vector<CtPtr>& dest) {
+    if (!dot_groups || cts.empty() || cts.size() > (size_t)EwDotGroups::MAX_A || pts.empty() || pts.size() > (size_t)EwDotGroups::MAX_G ||
+        dest.size() != pts.size())
+        return false;
+    const CtPtr& f = cts[0];
+    for (const CtPtr& c : cts)
+        if (c->npoly != 2 || c->deg != 1 || c->ell != f->ell || fabsl(c->scale / f->scale - 1.0L) > 1e-9L) return false;
+    for (const CtPtr& o : dest)
+        if (!o || o->npoly != 2 || o->ell != f->ell) return false;
+    const long double sf = pt_scale > 0 ? pt_scale : c_.sf_real[f->level()];
+    EwDotGroups d;
+    d.na = (int)cts.size();
+    d.ng = (int)pts.size();
+    d.ell = f->ell;
+    for (int b = 0; b < d.na; ++b) d.a[b] = cts[b]->d;
+    u64 terms = 0;
+    for (int g = 0; g < d.ng; ++g) {
+        if (pts[g].size() != cts.size()) return false;
+        for (int b = 0; b < d.na; ++b) {
+            d.p[g][b] = pts[g][b] ? pts[g][b]->at(f->ell, sf)->d : nullptr;
+            terms += pts[g][b] ? 1 : 0;
+        }
+        d.out[g] = dest[g]->d;
+        dest[g]->deg = f->deg + 1;
+        dest[g]->scale = f->scale * sf;
+        dest[g]->slots = f->slots;
+    }
+    launch_ew_dot_groups(c_.dt, d, c_.stream);
+    launch_ok("dot_plain_groups");
+    c_.stats.ct_pt_mult += terms;
+    c_.stats.ct_pt_limbs += terms * (u64)f->ell;
+    return true;
+}
+
 std::vector<CtPtr> Evaluator::add_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 1); }
 std::vector<CtPtr> Evaluator::sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 2); }
 

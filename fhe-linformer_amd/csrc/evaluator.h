@@ -86,6 +86,7 @@ public:
     // base pointer of `v` if its members are consecutive views of one block (else nullptr)
     static u64* contiguous_base(const std::vector<CtPtr>& v);
     std::vector<CtPtr> make_contiguous(const std::vector<CtPtr>& v);
+    bool dot_groups = true;    // inner sums of all giant steps of a linear stage in one pass (dot_plain_groups); FHELIN_DOT_GROUPS=0: one pass each
     bool cheb_rounds = true;   // Paterson-Stockmeyer products in rounds (polyeval.cpp cheb_recurse); FHELIN_CHEB_ROUNDS=0: one at a time
     int batch_limit = 16;   // rows processed per batched key switch (FHELIN_BATCH overrides; 8 / 16 / 24 / 32 measured: DESIGN.md)
     CtPtr clone(const CtPtr& a);
@@ -138,6 +139,10 @@ public:
     std::vector<CtPtr> mult_plain_each(const std::vector<CtPtr>& v, const std::vector<PtPtr>& p);  // v[i] * p[i]
     // sum_i v[i] * p[i]: the residues of add(...add(mult_plain(v0,p0), mult_plain(v1,p1))...) in one pass per 32 terms when the
     // operands share one shape after the usual pre-rescale (else that chain itself)
+    // out_g = sum_b cts[b] * pts[g][b] (null = term absent) for all g in ONE pass over the ciphertexts, written to dest[g]
+    // (deg+1, scale x plaintext scale); false if the operands do not fit the kernel (caller falls back to dot_plain per g)
+    bool dot_plain_groups(const std::vector<CtPtr>& cts, const std::vector<std::vector<PtPtr>>& pts, long double pt_scale,
+                          const std::vector<CtPtr>& dest);
     CtPtr dot_plain(const std::vector<CtPtr>& v, const std::vector<PtPtr>& p, long double pt_scale = 0,
                     const CtPtr& dest = CtPtr());   // pt_scale > 0: encode the plaintexts at this scale instead of the level's own;
                                                     // dest: write the sum there (a slice of a caller's batch block)

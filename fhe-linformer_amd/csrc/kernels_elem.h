@@ -54,6 +54,18 @@ void launch_ew_items(const DeviceTables& t, const EwItems& it, int op, int limb_
 // one pass (the diagonal sums of the bootstrapping linear transforms, wrapUpRepeated, matmulCRlarge) instead of n product
 // launches and a tree of additions.  128-bit accumulation, one reduction: the canonical residue of the sum.
 void launch_ew_dot(const DeviceTables& t, u64* out, const EwItems& it, int limb_count, hipStream_t s);
+// Several such inner products over the SAME ciphertexts in one pass: out_g = sum_b a_b * p_{g,b} for g < ng (the inner sums of
+// all giant steps of a baby-step/giant-step linear transform: every rotated ciphertext is read once instead of once per
+// giant step).  a_b: [2][ell][N]; p_{g,b}: [ell][N] or nullptr (term absent); out_g: [2][ell][N].  Same 128-bit accumulation and
+// single reduction per output as launch_ew_dot: identical residues.
+struct EwDotGroups {
+    static constexpr int MAX_A = 16, MAX_G = 8;
+    int na = 0, ng = 0, ell = 0;
+    const u64* a[MAX_A];
+    const u64* p[MAX_G][MAX_A];
+    u64* out[MAX_G];
+};
+void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& d, hipStream_t s);
 
 struct KsShape {
     int ell;     // live Q limbs

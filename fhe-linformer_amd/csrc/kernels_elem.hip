@@ -98,6 +98,43 @@ __global__ __launch_bounds__(256) void ew_dot_kernel(DeviceTables t, u64* out, E
     reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
 }
 
+// out_g[c][tt] = sum_b a_b[c][tt] * p_{g,b}[tt] for both components c and every g; grid (N/512, ell).  NA = compile-time bound
+// on the number of ciphertexts held in registers (2 components x a coefficient pair each).
+template <int NA>
+__global__ __launch_bounds__(256) void ew_dot_groups_kernel(DeviceTables t, EwDotGroups d) {
+    const int tt = blockIdx.y;
+    const Barrett br = load_barrett(t, tt);
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const size_t o0 = (size_t)tt * row + n2, o1 = (size_t)(d.ell + tt) * row + n2;
+    u64x2 a0[NA], a1[NA];
+#pragma unroll
+    for (int b = 0; b < NA; ++b)
+        if (b < d.na) {
+            a0[b] = reinterpret_cast<const u64x2*>(d.a[b])[o0];
+            a1[b] = reinterpret_cast<const u64x2*>(d.a[b])[o1];
+        }
+    for (int g = 0; g < d.ng; ++g) {
+        Acc128 x0 = {0, 0}, y0 = {0, 0}, x1 = {0, 0}, y1 = {0, 0};
+#pragma unroll
+        for (int b = 0; b < NA; ++b)
+            if (b < d.na && d.p[g][b]) {
+                const u64x2 w = reinterpret_cast<const u64x2*>(d.p[g][b])[o0];
+                acc_mac(x0, a0[b].x, w.x);
+                acc_mac(y0, a0[b].y, w.y);
+                acc_mac(x1, a1[b].x, w.x);
+                acc_mac(y1, a1[b].y, w.y);
+            }
+        u64x2 r0, r1;
+        r0.x = barrett_reduce128(x0.lo, x0.hi, br);
+        r0.y = barrett_reduce128(y0.lo, y0.hi, br);
+        r1.x = barrett_reduce128(x1.lo, x1.hi, br);
+        r1.y = barrett_reduce128(y1.lo, y1.hi, br);
+        reinterpret_cast<u64x2*>(d.out[g])[o0] = r0;
+        reinterpret_cast<u64x2*>(d.out[g])[o1] = r1;
+    }
+}
+
 // out[v] = acc[v] + a[v] * b[v % b_mod]
 __global__ __launch_bounds__(256) void ew_muladd_kernel(DeviceTables t, u64* out, const u64* acc, const u64* a, const u64* b,
                                                         int b_mod, int limb_first, int limb_count) {
@@ -311,6 +348,13 @@ void launch_ew_items(const DeviceTables& t, const EwItems& it, int op, int limb_
 void launch_ew_dot(const DeviceTables& t, u64* out, const EwItems& it, int limb_count, hipStream_t s) {
     if (it.n <= 0 || it.vecs <= 0) return;
     hipLaunchKernelGGL(ew_dot_kernel, grid2(t.log_n, it.vecs), dim3(256), 0, s, t, out, it, limb_count);
+}
+void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& d, hipStream_t s) {
+    if (d.na <= 0 || d.ng <= 0 || d.ell <= 0) return;
+    if (d.na <= 8)
+        hipLaunchKernelGGL((ew_dot_groups_kernel<8>), grid2(t.log_n, d.ell), dim3(256), 0, s, t, d);
+    else
+        hipLaunchKernelGGL((ew_dot_groups_kernel<16>), grid2(t.log_n, d.ell), dim3(256), 0, s, t, d);
 }
 void launch_ew_mul(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s) {
     if (nvec <= 0) return;

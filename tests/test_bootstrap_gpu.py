@@ -118,3 +118,20 @@ def test_packed_and_two_ciphertext_modular_reduction_agree(fa, monkeypatch):
     for packed in ("1", "0"):
         assert np.max(np.abs(res[packed][0] - m)) < 2e-4, packed
     assert res["1"][1:] == res["0"][1:]
+
+
+def test_grouped_inner_sums_give_the_same_residues(fa, monkeypatch):
+    """the inner sums of all giant steps of a linear stage come out of one pass over the rotated ciphertexts
+    (Evaluator::dot_plain_groups, kernel ew_dot_groups): exact integer sums, so the bootstrapped ciphertext must equal the one
+    computed with one pass per giant step (FHELIN_DOT_GROUPS=0) residue for residue"""
+    outs = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("FHELIN_DOT_GROUPS", on)
+        eng = _engine(fa, 10)
+        try:
+            m = np.random.default_rng(3).uniform(-1, 1, 1 << 10)
+            ct = eng.encrypt(m, level=eng.n_q - 3)               # same seed, same call sequence: the same keys and ciphertext
+            outs.append(eng.bootstrap(ct).export())
+        finally:
+            eng.close()
+    assert np.array_equal(outs[0], outs[1])
