@@ -98,40 +98,37 @@ __global__ __launch_bounds__(256) void ew_dot_kernel(DeviceTables t, u64* out, E
     reinterpret_cast<u64x2*>(out)[(size_t)v * row + n2] = r;
 }
 
-// out_g[c][tt] = sum_b a_b[c][tt] * p_{g,b}[tt] for both components c and every g; grid (N/512, ell).  NA = compile-time bound
-// on the number of ciphertexts held in registers (2 components x a coefficient pair each).
+// out_g[c][tt] = sum_b a_b[c][tt] * p_{g,b}[tt] for every g; grid (N/512, 2 ell): one component c of one limb tt per block, the
+// NA ciphertext pairs of a thread held in registers across the loop over g.  The two blocks of a (limb, tile) that differ
+// only in c read the same plaintext tile: in XCD-aware order (logical id = (tt, tile, c), c fastest, contiguous id ranges per
+// XCD) they run back to back on one XCD and the second finds the tile in L2.
 template <int NA>
 __global__ __launch_bounds__(256) void ew_dot_groups_kernel(DeviceTables t, EwDotGroups d) {
-    const int tt = blockIdx.y;
+    const unsigned nx = gridDim.x, nblk = gridDim.x * gridDim.y;
+    unsigned id = blockIdx.y * nx + blockIdx.x;
+    if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
+    const int comp = (int)(id & 1), bx = (int)((id >> 1) % nx), tt = (int)((id >> 1) / nx);
     const Barrett br = load_barrett(t, tt);
-    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n2 = (size_t)bx * 256 + threadIdx.x;
     const size_t row = ((size_t)1 << t.log_n) >> 1;
-    const size_t o0 = (size_t)tt * row + n2, o1 = (size_t)(d.ell + tt) * row + n2;
-    u64x2 a0[NA], a1[NA];
+    const size_t op = (size_t)tt * row + n2, oc = (size_t)(comp * d.ell + tt) * row + n2;
+    u64x2 a[NA];
 #pragma unroll
     for (int b = 0; b < NA; ++b)
-        if (b < d.na) {
-            a0[b] = reinterpret_cast<const u64x2*>(d.a[b])[o0];
-            a1[b] = reinterpret_cast<const u64x2*>(d.a[b])[o1];
-        }
+        if (b < d.na) a[b] = reinterpret_cast<const u64x2*>(d.a[b])[oc];
     for (int g = 0; g < d.ng; ++g) {
-        Acc128 x0 = {0, 0}, y0 = {0, 0}, x1 = {0, 0}, y1 = {0, 0};
+        Acc128 x = {0, 0}, y = {0, 0};
 #pragma unroll
         for (int b = 0; b < NA; ++b)
             if (b < d.na && d.p[g][b]) {
-                const u64x2 w = reinterpret_cast<const u64x2*>(d.p[g][b])[o0];
-                acc_mac(x0, a0[b].x, w.x);
-                acc_mac(y0, a0[b].y, w.y);
-                acc_mac(x1, a1[b].x, w.x);
-                acc_mac(y1, a1[b].y, w.y);
+                const u64x2 w = reinterpret_cast<const u64x2*>(d.p[g][b])[op];
+                acc_mac(x, a[b].x, w.x);
+                acc_mac(y, a[b].y, w.y);
             }
-        u64x2 r0, r1;
-        r0.x = barrett_reduce128(x0.lo, x0.hi, br);
-        r0.y = barrett_reduce128(y0.lo, y0.hi, br);
-        r1.x = barrett_reduce128(x1.lo, x1.hi, br);
-        r1.y = barrett_reduce128(y1.lo, y1.hi, br);
-        reinterpret_cast<u64x2*>(d.out[g])[o0] = r0;
-        reinterpret_cast<u64x2*>(d.out[g])[o1] = r1;
+        u64x2 r;
+        r.x = barrett_reduce128(x.lo, x.hi, br);
+        r.y = barrett_reduce128(y.lo, y.hi, br);
+        reinterpret_cast<u64x2*>(d.out[g])[oc] = r;
     }
 }
 
@@ -352,9 +349,9 @@ void launch_ew_dot(const DeviceTables& t, u64* out, const EwItems& it, int limb_
 void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& d, hipStream_t s) {
     if (d.na <= 0 || d.ng <= 0 || d.ell <= 0) return;
     if (d.na <= 8)
-        hipLaunchKernelGGL((ew_dot_groups_kernel<8>), grid2(t.log_n, d.ell), dim3(256), 0, s, t, d);
+        hipLaunchKernelGGL((ew_dot_groups_kernel<8>), grid2(t.log_n, 2 * d.ell), dim3(256), 0, s, t, d);
     else
-        hipLaunchKernelGGL((ew_dot_groups_kernel<16>), grid2(t.log_n, d.ell), dim3(256), 0, s, t, d);
+        hipLaunchKernelGGL((ew_dot_groups_kernel<16>), grid2(t.log_n, 2 * d.ell), dim3(256), 0, s, t, d);
 }
 void launch_ew_mul(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s) {
     if (nvec <= 0) return;
