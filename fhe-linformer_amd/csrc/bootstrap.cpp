@@ -174,6 +174,7 @@ void Bootstrapper::setup(int budget_enc, int budget_dec, int slots) {
     const int gapN = (c.N / 2) / n;
     packed_ = gapN >= 2;
     if (const char* e = std::getenv("FHELIN_BOOT_PACKED")) packed_ = packed_ && std::atoi(e) != 0;
+    if (const char* e = std::getenv("FHELIN_BOOT_STAGES_LEGACY")) stage_order_legacy_ = std::atoi(e) != 0;
     const double q0 = (double)c.chain.q[0];
     // CoeffsToSlots: inverse-FFT stages (len = n .. 2), total constant Delta_r / (gapN q0 K 2n) spread over the levels
     auto build = [&](bool inverse, int budget, double total_factor, std::vector<LinStage>& out) {
@@ -183,7 +184,11 @@ void Bootstrapper::setup(int budget_enc, int budget_dec, int slots) {
         const double f = std::pow(total_factor, 1.0 / budget);
         size_t pos = 0;
         for (int g = 0; g < budget; ++g) {
-            int cnt = logn / budget + (g < logn % budget ? 1 : 0);
+            // radix levels per stage: the remainder goes to the LATER stages.  The first CoeffsToSlots stage runs at the top of
+            // the chain (the dearest key switches) and the first SlotsToCoeffs stage has its diagonals doubled under sparse
+            // packing: both should be the small ones (14 levels, budget 3: 4 + 5 + 5 rather than 5 + 5 + 4)
+            int cnt = logn / budget + (budget - 1 - g < logn % budget ? 1 : 0);
+            if (stage_order_legacy_) cnt = logn / budget + (g < logn % budget ? 1 : 0);
             DiagMap m = stage_map(n, lens[pos], inverse, rot, ksi);
             for (int i = 1; i < cnt; ++i) m = compose(stage_map(n, lens[pos + i], inverse, rot, ksi), m, n);
             pos += cnt;

@@ -50,6 +50,7 @@ private:
     Evaluator& ev_;
     Client& cl_;
     int slots_ = 0;
+    bool stage_order_legacy_ = false;   // FHELIN_BOOT_STAGES_LEGACY=1: larger stages first (round-1 split 5+5+4)
     bool packed_ = false;   // sparse packing: real and imaginary halves share one ciphertext through EvalMod (bootstrap.cpp)
     int depth_ = 0;
     std::vector<LinStage> c2s_, s2c_;

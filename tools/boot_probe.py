@@ -12,7 +12,8 @@ if len(sys.argv) > 3:
     kw["n_p"] = int(sys.argv[3])
 e = fa.Engine(preset, seed=5, **kw)
 t0 = time.time(); e.keygen(); e.gen_relin_key(); print("keygen s", round(time.time() - t0, 2))
-t0 = time.time(); e.bootstrap_setup(3, 3, 1 << e.params.log_slots); print("setup s", round(time.time() - t0, 2))
+t0 = time.time(); _bud = [int(v) for v in os.environ.get("BOOT_BUDGET", "3,3").split(",")]
+t0 = time.time(); e.bootstrap_setup(_bud[0], _bud[1], 1 << e.params.log_slots); print("setup s", round(time.time() - t0, 2))
 n = 1 << e.params.log_slots
 m = np.random.default_rng(1).uniform(-1, 1, n)
 ct = e.encrypt(m, level=e.n_q - 3)
