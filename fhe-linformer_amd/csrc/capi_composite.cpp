@@ -25,6 +25,7 @@ static void emit_lazy(fhelin_ctx* c, const std::shared_ptr<LazyRows>& g, int n, 
         h->owner = c;
         if (c->plan.mode == 1) {
             h->node = c->plan.add_node(plan_inputs(), -1);   // level known once the row is evaluated (force_rows)
+            h->node_epoch = g->node_epoch = c->plan.epoch;
             g->node.push_back(h->node);
         }
         outs[i] = h;
@@ -47,7 +48,7 @@ void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx) {
     }
     for (size_t k = 0; k < todo.size(); ++k) {
         g.done[todo[k]] = r[k];
-        if (c->plan.mode == 1 && !g.node.empty()) c->plan.nodes[g.node[todo[k]]].eff = LevelPlan::eff_of(*r[k]);
+        if (!g.node.empty() && c->plan.live(g.node[todo[k]], g.node_epoch)) c->plan.nodes[g.node[todo[k]]].eff = LevelPlan::eff_of(*r[k]);
     }
     bool all = true;
     for (const CtPtr& d : g.done) all = all && d;
@@ -340,9 +341,9 @@ int fhelin_bootstrap(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     FHELIN_TRY
     // a bootstrap is a terminal for its input (two limbs are all it reads) and a source of the level plan for its output
     const int drop = c->plan.next_drop(c->boot.out_ell());
-    if (a->node >= 0) c->plan.terminal(a->node, 2);
+    if (c->plan.live(a->node, a->node_epoch)) c->plan.terminal(a->node, 2);
     *out = wrap(c, run_heavy(c, a, [&](const CtPtr& in) { return c->boot.bootstrap(in, drop); }));
-    if ((*out)->node >= 0) {
+    if (c->plan.live((*out)->node, (*out)->node_epoch)) {
         LevelPlan::Node& nd = c->plan.nodes[(*out)->node];
         nd.in.clear();
         nd.ordinal = c->plan.next_ordinal - 1;

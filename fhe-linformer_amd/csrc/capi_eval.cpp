@@ -104,7 +104,7 @@ int fhelin_encrypt(fhelin_ctx* c, const fhelin_pt* p, fhelin_ct** out) {
     NEED(c && p && out);
     FHELIN_TRY
     *out = wrap(c, c->cl.encrypt(p->p, c->plan.next_drop(c->ctx.L + 1 - p->p->level)));
-    if ((*out)->node >= 0) c->plan.nodes[(*out)->node].ordinal = c->plan.next_ordinal - 1;
+    if (c->plan.live((*out)->node, (*out)->node_epoch)) c->plan.nodes[(*out)->node].ordinal = c->plan.next_ordinal - 1;
     FHELIN_CATCH
 }
 int fhelin_encrypt_batch(fhelin_ctx* c, const double* vals, int32_t n_vec, int32_t n_per, int32_t level, int32_t slots, fhelin_ct** outs) {
@@ -137,7 +137,7 @@ int fhelin_encrypt_batch(fhelin_ctx* c, const double* vals, int32_t n_vec, int32
     }
     for (int i = 0; i < n_vec; ++i) {
         outs[i] = wrap(c, r[i]);
-        if (outs[i]->node >= 0) c->plan.nodes[outs[i]->node].ordinal = first_ordinal + i;
+        if (c->plan.live(outs[i]->node, outs[i]->node_epoch)) c->plan.nodes[outs[i]->node].ordinal = first_ordinal + i;
     }
     FHELIN_CATCH
 }
@@ -157,7 +157,7 @@ int fhelin_debug_sample(fhelin_ctx* c, int32_t kind, int32_t n_poly, int64_t* ou
 int fhelin_decrypt(fhelin_ctx* c, const fhelin_ct* ct, double* out, int32_t slots) {
     NEED(c && ct && out);
     FHELIN_TRY
-    c->plan.terminal(ct->node, 2);
+    if (c->plan.live(ct->node, ct->node_epoch)) c->plan.terminal(ct->node, 2);
     c->plan.check_terminal(*ct_in(c, ct), 2);
     auto v = c->cl.decrypt(ct_in(c, ct), slots);
     std::memcpy(out, v.data(), v.size() * sizeof(double));
@@ -176,7 +176,7 @@ int fhelin_ct_import(fhelin_ctx* c, const uint64_t* limbs, int32_t npoly, int32_
 int fhelin_ct_export(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* out, size_t cap) {
     NEED(c && ct && out);
     FHELIN_TRY
-    c->plan.terminal(ct->node, 2);
+    if (c->plan.live(ct->node, ct->node_epoch)) c->plan.terminal(ct->node, 2);
     const CtPtr& p = ct_in(c, ct);
     c->plan.check_terminal(*p, 2);
     if (cap < p->words()) throw Error(FHELIN_ERR_ARG, "buffer too small");
@@ -187,7 +187,7 @@ int fhelin_ct_export(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* out, size_t c
 int fhelin_ct_export_device(fhelin_ctx* c, const fhelin_ct* ct, uint64_t* d_out, size_t cap) {
     NEED(c && ct && d_out);
     FHELIN_TRY
-    c->plan.terminal(ct->node, 2);
+    if (c->plan.live(ct->node, ct->node_epoch)) c->plan.terminal(ct->node, 2);
     const CtPtr& p = ct_in(c, ct);
     c->plan.check_terminal(*p, 2);
     if (cap < p->words()) throw Error(FHELIN_ERR_ARG, "buffer too small");

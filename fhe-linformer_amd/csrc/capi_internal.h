@@ -26,6 +26,7 @@ struct LevelPlan {
         int need = -1;      // fewest effective limbs any consumer chain requires (-1: reaches no terminal)
     };
     std::vector<Node> nodes;
+    int epoch = 0;              // recordings are numbered: a handle's node id only means something in the recording that made it
     int next_ordinal = 0;
     std::vector<int> target;    // the plan, per source ordinal: effective limbs the source should start with (-1: as asked)
 
@@ -52,7 +53,9 @@ struct LevelPlan {
         mode = m;
         next_ordinal = 0;
         nodes.clear();
+        ++epoch;
     }
+    bool live(int node, int node_epoch) const { return mode == 1 && node >= 0 && node_epoch == epoch && node < (int)nodes.size(); }
     void finish();  // record mode: derive `target` from the recording (capi.cpp)
 };
 // handles read by the C-ABI call in progress on this thread (node ids of the recording context)
@@ -87,7 +90,8 @@ struct LazyRows {
     int n = 0;
     std::vector<CtPtr> done;    // per row: null until evaluated
     int partial_reads = 0;      // reads so far that asked for only some of the rows (force_group)
-    std::vector<int> node;      // level-plan recording: the rows' node ids
+    std::vector<int> node;      // level-plan recording: the rows' node ids ...
+    int node_epoch = -1;        // ... of this recording (LevelPlan::epoch)
 };
 }
 struct fhelin_ct {
@@ -95,7 +99,8 @@ struct fhelin_ct {
     mutable std::shared_ptr<fhelin::LazyRows> lazy;
     int lazy_idx = 0;
     fhelin_ctx* owner = nullptr;
-    int node = -1;                                    // level-plan recording: this value's node
+    int node = -1;                                    // level-plan recording: this value's node ...
+    int node_epoch = -1;                              // ... in this recording (a handle may outlive the pass that made it)
 };
 struct fhelin_pt {
     fhelin::PtPtr p;
@@ -122,13 +127,16 @@ void force_many(fhelin_ctx* c, const fhelin_ct* const* v, int n);
 // The main stream is about to consume `h`: if a worker lane is still producing it, order the main stream behind the
 // producing op (no host wait) and drop the holds that op needed.
 inline void note_input(fhelin_ctx* c, const fhelin_ct* h) {
-    if (c->plan.mode == 1 && h->node >= 0) plan_inputs().push_back(h->node);
+    if (c->plan.live(h->node, h->node_epoch)) plan_inputs().push_back(h->node);
 }
 // a new handle for a result of the call in progress
 inline fhelin_ct* wrap(fhelin_ctx* c, const CtPtr& p) {
     auto* h = new fhelin_ct;
     h->p = p;
-    if (c->plan.mode == 1) h->node = c->plan.add_node(plan_inputs(), LevelPlan::eff_of(*p));
+    if (c->plan.mode == 1) {
+        h->node = c->plan.add_node(plan_inputs(), LevelPlan::eff_of(*p));
+        h->node_epoch = c->plan.epoch;
+    }
     return h;
 }
 inline const CtPtr& ct_in(fhelin_ctx* c, const fhelin_ct* h) {

@@ -136,3 +136,33 @@ def test_bootstrap_to_fewer_limbs_keeps_its_precision(fa):
         assert np.max(np.abs(eng.decrypt(sq) - m * m)) < 1e-3
     finally:
         eng.close()
+
+
+def test_handles_from_an_earlier_recording_are_plain_inputs_of_a_later_one(fa):
+    """a handle may outlive the recording pass that made it (a driver keeping a ciphertext between passes, deferred rows
+    forced later): in a later recording it is an input with no history, not an index into a recording that is gone"""
+    eng = fa.Engine("toy13", seed=9)
+    try:
+        eng.keygen()
+        eng.gen_relin_key()
+        eng.gen_rotation_keys(fa.circuit_rotation_indices())
+        rng = np.random.default_rng(6)
+        n = 1 << eng.params.log_slots
+        x, y = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        w = eng.encode(rng.uniform(-1, 1, n))
+        eng.level_plan_begin("record")
+        old = eng.encrypt(x)                                    # node 0 of the first recording
+        for _ in range(40):                                     # ... which grows far beyond the second one
+            old2 = eng.add(old, old)
+        lazy = eng.matmulRE(eng.encrypt_batch(rng.uniform(-1, 1, (3, n))), w, None)   # deferred rows, not forced yet
+        eng.level_plan_end()
+        eng.level_plan_begin("record")
+        b = eng.encrypt(y)                                      # source 0 of THIS recording
+        c = eng.mult(old2, b)                                   # old2: a stale node id (41) in a recording of 2 nodes
+        got = eng.decrypt(c)
+        eng.decrypt(lazy[1])                                    # rows recorded in the first pass are forced in the second
+        plan = eng.level_plan_end()
+        assert np.max(np.abs(got - 2 * x * y)) < 1e-6
+        assert plan == [3]                                      # mult (1 level) + decrypt (2 limbs); `old2` puts no constraint
+    finally:
+        eng.close()
