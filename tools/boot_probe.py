@@ -10,7 +10,7 @@ if len(sys.argv) > 2:
     kw["n_q"] = int(sys.argv[2])
 if len(sys.argv) > 3:
     kw["n_p"] = int(sys.argv[3])
-e = fa.Engine(preset, seed=5, **kw)
+e = fa.Engine(preset, seed=int(os.environ.get("BOOT_SEED", "5")), **kw)
 t0 = time.time(); e.keygen(); e.gen_relin_key(); print("keygen s", round(time.time() - t0, 2))
 t0 = time.time(); _bud = [int(v) for v in os.environ.get("BOOT_BUDGET", "3,3").split(",")]
 t0 = time.time(); e.bootstrap_setup(_bud[0], _bud[1], 1 << e.params.log_slots); print("setup s", round(time.time() - t0, 2))
