@@ -1062,18 +1062,49 @@ CtPtr Evaluator::level_reduce(const CtPtr& a, int new_ell) {
     return o;
 }
 
-CtPtr Evaluator::mult_int(const CtPtr& a, u64 k, bool raise_deg, long double new_scale) {
+CtPtr Evaluator::mult_int(const CtPtr& a, u64 k, bool raise_deg, long double new_scale, int keep_ell) {
+    // keep_ell > 0: the product on the first keep_ell limbs only (== level_reduce(mult_int(a), keep_ell), without touching the
+    // limbs that would be dropped)
+    const int ell = keep_ell > 0 ? std::min(keep_ell, a->ell) : a->ell;
     ScalarSet sc;
-    for (int i = 0; i < a->ell; ++i) {
+    for (int i = 0; i < ell; ++i) {
         u64 q = c_.chain.q[i];
         u64 v = k % q;
         sc.v[2 * i] = v;
         sc.v[2 * i + 1] = h_shoup(v, q);
     }
-    CtPtr o = new_ct(a->npoly, a->ell, raise_deg ? a->deg + 1 : a->deg, new_scale, a->slots);
-    launch_ew_scalar(c_.dt, o->d, a->d, sc, a->npoly * a->ell, 0, a->ell, c_.stream);
+    CtPtr o = new_ct(a->npoly, ell, raise_deg ? a->deg + 1 : a->deg, new_scale, a->slots);
+    launch_ew_scalar(c_.dt, o->d, a->d, sc, a->npoly * ell, 0, ell, c_.stream, ell < a->ell ? a->ell : 0);
     launch_ok("mult_int");
     return o;
+}
+
+// FLEXIBLEAUTO level adjustment of several degree-1 ciphertexts to ONE (limb count, scale): integer scalar x, the limbs above
+// ell + 1 left out, and ONE batched rescale for all of them.  Same residues as adjust() one by one.
+std::vector<CtPtr> Evaluator::adjust_deg1_batch(const std::vector<CtPtr>& v, int ell, long double scale) {
+    std::vector<CtPtr> out(v.size()), pending;
+    std::vector<size_t> pos;
+    for (size_t i = 0; i < v.size(); ++i) {
+        CtPtr cur = v[i];
+        if (cur->ell < ell) throw Error(FHELIN_ERR_STATE, "adjust: cannot raise a ciphertext to a lower level");
+        if (cur->deg == 2) cur = rescale(cur);
+        if (cur->ell == ell) {
+            out[i] = cur;
+            continue;
+        }
+        const long double qdrop = (long double)c_.chain.q[ell];
+        const u64 k = (u64)llroundl(scale * qdrop / cur->scale);
+        pending.push_back(mult_int(cur, k, true, cur->scale * (long double)k, ell + 1));
+        pos.push_back(i);
+    }
+    if (!pending.empty()) {
+        std::vector<CtPtr> r = rescale_batch(pending);
+        for (size_t k = 0; k < pos.size(); ++k) {
+            r[k]->scale = scale;
+            out[pos[k]] = r[k];
+        }
+    }
+    return out;
 }
 
 CtPtr Evaluator::adjust(const CtPtr& a, int ell, int deg, long double scale) {
@@ -1092,8 +1123,7 @@ CtPtr Evaluator::adjust(const CtPtr& a, int ell, int deg, long double scale) {
         if (cur->ell == ell) return cur;
         const long double qdrop = (long double)c_.chain.q[ell];
         u64 k = (u64)llroundl(scale * qdrop / cur->scale);
-        cur = mult_int(cur, k, true, cur->scale * (long double)k);
-        cur = level_reduce(cur, ell + 1);
+        cur = mult_int(cur, k, true, cur->scale * (long double)k, ell + 1);   // only the limbs the rescale reads
         cur = rescale(cur);
         cur->scale = scale;
         return cur;

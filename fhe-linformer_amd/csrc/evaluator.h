@@ -165,7 +165,8 @@ public:
     CtPtr mult(const CtPtr& a, const CtPtr& b);             // tensor + relinearise (auto-rescale inputs of deg 2)
     CtPtr mult_no_relin(const CtPtr& a, const CtPtr& b);    // 3-component result
     CtPtr relinearize(const CtPtr& a);
-    CtPtr mult_int(const CtPtr& a, u64 k, bool raise_deg, long double new_scale);  // by an integer constant
+    CtPtr mult_int(const CtPtr& a, u64 k, bool raise_deg, long double new_scale, int keep_ell = 0);
+    std::vector<CtPtr> adjust_deg1_batch(const std::vector<CtPtr>& v, int ell, long double scale);  // by an integer constant
     CtPtr mult_real(const CtPtr& a, double c);              // by a real constant: per-limb scalar round(c * Delta_level)
     CtPtr add_real(const CtPtr& a, double c);               // add a real constant to every slot
     // sum_k coef[k] * terms[k] + c0 for ciphertexts of identical (level, degree 1, scale): the residues of the chain

@@ -16,7 +16,8 @@ void launch_ew_sub(const DeviceTables& t, u64* out, const u64* a, const u64* b, 
 void launch_ew_muladd(const DeviceTables& t, u64* out, const u64* acc, const u64* a, const u64* b, int nvec, int b_mod, int limb_first,
                       int limb_count, hipStream_t s);
 void launch_ew_neg(const DeviceTables& t, u64* out, const u64* a, int nvec, int limb_first, int limb_count, hipStream_t s);
-void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s);
+void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s,
+                      int in_limbs = 0);   // in_limbs > 0: inputs have in_limbs limbs per polynomial, the first limb_count are used
 void launch_ew_addscalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s);
 // out[v] = sum_k a_k[v] * scal[k][limb] + scal[n][limb]  (limb = v % ell): a linear combination with real constants of up to
 // MAX_TERMS ciphertexts of identical shape in ONE pass — the base case of a Chebyshev / power-basis evaluation, which as

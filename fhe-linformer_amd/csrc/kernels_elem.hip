@@ -162,15 +162,18 @@ __global__ __launch_bounds__(256) void ew_neg_kernel(DeviceTables t, u64* out, c
 }
 
 // out[v] = a[v] * s[limb]   (s given with Shoup companion: sc[2*i], sc[2*i+1] for i = v % limb_count)
+// in_limbs > 0: the input polynomials have in_limbs limbs each and only their first limb_count are read (a product that is
+// level-reduced at once: the limbs nobody will read are neither multiplied nor copied)
 __global__ __launch_bounds__(256) void ew_scalar_kernel(DeviceTables t, u64* out, const u64* a, ScalarSet sc, int limb_first,
-                                                        int limb_count) {
+                                                        int limb_count, int in_limbs) {
     const int v = blockIdx.y;
     const int li = v % limb_count;
     const u64 q = t.moduli[limb_first + li];
     const u64 w = sc.v[2 * li], ws = sc.v[2 * li + 1];
     const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t row = ((size_t)1 << t.log_n) >> 1;
-    const u64x2 x = reinterpret_cast<const u64x2*>(a)[(size_t)v * row + n2];
+    const size_t vin = in_limbs > 0 ? (size_t)(v / limb_count) * in_limbs + li : (size_t)v;
+    const u64x2 x = reinterpret_cast<const u64x2*>(a)[vin * row + n2];
     u64x2 r;
     r.x = mul_shoup(x.x, w, ws, q);
     r.y = mul_shoup(x.y, w, ws, q);
@@ -374,9 +377,10 @@ void launch_ew_neg(const DeviceTables& t, u64* out, const u64* a, int nvec, int 
     if (nvec <= 0) return;
     hipLaunchKernelGGL(ew_neg_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, limb_first, limb_count);
 }
-void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s) {
+void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s,
+                      int in_limbs) {
     if (nvec <= 0) return;
-    hipLaunchKernelGGL(ew_scalar_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, sc, limb_first, limb_count);
+    hipLaunchKernelGGL(ew_scalar_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, sc, limb_first, limb_count, in_limbs);
 }
 void launch_ew_addscalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s) {
     if (nvec <= 0) return;

@@ -120,7 +120,9 @@ static void align_deg1(Evaluator& ev, std::vector<CtPtr>& v, int from) {
         ell = std::min(ell, v[i]->ell);
     }
     const long double sf = ev.ctx().sf_real[ev.ctx().L + 1 - ell];
-    for (size_t i = from; i < v.size(); ++i) v[i] = ev.adjust(v[i], ell, 1, sf);
+    // all the powers that sit above the common level go down together: one batched rescale (Evaluator::adjust_deg1_batch)
+    std::vector<CtPtr> r = ev.adjust_deg1_batch(std::vector<CtPtr>(v.begin() + from, v.end()), ell, sf);
+    for (size_t i = from; i < v.size(); ++i) v[i] = r[i - from];
 }
 
 CtPtr Evaluator::eval_poly(const CtPtr& x, const std::vector<double>& coeffs) {
