@@ -1130,8 +1130,7 @@ CtPtr Evaluator::adjust(const CtPtr& a, int ell, int deg, long double scale) {
     }
     if (cur->deg == 2) cur = rescale(cur);
     u64 k = (u64)llroundl(scale / cur->scale);
-    cur = mult_int(cur, k, true, scale);
-    return level_reduce(cur, ell);
+    return mult_int(cur, k, true, scale, ell);   // the product on the limbs that are kept only
 }
 
 void Evaluator::match(const CtPtr& a, const CtPtr& b, CtPtr& ao, CtPtr& bo) {

@@ -87,6 +87,7 @@ public:
     static u64* contiguous_base(const std::vector<CtPtr>& v);
     std::vector<CtPtr> make_contiguous(const std::vector<CtPtr>& v);
     bool dot_groups = true;    // inner sums of all giant steps of a linear stage in one pass (dot_plain_groups); FHELIN_DOT_GROUPS=0: one pass each
+    bool cheb_leaf_at_product = true;   // r-leaves of the Paterson-Stockmeyer tree born at their product's (limbs, scale); FHELIN_CHEB_LEAF_AT=0: level-adjusted afterwards
     bool cheb_rounds = true;   // Paterson-Stockmeyer products in rounds (polyeval.cpp cheb_recurse); FHELIN_CHEB_ROUNDS=0: one at a time
     int batch_limit = 16;   // rows processed per batched key switch (FHELIN_BATCH overrides; 8 / 16 / 24 / 32 measured: DESIGN.md)
     CtPtr clone(const CtPtr& a);
@@ -173,6 +174,7 @@ public:
     // add(mult_real(t_1, c_1), mult_real(t_2, c_2), ...) + add_real(c0), in one kernel pass (falls back to that chain when
     // the shapes differ).  Terms with coef 0 are skipped.
     CtPtr lincomb(const std::vector<CtPtr>& terms, const std::vector<double>& coef, double c0);
+    CtPtr lincomb_at(const std::vector<CtPtr>& terms, const std::vector<double>& coef, double c0, long double want_scale, int keep_ell);
     CtPtr rotate(const CtPtr& a, int index);
     CtPtr conjugate(const CtPtr& a);
     // polynomial evaluation (EvalPoly :1291, EvalMultMany :1297, EvalChebyshevFunction :1319-1335)

@@ -198,16 +198,18 @@ __global__ __launch_bounds__(256) void ew_addscalar_kernel(DeviceTables t, u64* 
 
 // out[v] = sum_k a_k[v] * s_k[limb] + s_n[limb]; grid (N/512, vecs).  The products are summed in 128 bits and reduced once:
 // the canonical residue of the sum, whatever the order (32 q^2 < q 2^64 for the Q limbs, q < 2^59).
-__global__ __launch_bounds__(256) void ew_lincomb_kernel(DeviceTables t, u64* out, LinComb lc, const u64* __restrict__ scal, int ell) {
+__global__ __launch_bounds__(256) void ew_lincomb_kernel(DeviceTables t, u64* out, LinComb lc, const u64* __restrict__ scal, int ell,
+                                                         int in_limbs) {
     const int v = blockIdx.y;
     const int l = v % ell;
     const Barrett br = load_barrett(t, l);
     const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const size_t vin = in_limbs > 0 ? (size_t)(v / ell) * in_limbs + l : (size_t)v;   // inputs with more limbs: the first ell are read
     Acc128 ax = {0, 0}, ay = {0, 0};
     for (int k = 0; k < lc.n; ++k) {
         const u64 sk = scal[(size_t)k * ell + l];
-        const u64x2 x = reinterpret_cast<const u64x2*>(lc.a[k])[(size_t)v * row + n2];
+        const u64x2 x = reinterpret_cast<const u64x2*>(lc.a[k])[vin * row + n2];
         acc_mac(ax, x.x, sk);
         acc_mac(ay, x.y, sk);
     }
@@ -386,9 +388,9 @@ void launch_ew_addscalar(const DeviceTables& t, u64* out, const u64* a, const Sc
     if (nvec <= 0) return;
     hipLaunchKernelGGL(ew_addscalar_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, sc, limb_first, limb_count);
 }
-void launch_ew_lincomb(const DeviceTables& t, u64* out, const LinComb& lc, const u64* scal, int ell, hipStream_t s) {
+void launch_ew_lincomb(const DeviceTables& t, u64* out, const LinComb& lc, const u64* scal, int ell, hipStream_t s, int in_limbs) {
     if (lc.n <= 0 || lc.vecs <= 0) return;
-    hipLaunchKernelGGL(ew_lincomb_kernel, grid2(t.log_n, lc.vecs), dim3(256), 0, s, t, out, lc, scal, ell);
+    hipLaunchKernelGGL(ew_lincomb_kernel, grid2(t.log_n, lc.vecs), dim3(256), 0, s, t, out, lc, scal, ell, in_limbs);
 }
 void launch_tensor(const DeviceTables& t, u64* d, const u64* a, const u64* b, int ell, hipStream_t s) {
     hipLaunchKernelGGL(tensor_kernel, grid2(t.log_n, ell), dim3(256), 0, s, t, d, a, b, ell);

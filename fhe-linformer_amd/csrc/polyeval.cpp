@@ -44,6 +44,14 @@ CtPtr Evaluator::add_real(const CtPtr& a, double cst) {
 }
 
 CtPtr Evaluator::lincomb(const std::vector<CtPtr>& terms_in, const std::vector<double>& coef_in, double c0) {
+    return lincomb_at(terms_in, coef_in, c0, 0, 0);
+}
+
+// out_scale > 0: the coefficients are scaled so that the result has exactly this scale (instead of the level's own factor),
+// keep_ell > 0: on the first keep_ell limbs only.  A summand that is going to be added to a product of known (limbs, scale) is
+// born there and needs no level adjustment (scalar multiply + rescale) afterwards.  Null if the operands do not fit the kernel.
+CtPtr Evaluator::lincomb_at(const std::vector<CtPtr>& terms_in, const std::vector<double>& coef_in, double c0, long double want_scale,
+                            int keep_ell) {
     std::vector<CtPtr> terms;
     std::vector<double> coef;
     for (size_t i = 0; i < terms_in.size(); ++i)
@@ -57,6 +65,7 @@ CtPtr Evaluator::lincomb(const std::vector<CtPtr>& terms_in, const std::vector<d
         uniform = uniform && t->deg == 1 && t->npoly == terms[0]->npoly && t->ell == terms[0]->ell &&
                   fabsl(t->scale / terms[0]->scale - 1.0L) < 1e-9L;
     if (!uniform) {  // the chain of single operations (also the definition of the result)
+        if (want_scale > 0 || keep_ell > 0) return CtPtr();
         CtPtr acc;
         for (size_t i = 0; i < terms.size(); ++i) {
             CtPtr t = mult_real(terms[i], coef[i]);
@@ -65,8 +74,8 @@ CtPtr Evaluator::lincomb(const std::vector<CtPtr>& terms_in, const std::vector<d
         return c0 != 0.0 ? add_real(acc, c0) : acc;
     }
     const CtPtr& x = terms[0];
-    const int ell = x->ell, n = (int)terms.size();
-    const long double sf = c_.sf_real[x->level()];
+    const int ell = keep_ell > 0 ? std::min(keep_ell, x->ell) : x->ell, n = (int)terms.size();
+    const long double sf = want_scale > 0 ? want_scale / x->scale : c_.sf_real[x->level()];
     const long double out_scale = x->scale * sf;
     std::vector<u64> sc((size_t)(n + 1) * ell, 0);
     ScalarSet one;
@@ -85,7 +94,7 @@ CtPtr Evaluator::lincomb(const std::vector<CtPtr>& terms_in, const std::vector<d
     lc.vecs = x->npoly * ell;
     for (int k = 0; k < n; ++k) lc.a[k] = terms[k]->d;
     CtPtr o = new_ct(x->npoly, ell, 2, out_scale, x->slots);
-    launch_ew_lincomb(c_.dt, o->d, lc, dsc, ell, c_.stream);
+    launch_ew_lincomb(c_.dt, o->d, lc, dsc, ell, c_.stream, ell < x->ell ? x->ell : 0);
     hip_check(hipGetLastError(), "lincomb");
     c_.pool.free(dsc);
     return o;
@@ -193,9 +202,24 @@ Evaluator::CtRow Evaluator::cheb_recurse(const std::vector<double>& c, const std
     const size_t rows = T[1].size();
     std::vector<ChebNode> nodes;
     const int root = cheb_build(nodes, c, baby);
+    // a leaf that is the r of p = q T_m + r is only ever ADDED to the product q T_m: it is evaluated when that product is known,
+    // with its coefficients scaled so that it is born with the product's limbs and scale (no level adjustment = no rescale)
+    std::vector<char> is_r_leaf(nodes.size(), 0);
+    for (const ChebNode& nd : nodes)
+        if (nd.m && nd.r >= 0 && !nodes[nd.r].m) {
+            bool any = false;
+            for (size_t k = 1; k < nodes[nd.r].c.size(); ++k) any = any || nodes[nd.r].c[k] != 0.0;
+            is_r_leaf[nd.r] = any && cheb_leaf_at_product ? 1 : 0;
+        }
+    auto leaf_terms = [&](const ChebNode& nd, size_t i) {
+        std::vector<CtPtr> terms;
+        for (size_t k = 1; k < nd.c.size(); ++k) terms.push_back(T[k][i]);
+        return terms;
+    };
     // leaves: sum_k c_k T_k + c_0 in one pass per input (the babies share one level: align_deg1)
-    for (ChebNode& nd : nodes) {
-        if (nd.m) continue;
+    for (size_t id = 0; id < nodes.size(); ++id) {
+        ChebNode& nd = nodes[id];
+        if (nd.m || is_r_leaf[id]) continue;
         const int n = (int)nd.c.size() - 1;
         bool any = false;
         for (int k = 1; k <= n; ++k) any = any || nd.c[k] != 0.0;
@@ -240,6 +264,17 @@ Evaluator::CtRow Evaluator::cheb_recurse(const std::vector<double>& c, const std
             moved = false;
             for (ChebNode& nd : nodes) {
                 if (nd.done || !nd.has_prod) continue;
+                if (nd.r >= 0 && is_r_leaf[nd.r] && !nodes[nd.r].done) {
+                    ChebNode& lf = nodes[nd.r];
+                    const std::vector<double> cf(lf.c.begin() + 1, lf.c.end());
+                    lf.val.resize(rows);
+                    for (size_t i = 0; i < rows; ++i) {
+                        const CtPtr& pr = nd.prod[i];
+                        CtPtr v = pr->deg == 2 ? lincomb_at(leaf_terms(lf, i), cf, lf.c[0], pr->scale, pr->ell) : CtPtr();
+                        lf.val[i] = v ? v : lincomb(leaf_terms(lf, i), cf, lf.c[0]);
+                    }
+                    lf.done = true;
+                }
                 if (nd.r >= 0 && !nodes[nd.r].done) continue;
                 nd.val = nd.r >= 0 ? add_batch(nd.prod, nodes[nd.r].val) : nd.prod;
                 if (nd.r >= 0) nodes[nd.r].val.clear();
