@@ -1179,8 +1179,16 @@ CtPtr Evaluator::negate(const CtPtr& a) {
 
 CtPtr Evaluator::add_plain(const CtPtr& a, const PtPtr& p) {
     auto enc = p->at(a->ell, a->scale);
-    CtPtr o = clone(a);
-    launch_ew_add(c_.dt, o->d, a->d, enc->d, a->ell, a->ell, 0, a->ell, c_.stream);
+    // one pass (op 3 of ew_items: add on component 0, copy the others) instead of a copy of the ciphertext + an add
+    CtPtr o = new_ct(a->npoly, a->ell, a->deg, a->scale, a->slots);
+    EwItems it;
+    it.n = 1;
+    it.vecs = a->npoly * a->ell;
+    it.b_vecs = a->ell;
+    it.out[0] = o->d;
+    it.a[0] = a->d;
+    it.b[0] = enc->d;
+    launch_ew_items(c_.dt, it, 3, a->ell, c_.stream);
     launch_ok("add_plain");
     return o;
 }

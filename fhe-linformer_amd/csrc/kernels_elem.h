@@ -18,7 +18,8 @@ void launch_ew_muladd(const DeviceTables& t, u64* out, const u64* acc, const u64
 void launch_ew_neg(const DeviceTables& t, u64* out, const u64* a, int nvec, int limb_first, int limb_count, hipStream_t s);
 void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s,
                       int in_limbs = 0);   // in_limbs > 0: inputs have in_limbs limbs per polynomial, the first limb_count are used
-void launch_ew_addscalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s);
+void launch_ew_addscalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s,
+                         int add_vecs = -1);   // add_vecs >= 0: the constant goes to the first add_vecs vectors, the rest are copied
 // out[v] = sum_k a_k[v] * scal[k][limb] + scal[n][limb]  (limb = v % ell): a linear combination with real constants of up to
 // MAX_TERMS ciphertexts of identical shape in ONE pass — the base case of a Chebyshev / power-basis evaluation, which as
 // single ops is one scalar-multiply launch and one add launch per term.  scal: device array [(n + 1)][ell] of residues.

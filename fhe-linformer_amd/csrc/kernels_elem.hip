@@ -181,12 +181,13 @@ __global__ __launch_bounds__(256) void ew_scalar_kernel(DeviceTables t, u64* out
 }
 
 // out[v] = a[v] + s[limb]   (adds a constant to every NTT slot == adds the constant polynomial)
+// add_vecs: only the first add_vecs vectors (component 0 of a ciphertext) get the constant, the others are copied through
 __global__ __launch_bounds__(256) void ew_addscalar_kernel(DeviceTables t, u64* out, const u64* a, ScalarSet sc, int limb_first,
-                                                           int limb_count) {
+                                                           int limb_count, int add_vecs) {
     const int v = blockIdx.y;
     const int li = v % limb_count;
     const u64 q = t.moduli[limb_first + li];
-    const u64 w = sc.v[2 * li];
+    const u64 w = v < add_vecs ? sc.v[2 * li] : 0;
     const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t row = ((size_t)1 << t.log_n) >> 1;
     const u64x2 x = reinterpret_cast<const u64x2*>(a)[(size_t)v * row + n2];
@@ -384,9 +385,10 @@ void launch_ew_scalar(const DeviceTables& t, u64* out, const u64* a, const Scala
     if (nvec <= 0) return;
     hipLaunchKernelGGL(ew_scalar_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, sc, limb_first, limb_count, in_limbs);
 }
-void launch_ew_addscalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s) {
+void launch_ew_addscalar(const DeviceTables& t, u64* out, const u64* a, const ScalarSet& sc, int nvec, int limb_first, int limb_count, hipStream_t s,
+                         int add_vecs) {
     if (nvec <= 0) return;
-    hipLaunchKernelGGL(ew_addscalar_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, sc, limb_first, limb_count);
+    hipLaunchKernelGGL(ew_addscalar_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, a, sc, limb_first, limb_count, add_vecs < 0 ? nvec : add_vecs);
 }
 void launch_ew_lincomb(const DeviceTables& t, u64* out, const LinComb& lc, const u64* scal, int ell, hipStream_t s, int in_limbs) {
     if (lc.n <= 0 || lc.vecs <= 0) return;

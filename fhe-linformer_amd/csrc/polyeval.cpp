@@ -37,8 +37,9 @@ CtPtr Evaluator::mult_real(const CtPtr& a, double cst) {
 CtPtr Evaluator::add_real(const CtPtr& a, double cst) {
     ScalarSet sc;
     real_to_scalars(c_, (long double)cst * a->scale, a->ell, sc);
-    CtPtr o = clone(a);
-    launch_ew_addscalar(c_.dt, o->d, a->d, sc, a->ell, 0, a->ell, c_.stream);
+    // one pass: component 0 gets the constant, the other components are copied through (no separate copy of the ciphertext)
+    CtPtr o = new_ct(a->npoly, a->ell, a->deg, a->scale, a->slots);
+    launch_ew_addscalar(c_.dt, o->d, a->d, sc, a->npoly * a->ell, 0, a->ell, c_.stream, a->ell);
     hip_check(hipGetLastError(), "add_real");
     return o;
 }
