@@ -1,6 +1,7 @@
 // extern "C" boundary: translates C++ exceptions into status codes, owns nothing but handles.
 #include "../../include/fhelin.h"
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -99,7 +100,16 @@ int fhelin_prng_block(const uint8_t* seed32, uint64_t counter, uint64_t stream, 
     return FHELIN_OK;
 }
 
-void fhelin_ctx_destroy(fhelin_ctx* c) { delete c; }
+void fhelin_ctx_destroy(fhelin_ctx* c) {
+    if (c && std::getenv("FHELIN_COPY_STATS")) {
+        // diagnostics: ciphertext copies made to line operands up for a batched key switch, per call site of make_contiguous
+        // (0 rotate_sum_batch, 1 rotate_each_sum, 2 rotate_each_sum_rows, 3 rotate_each, 4 rotate_batch, 5 rescale_batch)
+        std::fprintf(stderr, "fhelin gather copies:");
+        for (int i = 0; i < 6; ++i) std::fprintf(stderr, " %llu", (unsigned long long)c->ev.gather_copies[i]);
+        std::fprintf(stderr, "\n");
+    }
+    delete c;
+}
 
 int fhelin_ctx_info(const fhelin_ctx* c, fhelin_params* out, int32_t* alpha, int32_t* has_device) {
     if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");

@@ -83,8 +83,9 @@ u64* Evaluator::contiguous_base(const std::vector<CtPtr>& v) {
     return v[0]->d;
 }
 
-std::vector<CtPtr> Evaluator::make_contiguous(const std::vector<CtPtr>& v) {
+std::vector<CtPtr> Evaluator::make_contiguous(const std::vector<CtPtr>& v, int site) {
     if (v.size() <= 1 || contiguous_base(v)) return v;
+    if (site >= 0 && site < 8) gather_copies[site] += v.size();   // FHELIN_COPY_STATS=1 prints these when the context goes away
     std::vector<CtPtr> o = new_ct_batch((int)v.size(), v[0]->npoly, v[0]->ell, v[0]->deg, v[0]->scale, v[0]->slots);
     for (size_t i = 0; i < v.size(); ++i)
         hip_check(hipMemcpyAsync(o[i]->d, v[i]->d, v[i]->words() * 8, hipMemcpyDeviceToDevice, c_.stream), "batch gather");
@@ -250,7 +251,7 @@ std::vector<CtPtr> Evaluator::rotate_sum_batch(const std::vector<CtPtr>& vin, co
         }
         std::vector<CtPtr> chunk;
         for (size_t i : idx) chunk.push_back(vin[i]);
-        chunk = make_contiguous(chunk);
+        chunk = make_contiguous(chunk, 0);
         const int B = (int)chunk.size(), ell = chunk[0]->ell;
         const size_t pn = (size_t)ell * N, ctw = 2 * pn;
         const LevelTables& lt = c_.lvl[ell];
@@ -346,7 +347,7 @@ CtPtr Evaluator::rotate_each_sum(const std::vector<CtPtr>& vin, const std::vecto
             }
             continue;
         }
-        chunk = make_contiguous(chunk);
+        chunk = make_contiguous(chunk, 1);
         const size_t N = c_.N;
         const int K = c_.K, L1 = c_.L + 1, ell = chunk[0]->ell;
         const size_t pn = (size_t)ell * N, ctw = 2 * pn;
@@ -447,7 +448,7 @@ std::vector<CtPtr> Evaluator::rotate_each_sum_rows(const std::vector<std::vector
         std::vector<CtPtr> flat;
         for (size_t b = lo; b < hi; ++b)
             for (int r : rot_pos) flat.push_back(rows[b][r]);
-        flat = make_contiguous(flat);
+        flat = make_contiguous(flat, 2);
         const u64* base = flat[0]->d;
         KsShape up{ell, K, c_.alpha, lt.beta, L1, B * R, ctw, 0, 0, 0};
         u64* cc = c_.dalloc<u64>((size_t)B * R * ell * N);
@@ -582,7 +583,7 @@ std::vector<CtPtr> Evaluator::rotate_each(const std::vector<CtPtr>& vin, const s
             rows.keys.push_back(it->second.get());
             rows.maps.push_back(c_.automorph_map(g));
         }
-        chunk = make_contiguous(chunk);
+        chunk = make_contiguous(chunk, 3);
         const int B = (int)chunk.size();
         const size_t pn = (size_t)a->ell * c_.N, ctw = 2 * pn;
         std::vector<CtPtr> o = new_ct_batch(B, 2, a->ell, a->deg, a->scale, a->slots);
@@ -679,7 +680,7 @@ std::vector<CtPtr> Evaluator::rotate_batch_impl(const std::vector<CtPtr>& vin, i
         }
         std::vector<CtPtr> chunk;
         for (size_t i : idx) chunk.push_back(vin[i]);
-        chunk = make_contiguous(chunk);
+        chunk = make_contiguous(chunk, 4);
         const int B = (int)chunk.size();
         const int ell = chunk[0]->ell;
         const size_t pn = (size_t)ell * c_.N, ctw = 2 * pn;
@@ -711,7 +712,7 @@ std::vector<CtPtr> Evaluator::rescale_batch(const std::vector<CtPtr>& vin) {
         }
         std::vector<CtPtr> chunk;
         for (size_t i : idx) chunk.push_back(vin[i]);
-        chunk = make_contiguous(chunk);
+        chunk = make_contiguous(chunk, 5);
         const int B = (int)chunk.size(), ell = chunk[0]->ell, P = 2 * B;
         if (ell < 2) throw Error(FHELIN_ERR_STATE, "rescale: no limb left to drop");
         const size_t N = c_.N;

@@ -85,7 +85,8 @@ public:
     std::vector<CtPtr> new_ct_batch(int count, int npoly, int ell, int deg, long double scale, int slots);
     // base pointer of `v` if its members are consecutive views of one block (else nullptr)
     static u64* contiguous_base(const std::vector<CtPtr>& v);
-    std::vector<CtPtr> make_contiguous(const std::vector<CtPtr>& v);
+    std::vector<CtPtr> make_contiguous(const std::vector<CtPtr>& v, int site = -1);
+    u64 gather_copies[8] = {};   // ciphertext copies made by make_contiguous, per call site (diagnostics)
     bool dot_groups = true;    // inner sums of all giant steps of a linear stage in one pass (dot_plain_groups); FHELIN_DOT_GROUPS=0: one pass each
     bool cheb_leaf_at_product = true;   // r-leaves of the Paterson-Stockmeyer tree born at their product's (limbs, scale); FHELIN_CHEB_LEAF_AT=0: level-adjusted afterwards
     bool cheb_rounds = true;   // Paterson-Stockmeyer products in rounds (polyeval.cpp cheb_recurse); FHELIN_CHEB_ROUNDS=0: one at a time
