@@ -172,6 +172,10 @@ def load_library():
         "fhelin_bootstrap": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_bootstrap_config": (i32, [vp, i32, i32, i32, i32]),
         "fhelin_bootstrap_partial": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "fhelin_bootstrap_drop": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "fhelin_bootstrap_describe": (i32, [vp, C.POINTER(i32), i32, C.POINTER(i32)]),
+        "fhelin_bootstrap_diag": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
+        "fhelin_bootstrap_cheb": (i32, [vp, C.POINTER(C.c_double), i32, C.POINTER(i32)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -574,6 +578,41 @@ class Engine:
 
     def bootstrap_config(self, K=28, R=3, cheb_degree=47, correction=10):
         self._ck(self.lib.fhelin_bootstrap_config(self.h, K, R, cheb_degree, correction))
+
+    def bootstrap_drop(self, a, drop):
+        """bootstrap raising to L+1-drop limbs only (what a level plan asks of a bootstrap)"""
+        return self._un(self.lib.fhelin_bootstrap_drop, a, int(drop))
+
+    def bootstrap_describe(self):
+        """the bootstrapping set-up as the residue-level oracle needs it: parameters + per linear stage the stage's slot count
+        and its (giant, baby, diagonal plaintext) terms in evaluation order"""
+        n = C.c_int32()
+        self._ck(self.lib.fhelin_bootstrap_describe(self.h, None, 0, C.byref(n)))
+        d = (C.c_int32 * n.value)()
+        self._ck(self.lib.fhelin_bootstrap_describe(self.h, d, n.value, C.byref(n)))
+        d = list(d)
+        out = dict(zip(("packed", "slots", "K", "R", "cheb_degree", "correction", "depth"), d[:7]))
+        out["packed"] = bool(out["packed"])
+        n_c2s, n_s2c = d[7], d[8]
+        pos, stages = 9, []
+        for k in range(n_c2s + n_s2c):
+            which, idx = (0, k) if k < n_c2s else (1, k - n_c2s)
+            st_slots, nt = d[pos], d[pos + 1]
+            pos += 2
+            terms = []
+            for t in range(nt):
+                h = C.c_void_p()
+                self._ck(self.lib.fhelin_bootstrap_diag(self.h, which, idx, t, C.byref(h)))
+                terms.append((d[pos], d[pos + 1], Pt(self, h)))
+                pos += 2
+            stages.append(dict(slots=st_slots, terms=terms))
+        out["c2s"], out["s2c"] = stages[:n_c2s], stages[n_c2s:]
+        cn = C.c_int32()
+        self._ck(self.lib.fhelin_bootstrap_cheb(self.h, None, 0, C.byref(cn)))
+        cf = (C.c_double * cn.value)()
+        self._ck(self.lib.fhelin_bootstrap_cheb(self.h, cf, cn.value, C.byref(cn)))
+        out["cheb"] = list(cf)
+        return out
 
     def bootstrap_partial(self, a, stage):
         return self._un(self.lib.fhelin_bootstrap_partial, a, stage)

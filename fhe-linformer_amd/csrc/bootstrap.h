@@ -39,6 +39,12 @@ public:
     CtPtr partial(const CtPtr& ct, int stage);
     int depth() const { return depth_; }
     int out_ell() const { return ev_.ctx().L + 1 - depth_; }   // limbs of the result when nothing is dropped
+    // read-only views for the residue-level parity tests (include/fhelin.h fhelin_bootstrap_describe / _diag / _cheb): the
+    // oracle composes the same stages from the diagonals' exported encodings
+    const std::vector<LinStage>& stages(bool s2c) const { return s2c ? s2c_ : c2s_; }
+    const std::vector<double>& cheb() const { return cheb_; }
+    bool packed() const { return packed_; }
+    int slots() const { return slots_; }
 
     // parameters (DESIGN.md "Bootstrapping")
     int K = 28;            // bound on |I|: t = Delta m + q0 I

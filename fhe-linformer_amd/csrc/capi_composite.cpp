@@ -356,6 +356,53 @@ int fhelin_bootstrap_partial(fhelin_ctx* c, const fhelin_ct* a, int32_t stage, f
     *out = wrap(c, c->boot.partial(ct_in(c, a), stage));
     FHELIN_CATCH
 }
+int fhelin_bootstrap_drop(fhelin_ctx* c, const fhelin_ct* a, int32_t drop, fhelin_ct** out) {
+    NEED(c && a && out);
+    FHELIN_TRY
+    *out = wrap(c, c->boot.bootstrap(ct_in(c, a), drop));
+    FHELIN_CATCH
+}
+int fhelin_bootstrap_describe(fhelin_ctx* c, int32_t* out, int32_t cap, int32_t* n) {
+    NEED(c && n && (out || cap == 0));
+    FHELIN_TRY
+    if (!c->boot.ready()) throw Error(FHELIN_ERR_STATE, "EvalBootstrapSetup has not been called");
+    const Bootstrapper& b = c->boot;
+    std::vector<int32_t> d = {b.packed() ? 1 : 0, b.slots(), b.K, b.R, b.cheb_degree, b.correction, b.depth(),
+                              (int32_t)b.stages(false).size(), (int32_t)b.stages(true).size()};
+    for (int which = 0; which < 2; ++which)
+        for (const LinStage& st : b.stages(which != 0)) {
+            d.push_back(st.terms.empty() ? 0 : st.terms[0].diag->slots);
+            d.push_back((int32_t)st.terms.size());
+            for (const auto& t : st.terms) {
+                d.push_back(t.giant);
+                d.push_back(t.baby);
+            }
+        }
+    *n = (int32_t)d.size();
+    for (int i = 0; i < std::min(cap, *n); ++i) out[i] = d[i];
+    FHELIN_CATCH
+}
+int fhelin_bootstrap_diag(fhelin_ctx* c, int32_t which, int32_t stage, int32_t term, fhelin_pt** out) {
+    NEED(c && out);
+    FHELIN_TRY
+    if (!c->boot.ready()) throw Error(FHELIN_ERR_STATE, "EvalBootstrapSetup has not been called");
+    const auto& sts = c->boot.stages(which != 0);
+    if (which < 0 || which > 1 || stage < 0 || stage >= (int)sts.size() || term < 0 || term >= (int)sts[stage].terms.size())
+        throw Error(FHELIN_ERR_ARG, "bootstrap_diag: no such term");
+    auto* h = new fhelin_pt;
+    h->p = sts[stage].terms[term].diag;
+    *out = h;
+    FHELIN_CATCH
+}
+int fhelin_bootstrap_cheb(fhelin_ctx* c, double* out, int32_t cap, int32_t* n) {
+    NEED(c && n && (out || cap == 0));
+    FHELIN_TRY
+    if (!c->boot.ready()) throw Error(FHELIN_ERR_STATE, "EvalBootstrapSetup has not been called");
+    const std::vector<double>& cf = c->boot.cheb();
+    *n = (int32_t)cf.size();
+    for (int i = 0; i < std::min(cap, *n); ++i) out[i] = cf[i];
+    FHELIN_CATCH
+}
 int fhelin_bootstrap_config(fhelin_ctx* c, int32_t K, int32_t R, int32_t cheb_degree, int32_t correction) {
     NEED(c);
     FHELIN_TRY

@@ -12,6 +12,7 @@ using namespace fhelin;
 static KeyPtr& key_slot(fhelin_ctx* c, int kind, int index) {
     if (kind == 0) return c->ev.relin_key;
     if (kind == 1) return c->ev.rot_keys[c->ctx.galois_element(index)];
+    if (kind == 2) return c->ev.conj_key;
     throw Error(FHELIN_ERR_ARG, "unknown key kind");
 }
 

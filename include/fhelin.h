@@ -130,7 +130,7 @@ int fhelin_gen_relin_key(fhelin_ctx* c);                /* context->EvalMultKeyG
 int fhelin_gen_rotation_keys(fhelin_ctx* c, const int32_t* indices, int32_t n);  /* EvalRotateKeyGen  :248       */
 int fhelin_gen_conj_key(fhelin_ctx* c);
 /* raw key material, [L+1+k][N] (secret, NTT form) and [dnum][2][L+1+k][N] (switching keys): parity tests
- * hand the same arrays to the oracle.  kind: 0 = relinearisation key, 1 = rotation key for `index`. */
+ * hand the same arrays to the oracle.  kind: 0 = relinearisation key, 1 = rotation key for `index`, 2 = conjugation key. */
 int fhelin_secret_export(fhelin_ctx* c, uint64_t* out, size_t cap_words);
 int fhelin_secret_import(fhelin_ctx* c, const uint64_t* in, size_t words);
 int fhelin_key_export(fhelin_ctx* c, int32_t kind, int32_t index, uint64_t* out, size_t cap_words);
@@ -276,6 +276,18 @@ int fhelin_bootstrap(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);
 int fhelin_bootstrap_config(fhelin_ctx* c, int32_t K, int32_t R, int32_t cheb_degree, int32_t correction);
 /* test hook: stop after 1 = ModRaise(+SubSum), 2 = CoeffsToSlots (real part), 3 = approximate mod (real part) */
 int fhelin_bootstrap_partial(fhelin_ctx* c, const fhelin_ct* a, int32_t stage, fhelin_ct** out);
+/* fhelin_bootstrap raising to L+1-drop limbs only: what a level plan (fhelin_level_plan_*) asks of the k-th bootstrap of a
+ * recorded program, here with the number given by the caller */
+int fhelin_bootstrap_drop(fhelin_ctx* c, const fhelin_ct* a, int32_t drop, fhelin_ct** out);
+/* ---- read-only views of the bootstrapping set-up: the residue-level oracle (oracle/residue_boot.py, tests only) composes
+ * EvalBootstrap (:445) from the same linear stages, Chebyshev coefficients and keys and must reach the same residues.
+ * describe: out = {packed, slots, K, R, cheb_degree, correction, depth, n_c2s, n_s2c, then per stage (CoeffsToSlots stages
+ * first): stage_slots, n_terms, n_terms x (giant, baby)}; *n = words needed (fills min(cap, *n)).
+ * diag: the plaintext diagonal of term `term` of stage `stage` (which: 0 CoeffsToSlots, 1 SlotsToCoeffs) as a handle for
+ * fhelin_pt_export.  cheb: the cosine-fit coefficients EvalMod evaluates.  Key kind 2 of fhelin_key_export = conjugation key. */
+int fhelin_bootstrap_describe(fhelin_ctx* c, int32_t* out, int32_t cap, int32_t* n);
+int fhelin_bootstrap_diag(fhelin_ctx* c, int32_t which, int32_t stage, int32_t term, fhelin_pt** out);
+int fhelin_bootstrap_cheb(fhelin_ctx* c, double* out, int32_t cap, int32_t* n);
 
 #ifdef __cplusplus
 }

@@ -184,6 +184,194 @@ class ResidueEvaluator:
             acc = t if acc is None else self.add(acc, t)
         return acc
 
+    # ---- ct x ct, real constants, polynomial evaluation (reference :431, :1289-1336; order of csrc/polyeval.cpp)
+    def mult(self, a, b):
+        """EvalMult(ct, ct) (:431): degree-2 operands are rescaled first, the pair is level-adjusted, tensor + relinearisation
+        (keys[0] is the relinearisation key).  Evaluator::mult and one pair of Evaluator::mult_batch."""
+        x = self.rescale(a) if a.deg >= 2 else a
+        y = x if b is a else (self.rescale(b) if b.deg >= 2 else b)
+        x, y = self.match(x, y)
+        d = orc.mult_relin(x.d, y.d, self.keys["relin"], self.alpha, self.q, self.p, self.psi_q, self.psi_p)
+        return RCt(d, x.deg + y.deg, x.scale * y.scale)
+
+    def real_scalars(self, v, ell):
+        """polyeval.cpp real_to_scalars: round(|v|) (half away from zero, 80-bit v) with the sign restored, modulo each limb"""
+        k = _llround(v)
+        return np.array([k % int(m) for m in self.q[:ell]], dtype=np.uint64)
+
+    def mult_real(self, a, cst):
+        """EvalMult(ct, double): a constant vector encodes to a constant polynomial -> per-limb scalar round(cst * Delta_level)"""
+        x = self.rescale(a) if a.deg >= 2 else a
+        sf = self.sf[self.level(x)]
+        s = self.real_scalars(LD(cst) * sf, x.ell)
+        ql = self.q[:x.ell]
+        return RCt(self._each(lambda u: orc.mul_scalar(u, s, ql), x), x.deg + 1, x.scale * sf)
+
+    def add_real(self, a, cst):
+        """EvalAdd(ct, double): round(cst * scale) added to component 0"""
+        ql = self.q[:a.ell]
+        d = a.d.copy()
+        d[0] = orc.add_scalar(a.d[0], self.real_scalars(LD(cst) * a.scale, a.ell), ql)
+        return RCt(d, a.deg, a.scale)
+
+    MAX_LINCOMB = 32       # LinComb::MAX_TERMS (kernels_elem.h): above it the library runs the chain of single operations
+
+    def lincomb(self, terms, coef, c0):
+        return self.lincomb_at(terms, coef, c0, 0, 0)
+
+    def lincomb_at(self, terms_in, coef_in, c0, want_scale, keep_ell):
+        """sum_k coef_k T_k + c0 (EvalLinearWSum; Evaluator::lincomb_at).  Uniform operands: every coefficient becomes the scalar
+        round(coef * f) with f = the level's Delta, or want_scale / scale when the sum has to be born at `want_scale` on the first
+        keep_ell limbs (a summand of a Paterson-Stockmeyer product).  Otherwise the chain mult_real / add / add_real; None
+        when a (want_scale, keep_ell) request cannot be met that way."""
+        pairs = [(t, c) for t, c in zip(terms_in, coef_in) if c != 0.0]
+        assert pairs, "lincomb: all coefficients are zero"
+        terms, coef = [t for t, _ in pairs], [c for _, c in pairs]
+        x = terms[0]
+        uniform = 2 <= len(terms) <= self.MAX_LINCOMB and all(
+            t.deg == 1 and t.npoly == x.npoly and t.ell == x.ell and abs(t.scale / x.scale - LD(1)) < LD(1e-9) for t in terms)
+        if not uniform:
+            if want_scale > 0 or keep_ell > 0:
+                return None
+            acc = None
+            for t, c in zip(terms, coef):
+                m = self.mult_real(t, c)
+                acc = m if acc is None else self.add(acc, m)
+            return self.add_real(acc, c0) if c0 != 0.0 else acc
+        ell = min(keep_ell, x.ell) if keep_ell > 0 else x.ell
+        sf = LD(want_scale) / x.scale if want_scale > 0 else self.sf[self.level(x)]
+        out_scale = x.scale * sf
+        ql = self.q[:ell]
+        acc = None
+        for t, c in zip(terms, coef):
+            s = self.real_scalars(LD(c) * sf, ell)
+            m = np.stack([orc.mul_scalar(t.d[k, :ell], s, ql) for k in range(t.npoly)])
+            acc = m if acc is None else np.stack([orc.add(acc[k], m[k], ql) for k in range(x.npoly)])
+        if c0 != 0.0:
+            acc[0] = orc.add_scalar(acc[0], self.real_scalars(LD(c0) * out_scale, ell), ql)
+        return RCt(acc, 2, out_scale)
+
+    def align_deg1(self, v):
+        """polyeval.cpp align_deg1: a set of powers to one common (fewest limbs, degree 1, that level's Delta)"""
+        v = [self.rescale(t) if t.deg >= 2 else t for t in v]
+        ell = min(t.ell for t in v)
+        sf = self.sf[len(self.q) - ell]
+        return [self.adjust(t, ell, 1, sf) for t in v]
+
+    def mult_many(self, v):
+        """EvalMultMany (:1297): pairwise product tree; identical operand pairs give one product"""
+        cur = list(v)
+        while len(cur) > 1:
+            nxt = []
+            for i in range(0, len(cur) - 1, 2):
+                if i >= 2 and cur[i] is cur[i - 2] and cur[i + 1] is cur[i - 1]:
+                    nxt.append(nxt[-1])
+                else:
+                    nxt.append(self.mult(cur[i], cur[i + 1]))
+            if len(cur) & 1:
+                nxt.append(cur[-1])
+            cur = nxt
+        return cur[0]
+
+    def eval_poly(self, x, coeffs):
+        """EvalPoly (:1291), power basis: x^i by the binary power tree, powers aligned, one linear combination"""
+        n = len(coeffs) - 1
+        while n > 0 and coeffs[n] == 0.0:
+            n -= 1
+        pw = [None] * (n + 1)
+        pw[1] = self.rescale(x) if x.deg >= 2 else x
+        for i in range(2, n + 1):
+            hi = 1
+            while hi * 2 <= i:
+                hi *= 2
+            pw[i] = self.mult(pw[i // 2], pw[i // 2]) if hi == i else self.mult(pw[hi], pw[i - hi])
+        terms = self.align_deg1(pw[1:])
+        return self.lincomb(terms, list(coeffs[1:n + 1]), coeffs[0])
+
+    def eval_chebyshev(self, x, coeffs_in, a=-1.0, b=1.0, leaf_at_product=True):
+        """EvalChebyshevFunction's series evaluation (:1319-1335) as polyeval.cpp runs it: c0/2 + sum c_k T_k(u); babies
+        T_1..T_{b-1} (b = 2^ceil(log2(n+1)/2)) by T_k = 2 T_floor(k/2) T_ceil(k/2) - T_(k mod 2), giants T_b, T_2b, ... by
+        squaring, Paterson-Stockmeyer recursion p = q T_m + r.  The library evaluates the recursion's products in batched
+        rounds; every node computes mult(q, T_m) then add(., r), so the order does not enter the residues."""
+        a, b = float(a), float(b)
+        c = [float(v) for v in coeffs_in]
+        n = len(c) - 1
+        while n > 0 and c[n] == 0.0:
+            n -= 1
+        c = c[:n + 1]
+        assert n >= 1
+        c[0] *= 0.5
+        u = x
+        if not (a == -1.0 and b == 1.0):
+            u = self.mult_real(x, 2.0 / (b - a))
+            u = self.add_real(u, -(a + b) / (b - a))
+        if u.deg >= 2:
+            u = self.rescale(u)
+        l = 0
+        while (1 << (2 * l)) < n + 1:
+            l += 1
+        baby = max(2, 1 << l)
+        T = [None] * (baby + 1)
+        T[1] = u
+        h = 1
+        while h < baby:
+            for k in range(h + 1, min(2 * h, baby) + 1):
+                t = self.mult(T[k // 2], T[k - k // 2])
+                t = self.add(t, t)
+                t = self.add_real(t, -1.0) if k % 2 == 0 else self.sub(t, T[1])
+                T[k] = self.rescale(t)
+            h *= 2
+        G = {baby: T[baby]}
+        m = baby
+        while m * 2 <= n:
+            t = self.mult(G[m], G[m])
+            t = self.add_real(self.add(t, t), -1.0)
+            G[2 * m] = self.rescale(t)
+            m *= 2
+        B = [None] + self.align_deg1(T[1:baby])
+
+        def strip(p):
+            k = len(p) - 1
+            while k > 0 and p[k] == 0.0:
+                k -= 1
+            return p[:k + 1]
+
+        def leaf(p, at=None):
+            """sum_{k>=1} p_k T_k + p_0 over the aligned babies; at = the product it will be added to"""
+            if not any(v != 0.0 for v in p[1:]):
+                z = self.mult_real(B[1], 0.0)
+                return self.add_real(z, p[0]) if p[0] != 0.0 else z
+            terms, cf = B[1:len(p)], p[1:]
+            if at is not None and at.deg == 2:
+                v = self.lincomb_at(terms, cf, p[0], at.scale, at.ell)
+                if v is not None:
+                    return v
+            return self.lincomb(terms, cf, p[0])
+
+        def node(p, at=None):
+            p = strip(p)
+            k = len(p) - 1
+            if k < baby:
+                return leaf(p, at)
+            mm = baby
+            while mm * 2 <= k:
+                mm *= 2
+            qc, rc = [0.0] * (k - mm + 1), list(p[:mm])
+            qc[0] = p[mm]
+            for i in range(mm + 1, k + 1):
+                qc[i - mm] = 2 * p[i]
+                rc[2 * mm - i] -= p[i]
+            prod = self.mult(node(qc), G[mm])
+            if all(v == 0.0 for v in rc):
+                return prod
+            rs = strip(rc)
+            r_is_leaf = len(rs) - 1 < baby
+            if r_is_leaf and leaf_at_product and any(v != 0.0 for v in rs[1:]):
+                return self.add(prod, leaf(rs, prod))
+            return self.add(prod, node(rc))
+
+        return node(c)
+
     # ---- composites as composite.cpp runs them by default
     @staticmethod
     def log_steps(slots):
