@@ -332,9 +332,10 @@ class Engine:
         self._ck(self.lib.fhelin_ntt(self.h, buf.ptr, nvec, limb_first, limb_count, 1 if inverse else 0))
 
     def stats(self, reset=False):
-        out = np.zeros(9, dtype=np.uint64)
-        self._ck(self.lib.fhelin_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), 9, 1 if reset else 0))
-        keys = ["limb_ntt", "keyswitch", "keyswitch_limbs", "rescale", "ct_pt_mult", "bootstrap", "encode", "rescale_limbs", "ct_pt_limbs"]
+        out = np.zeros(12, dtype=np.uint64)
+        self._ck(self.lib.fhelin_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), 12, 1 if reset else 0))
+        keys = ["limb_ntt", "keyswitch", "keyswitch_limbs", "rescale", "ct_pt_mult", "bootstrap", "encode", "rescale_limbs", "ct_pt_limbs",
+                "pool_malloc_calls", "pool_malloc_bytes", "pool_malloc_ns"]
         return {k: int(v) for k, v in zip(keys, out)}
 
     def microbench(self, variant, iters=4096, blocks=2048):

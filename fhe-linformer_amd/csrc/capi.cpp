@@ -160,6 +160,7 @@ int fhelin_ctx_set_stream(fhelin_ctx* c, void* hip_stream) {
     c->ctx.sync();
     if (c->ctx.own_stream && c->ctx.main_stream) hip_check(hipStreamDestroy(c->ctx.main_stream), "hipStreamDestroy");
     c->ctx.stream = c->ctx.main_stream = (hipStream_t)hip_stream;
+    c->ctx.pool.lane_stream[0] = c->ctx.main_stream;
     c->ctx.own_stream = false;
     FHELIN_CATCH
 }
@@ -290,6 +291,13 @@ int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset) {
     if (cap >= 9) {
         out[7] = s.rescale_limbs;
         out[8] = s.ct_pt_limbs;
+    }
+    if (cap >= 12) {   // device-pool growth: blocks obtained from hipMalloc, their bytes, host nanoseconds inside hipMalloc
+        DevicePool& p = c->ctx.pool;
+        out[9] = p.malloc_calls;
+        out[10] = p.malloc_bytes;
+        out[11] = p.malloc_ns;
+        if (reset) p.malloc_calls = p.malloc_bytes = p.malloc_ns = 0;
     }
     if (reset) s = OpStats();
     return FHELIN_OK;

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <sys/random.h>
+#include <time.h>
 
 namespace fhelin {
 
@@ -14,7 +15,11 @@ void hip_check(hipError_t e, const char* what) {
 // ---------------------------------------------------------------- DevicePool
 DevicePool::~DevicePool() {
     for (auto& lane : idle_)
-        for (auto& kv : lane) (void)hipFree(kv.second);
+        for (auto& kv : lane) {
+            if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
+            (void)hipFree(kv.second.p);
+        }
+    for (hipEvent_t e : spare_events_) (void)hipEventDestroy(e);
     for (auto& kv : live_) (void)hipFree(kv.first);
 }
 void* DevicePool::alloc(size_t bytes) {
@@ -32,15 +37,26 @@ void* DevicePool::alloc(size_t bytes) {
     auto it = idle.find(bytes);
     void* p = nullptr;
     if (it != idle.end()) {
-        p = it->second;
+        p = it->second.p;
+        if (it->second.ev) {
+            // last used by work on another lane's stream: this lane's stream goes behind it (no host wait)
+            hip_check(hipStreamWaitEvent(lane_stream[cur_lane], it->second.ev, 0), "hipStreamWaitEvent(pool reuse)");
+            spare_events_.push_back(it->second.ev);
+        }
         idle.erase(it);
     } else {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
         hipError_t e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
             (void)hipGetLastError();  // the failure is handled here; do not leave it for the next launch check
             trim();
             hip_check(hipMalloc(&p, bytes), "hipMalloc");
         }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        malloc_calls += 1;
+        malloc_bytes += bytes;
+        malloc_ns += (u64)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
         reserved_ += bytes;
     }
     live_[p] = Live{bytes, cur_lane};
@@ -50,14 +66,27 @@ void DevicePool::free(void* p) {
     if (!p) return;
     auto it = live_.find(p);
     if (it == live_.end()) throw Error(FHELIN_ERR_STATE, "DevicePool::free of unknown pointer");
-    idle_[it->second.lane].emplace(it->second.bytes, p);  // back to the lane (stream) that owns it
+    hipEvent_t ev = nullptr;
+    if (have_streams && it->second.lane != cur_lane) {
+        // freed under another lane than the one that owns it: whatever that lane's stream has queued so far may still read it
+        if (!spare_events_.empty()) {
+            ev = spare_events_.back();
+            spare_events_.pop_back();
+        } else {
+            hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate(pool)");
+        }
+        hip_check(hipEventRecord(ev, lane_stream[cur_lane]), "hipEventRecord(pool free)");
+        foreign_frees += 1;
+    }
+    idle_[it->second.lane].emplace(it->second.bytes, Idle{p, ev});  // back to the lane (stream) that owns it
     live_.erase(it);
 }
 void DevicePool::trim() {
     (void)hipDeviceSynchronize();
     for (auto& lane : idle_) {
         for (auto& kv : lane) {
-            (void)hipFree(kv.second);
+            if (kv.second.ev) spare_events_.push_back(kv.second.ev);
+            (void)hipFree(kv.second.p);
             reserved_ -= kv.first;
         }
         lane.clear();
@@ -166,6 +195,9 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
             hip_check(hipEventCreateWithFlags(&lane_event[k], hipEventDisableTiming), "hipEventCreate(lane)");
         }
         hip_check(hipEventCreateWithFlags(&fork_event, hipEventDisableTiming), "hipEventCreate(fork)");
+        pool.lane_stream[0] = main_stream;
+        for (int k = 1; k <= n_lanes; ++k) pool.lane_stream[k] = lane_stream[k];
+        pool.have_streams = true;
         if (const char* e = std::getenv("FHELIN_ASYNC")) async_lanes = std::atoi(e) != 0;
         if (const char* e = std::getenv("FHELIN_FUSE_MODDOWN")) fuse_moddown = std::atoi(e) != 0;
         if (const char* e = std::getenv("FHELIN_HOST_ENCODE")) host_encode = std::atoi(e) != 0;

@@ -45,7 +45,9 @@ void hip_check(hipError_t e, const char* what);
 
 // Size-bucketed caching allocator.  Work is stream-ordered, so a freed block can be handed out again immediately —
 // to the SAME stream.  With several lanes (streams) every block belongs to the lane that allocated it and only
-// that lane's idle list gets it back (Context::LaneScope orders lane streams against the main stream).
+// that lane's idle list gets it back.  A block that is freed while ANOTHER lane is current (a worker lane's result
+// consumed and released on the main stream, or the reverse) may still be read by work queued on that other lane's
+// stream: the free records an event there and the owner lane's stream waits for it before the block's next use.
 class DevicePool {
 public:
     static constexpr int MAX_LANES = 5;  // lane 0 = main stream
@@ -55,10 +57,17 @@ public:
     void trim();
     size_t bytes_reserved() const { return reserved_; }
     int cur_lane = 0;
+    hipStream_t lane_stream[MAX_LANES] = {};   // set by the Context: the stream each lane launches on (lane 0 = main stream)
+    bool have_streams = false;
+    // growth diagnostics (fhelin_stats slots 9..11): blocks obtained from hipMalloc, their bytes, host time spent inside hipMalloc
+    u64 malloc_calls = 0, malloc_bytes = 0, malloc_ns = 0;
+    u64 foreign_frees = 0;
 private:
     struct Live { size_t bytes; int lane; };
+    struct Idle { void* p; hipEvent_t ev; };   // ev: last use on a foreign lane's stream (null: none)
     std::unordered_map<void*, Live> live_;
-    std::multimap<size_t, void*> idle_[MAX_LANES];
+    std::multimap<size_t, Idle> idle_[MAX_LANES];
+    std::vector<hipEvent_t> spare_events_;
     size_t reserved_ = 0;
 };
 

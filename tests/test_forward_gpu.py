@@ -10,16 +10,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("variant,preset,n_q", [
-    ("main", "reference", 28),       # src/main.cpp as built: CLS-query attention (BASELINE configs 2-3), the reference's 28+7 limbs
-    ("main_2", "reference", 28),     # src/main_2.cpp: full attention over all S tokens
-    ("main_2", "deep", 30),          # BASELINE config 5: N=2^17, 30+7 limbs, sparse (N/8) bootstrapping
-    ("main", "bench", 28),           # the headline configuration of bench.py: N=2^16, 28+7 limbs (alpha=7), sparse (N/4) packing
+@pytest.mark.parametrize("variant,preset,n_q,S", [
+    ("main", "reference", 28, 129),       # src/main.cpp as built: CLS-query attention (BASELINE configs 2-3), the reference's 28+7 limbs
+    ("main_2", "reference", 28, 129),     # src/main_2.cpp: full attention over all S tokens
+    ("main_2", "deep", 30, 129),          # BASELINE config 5: N=2^17, 30+7 limbs, sparse (N/8) bootstrapping
+    ("main", "bench", 28, 129),           # the headline configuration of bench.py: N=2^16, 28+7 limbs (alpha=7), sparse (N/4) packing
+    ("main", "bench", 28, 200),           # SURVEY 8(d)'s second input size: 201 rows = 128 + a ragged 73 (src/main.cpp:300-309), 7 GELU
+                                          # containers (:354-358) -> 10 bootstraps
+    ("main_2", "reference", 28, 200),
 ])
-def test_encrypted_forward_matches_plaintext_circuit(fa, variant, preset, n_q):
+def test_encrypted_forward_matches_plaintext_circuit(fa, variant, preset, n_q, S):
     from fhe_linformer_amd import linformer as lf
     from oracle import plain_forward as pf, circuit_sim as cs
-    S = 129
     w = pf.synthetic_model(1234)
     x = pf.synthetic_tokens(S, 4321)
     x_in, X_E, X_F = pf.client_inputs(w, x)
@@ -34,7 +36,7 @@ def test_encrypted_forward_matches_plaintext_circuit(fa, variant, preset, n_q):
         eng.bootstrap_setup(3, 3, 16384)
         ctl, tr = lf.GpuController(eng), {}
         out = lf.forward(ctl, w, x_in, X_E, X_F, tr, variant)
-        assert ctl.n_boot == sim.n_boot == 8                   # 2 (affine-1) + 5 (GELU containers) + 1 (pooler)
+        assert ctl.n_boot == sim.n_boot == 3 + -(-(S + 1) // 32)   # 2 (affine-1) + ceil((S+1)/32) GELU containers + 1 (pooler): 8 / 10
         # before the first bootstrap only CKKS noise separates the two: with OpenFHE's count of special primes (P barely
         # above the widest digit) hybrid key switching leaves ~2^-37 relative noise per rotation, ~2e-8 after the thousands
         # of rotations up to `self_attention`; after bootstrapping its 2.5e-5 precision dominates
