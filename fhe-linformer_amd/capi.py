@@ -173,6 +173,7 @@ def load_library():
         "fhelin_bootstrap_config": (i32, [vp, i32, i32, i32, i32]),
         "fhelin_bootstrap_partial": (i32, [vp, vp, i32, C.POINTER(vp)]),
         "fhelin_bootstrap_drop": (i32, [vp, vp, i32, C.POINTER(vp)]),
+        "fhelin_bootstrap_batch": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp)]),
         "fhelin_bootstrap_describe": (i32, [vp, C.POINTER(i32), i32, C.POINTER(i32)]),
         "fhelin_bootstrap_diag": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
         "fhelin_bootstrap_cheb": (i32, [vp, C.POINTER(C.c_double), i32, C.POINTER(i32)]),
@@ -579,6 +580,12 @@ class Engine:
 
     def bootstrap_config(self, K=28, R=3, cheb_degree=47, correction=10):
         self._ck(self.lib.fhelin_bootstrap_config(self.h, K, R, cheb_degree, correction))
+
+    def bootstrap_batch(self, v):
+        """EvalBootstrap on independent ciphertexts in one batched pipeline (same residues as bootstrap() one by one)"""
+        outs = self._outs(len(v))
+        self._ck(self.lib.fhelin_bootstrap_batch(self.h, self._harr(v), len(v), outs))
+        return self._cts(outs, len(v))
 
     def bootstrap_drop(self, a, drop):
         """bootstrap raising to L+1-drop limbs only (what a level plan asks of a bootstrap)"""

@@ -389,6 +389,165 @@ CtPtr Bootstrapper::run(const CtPtr& ct, int stop_after, int drop) {
     return v;
 }
 
+// ---- the same pipeline over a batch of independent ciphertexts ----------------------------------------------------------
+// Every step below is the batched form of the step of run() / apply() above it stands for; each ciphertext goes through
+// exactly the same residue operations (the batched evaluator entry points return the residues of the single ones).
+std::vector<CtPtr> Bootstrapper::apply_batch(const LinStage& st, const std::vector<CtPtr>& xin) {
+    Context& c = ev_.ctx();
+    const size_t B = xin.size();
+    std::vector<CtPtr> xs = xin[0]->deg >= 2 ? ev_.rescale_batch(xin) : xin;
+    std::vector<int> bidx;
+    for (const auto& t : st.terms)
+        if (std::find(bidx.begin(), bidx.end(), t.baby) == bidx.end()) bidx.push_back(t.baby);
+    // baby steps: ONE ModUp over the batch, per ciphertext the inner products of all indices, ONE ModDown over everything
+    std::vector<std::vector<CtPtr>> brot = ev_.rotate_many_batch(xs, bidx);
+    const CtPtr& x = xs[0];
+    long double pt_scale = 0;
+    const int lvl = x->level();
+    if (x->ell >= 2 && fabsl(x->scale / c.sf_real[lvl] - 1.0L) > 1e-12L)
+        pt_scale = c.sf_real[lvl + 1] * (long double)c.chain.q[x->ell - 1] / x->scale;
+    // giant-step groups: the unrotated one first, then ascending (= rotate_each_sum's order)
+    std::vector<int> order;
+    {
+        std::set<int> gs;
+        for (const auto& t : st.terms) gs.insert(t.giant);
+        for (int g : gs)
+            if (g % x->slots == 0) order.push_back(g);
+        for (int g : gs)
+            if (g % x->slots != 0) order.push_back(g);
+    }
+    const size_t G = order.size();
+    size_t n_plain = 0;
+    for (int g : order) n_plain += g % x->slots == 0 ? 1 : 0;
+    std::vector<std::vector<PtPtr>> pts(G, std::vector<PtPtr>(bidx.size()));
+    for (const auto& t : st.terms) {
+        const size_t gi = std::find(order.begin(), order.end(), t.giant) - order.begin();
+        const size_t bi = std::find(bidx.begin(), bidx.end(), t.baby) - bidx.begin();
+        pts[gi][bi] = t.diag;
+    }
+    // inner sums: the rotated groups of ALL ciphertexts in one block (the batched giant-step key switch takes them as they
+    // stand), the unrotated groups in another
+    std::vector<CtPtr> slab_plain, slab_rot;
+    if (n_plain) slab_plain = ev_.new_ct_batch((int)(B * n_plain), 2, x->ell, 2, 0, x->slots);
+    if (G > n_plain) slab_rot = ev_.new_ct_batch((int)(B * (G - n_plain)), 2, x->ell, 2, 0, x->slots);
+    std::vector<std::vector<CtPtr>> rows(B);
+    for (size_t i = 0; i < B; ++i) {
+        std::vector<CtPtr> dest;
+        for (size_t k = 0; k < G; ++k)
+            dest.push_back(k < n_plain ? slab_plain[i * n_plain + k] : slab_rot[i * (G - n_plain) + (k - n_plain)]);
+        if (!ev_.dot_plain_groups(brot[i], pts, pt_scale, dest)) {
+            for (size_t k = 0; k < G; ++k) {
+                std::vector<CtPtr> cts;
+                std::vector<PtPtr> ps;
+                for (size_t b = 0; b < bidx.size(); ++b)
+                    if (pts[k][b]) {
+                        cts.push_back(brot[i][b]);
+                        ps.push_back(pts[k][b]);
+                    }
+                dest[k] = ev_.dot_plain(cts, ps, pt_scale, dest[k]);
+            }
+        }
+        // ascending giant shift, as apply() hands them to rotate_each_sum
+        std::vector<std::pair<int, CtPtr>> byg;
+        for (size_t k = 0; k < G; ++k) byg.push_back({order[k], dest[k]});
+        std::sort(byg.begin(), byg.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+        for (auto& e : byg) rows[i].push_back(e.second);
+    }
+    std::vector<int> gidx = order;
+    std::sort(gidx.begin(), gidx.end());
+    return ev_.rotate_each_sum_rows(rows, gidx);
+}
+
+std::vector<CtPtr> Bootstrapper::run_batch(const std::vector<CtPtr>& cts, int drop) {
+    if (!ready()) throw Error(FHELIN_ERR_STATE, "EvalBootstrapSetup has not been called");
+    Context& c = ev_.ctx();
+    if (drop < 0 || c.L + 1 - drop - depth_ < 1) throw Error(FHELIN_ERR_ARG, "bootstrap: level plan leaves no limb for the result");
+    const size_t B = cts.size();
+    const int top_ell = c.L + 1 - drop;
+    // ---- ModRaise (mod_raise() per ciphertext: the integer constant depends on each one's scale)
+    std::vector<CtPtr> xs(B);
+    {
+        std::vector<CtPtr> need;
+        std::vector<size_t> pos;
+        for (size_t i = 0; i < B; ++i) {
+            if (cts[i]->deg >= 2) {
+                need.push_back(cts[i]);
+                pos.push_back(i);
+            } else {
+                xs[i] = cts[i];
+            }
+        }
+        if (!need.empty()) {
+            std::vector<CtPtr> r = ev_.rescale_batch(need);
+            for (size_t k = 0; k < pos.size(); ++k) xs[pos[k]] = r[k];
+        }
+    }
+    std::vector<long double> rho(B);
+    const long double q0 = (long double)c.chain.q[0], q1 = (long double)c.chain.q[1];
+    const long double target = q0 / (long double)(1ull << correction);
+    for (size_t i = 0; i < B; ++i) {
+        CtPtr x = xs[i];
+        if (x->npoly != 2) throw Error(FHELIN_ERR_STATE, "bootstrap: ciphertext must be relinearised");
+        if (x->ell < 2) throw Error(FHELIN_ERR_STATE, "bootstrap: need at least two limbs to set the message scale (bootstrap one level earlier)");
+        if (x->ell > 2) x = ev_.level_reduce(x, 2);
+        const u64 k0 = (u64)llroundl(target * q1 / x->scale);
+        if (k0 < 2) throw Error(FHELIN_ERR_STATE, "bootstrap: ciphertext scale too large for the correction factor");
+        xs[i] = ev_.mult_int(x, k0, true, x->scale * (long double)k0);
+    }
+    xs = ev_.rescale_batch(xs);
+    for (size_t i = 0; i < B; ++i) rho[i] = xs[i]->scale * (long double)(1ull << correction) / q0;
+    c.stats.bootstrap += B;
+    std::vector<CtPtr> w = ev_.raw_modraise_batch(xs, top_ell);
+    for (CtPtr& u : w) {
+        u->deg = 1;
+        u->scale = c.sf_real[0];
+        u->slots = slots_;
+    }
+    const int gapN = (c.N / 2) / slots_;
+    for (int j = 1; j < gapN; j <<= 1) {
+        const u64 g = c.galois_element(slots_ * j);
+        auto it = ev_.rot_keys.find(g);
+        if (it == ev_.rot_keys.end()) throw Error(FHELIN_ERR_KEY, "bootstrap: SubSum rotation key missing");
+        w = ev_.rotate_galois_batch(w, g, *it->second, true);     // u + sigma_g(u), the sum in the key switch's epilogue
+    }
+    // ---- CoeffsToSlots, conjugation, EvalMod, SlotsToCoeffs
+    for (const auto& st : c2s_) w = apply_batch(st, w);
+    if (packed_)
+        for (CtPtr& u : w) u->slots = 2 * slots_;
+    std::vector<CtPtr> wc = ev_.conjugate_batch(w);
+    std::vector<CtPtr> a = ev_.add_batch(w, wc);
+    std::vector<CtPtr> v;
+    if (packed_) {
+        v = eval_mod(a);
+    } else {
+        std::vector<CtPtr> d = ev_.sub_batch(wc, w), all = a;
+        for (const CtPtr& t : d) all.push_back(mult_i(t));
+        std::vector<CtPtr> ab = eval_mod(all);
+        std::vector<CtPtr> im;
+        for (size_t i = 0; i < B; ++i) im.push_back(mult_i(ab[B + i]));
+        v = ev_.add_batch(std::vector<CtPtr>(ab.begin(), ab.begin() + B), im);
+    }
+    for (size_t k = 0; k < s2c_.size(); ++k) {
+        v = apply_batch(s2c_[k], v);
+        if (packed_ && k == 0)
+            for (CtPtr& u : v) u->slots = slots_;
+    }
+    std::vector<CtPtr> out(B);
+    for (size_t i = 0; i < B; ++i) {
+        out[i] = ev_.mult_int(v[i], 1ull << correction, false, v[i]->scale);
+        out[i]->scale = out[i]->scale * rho[i];
+    }
+    if (out[0]->deg >= 2) out = ev_.rescale_batch(out);
+    for (size_t i = 0; i < B; ++i) out[i]->slots = cts[i]->slots > 0 ? cts[i]->slots : slots_;
+    return out;
+}
+
+std::vector<CtPtr> Bootstrapper::bootstrap_batch(const std::vector<CtPtr>& cts, int drop) {
+    if (cts.empty()) return {};
+    if (cts.size() == 1) return {run(cts[0], 0, drop)};
+    return run_batch(cts, drop);
+}
+
 CtPtr Bootstrapper::bootstrap(const CtPtr& ct, int drop) { return run(ct, 0, drop); }
 CtPtr Bootstrapper::partial(const CtPtr& ct, int stage) { return run(ct, stage); }
 

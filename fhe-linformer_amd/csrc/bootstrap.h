@@ -35,6 +35,10 @@ public:
     // drop: raise to L+1-drop limbs only, so that the result has `drop` limbs fewer (level plan: the caller knows that the
     // circuit up to the next bootstrap leaves that many unused)
     CtPtr bootstrap(const CtPtr& ct, int drop = 0);
+    // several independent ciphertexts at once (the GELU containers of one sample, src/main.cpp:354-358; the two halves of
+    // affine-1, :319-320): every launch of the pipeline carries all of them, the switching keys and plaintext diagonals are
+    // read once per batch.  out[i] holds exactly the residues of bootstrap(cts[i], drop).
+    std::vector<CtPtr> bootstrap_batch(const std::vector<CtPtr>& cts, int drop = 0);
     // debug / test hook: stop after stage 1 (ModRaise+SubSum), 2 (CoeffsToSlots, real part), 3 (EvalMod, real part)
     CtPtr partial(const CtPtr& ct, int stage);
     int depth() const { return depth_; }
@@ -69,6 +73,8 @@ private:
     CtPtr mod_raise(const CtPtr& ct, long double& rho, int top_ell);
     std::vector<CtPtr> eval_mod(const std::vector<CtPtr>& xs);
     CtPtr run(const CtPtr& ct, int stop_after, int drop = 0);
+    std::vector<CtPtr> apply_batch(const LinStage& st, const std::vector<CtPtr>& xs);
+    std::vector<CtPtr> run_batch(const std::vector<CtPtr>& cts, int drop);
 };
 
 }  // namespace fhelin

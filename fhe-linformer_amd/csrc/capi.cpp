@@ -21,6 +21,7 @@ int capi_fail(int code, const std::string& msg) {
 
 fhelin_ctx::fhelin_ctx(const fhelin::Params& p) : ctx(p), ev(ctx), cl(ev, ctx.prm.seed_bytes), comp(ev, cl), boot(ev, cl) {
     if (const char* e = std::getenv("FHELIN_LAZY_ROWS")) lazy_rows = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FHELIN_LAZY_HEAVY")) lazy_heavy = std::atoi(e) != 0;
 }
 
 #define NEED(x) if (!(x)) return capi_fail(FHELIN_ERR_ARG, "null argument")
@@ -208,6 +209,7 @@ int fhelin_level_plan_set(fhelin_ctx* c, const int32_t* target, int32_t n) {
 int fhelin_sync(fhelin_ctx* c) {
     if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
     FHELIN_TRY
+    if (!c->pending_heavy.empty()) flush_heavy(c);   // deferred bootstraps / polynomial evaluations count as issued work
     c->ctx.sync();
     FHELIN_CATCH
 }

@@ -57,7 +57,89 @@ void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx) {
         g.src.reset();
     }
 }
+// Deferred heavy operations: everything pending, in dependency order; per round the ready operations of one kind, one
+// parameter set and one input shape go through ONE batched call.
+void flush_heavy(fhelin_ctx* c) {
+    std::vector<std::shared_ptr<LazyHeavy>> pend;
+    pend.swap(c->pending_heavy);
+    try {
+        for (;;) {
+            std::vector<LazyHeavy*> ready;
+            bool waiting = false;
+            for (auto& sp : pend) {
+                LazyHeavy& h = *sp;
+                if (h.done) continue;
+                if (sp.use_count() == 1) {   // every handle to the result is gone and nothing pending reads it: never evaluated
+                    h.done = h.failed = true;
+                    h.in.reset();
+                    h.in_heavy.reset();
+                    continue;
+                }
+                if (h.in_heavy && h.in_heavy->done) {
+                    if (h.in_heavy->failed || !h.in_heavy->result) throw Error(FHELIN_ERR_STATE, "a deferred operation's input failed earlier");
+                    h.in = h.in_heavy->result;
+                    h.in_heavy.reset();
+                }
+                if (h.in) ready.push_back(&h);
+                else waiting = true;
+            }
+            if (ready.empty()) {
+                if (waiting) throw Error(FHELIN_ERR_INTERNAL, "deferred heavy operations: dependency cycle");
+                break;
+            }
+            std::vector<char> taken(ready.size(), 0);
+            for (size_t first = 0; first < ready.size(); ++first) {
+                if (taken[first]) continue;
+                LazyHeavy& f = *ready[first];
+                std::vector<LazyHeavy*> grp;
+                for (size_t k = first; k < ready.size(); ++k) {
+                    LazyHeavy& g = *ready[k];
+                    const bool same = !taken[k] && g.kind == f.kind && g.in->ell == f.in->ell && g.in->deg == f.in->deg &&
+                                      g.in->npoly == f.in->npoly &&
+                                      (f.kind == LazyHeavy::Boot ? g.drop == f.drop : (g.a == f.a && g.b == f.b && g.coeffs == f.coeffs));
+                    if (same) {
+                        grp.push_back(&g);
+                        taken[k] = 1;
+                    }
+                }
+                CtVec in;
+                for (LazyHeavy* g : grp) in.push_back(g->in);
+                CtVec out = f.kind == LazyHeavy::Boot ? c->boot.bootstrap_batch(in, f.drop) : c->ev.eval_chebyshev_many(in, f.coeffs, f.a, f.b);
+                for (size_t k = 0; k < grp.size(); ++k) {
+                    grp[k]->result = out[k];
+                    grp[k]->done = true;
+                    grp[k]->in.reset();
+                }
+            }
+        }
+    } catch (...) {
+        for (auto& sp : pend)
+            if (!sp->done) {
+                sp->done = sp->failed = true;
+                sp->in.reset();
+                sp->in_heavy.reset();
+            }
+        throw;
+    }
+}
+// a handle to a deferred heavy operation on `a` (itself possibly deferred)
+static fhelin_ct* defer_heavy(fhelin_ctx* c, const fhelin_ct* a, const std::shared_ptr<LazyHeavy>& op) {
+    if (!a->p && a->heavy && !a->heavy->done) {
+        op->in_heavy = a->heavy;
+    } else {
+        op->in = ct_in(c, a);
+    }
+    c->pending_heavy.push_back(op);
+    auto* h = new fhelin_ct;
+    h->heavy = op;
+    h->owner = c;
+    return h;
+}
+static bool defer_ok(fhelin_ctx* c) { return c->lazy_heavy && c->plan.mode != 1 && c->ctx.stream == c->ctx.main_stream; }
+
 void force_many(fhelin_ctx* c, const fhelin_ct* const* v, int n) {
+    for (int i = 0; i < n; ++i)
+        if (v[i] && !v[i]->p && v[i]->heavy) force(c, v[i]);      // the first one evaluates everything pending
     std::vector<std::pair<LazyRows*, std::vector<int>>> groups;
     for (int i = 0; i < n; ++i) {
         const fhelin_ct* h = v[i];
@@ -319,7 +401,16 @@ int fhelin_eval_chebyshev(fhelin_ctx* c, const fhelin_ct* x, const double* coeff
     NEED(c && x && coeffs && out);
     FHELIN_TRY
     const std::vector<double> cf(coeffs, coeffs + n);
-    *out = wrap(c, run_heavy(c, x, [&](const CtPtr& in) { return c->ev.eval_chebyshev(in, cf, a, b); }));
+    if (defer_ok(c)) {
+        auto op = std::make_shared<LazyHeavy>();
+        op->kind = LazyHeavy::Cheb;
+        op->coeffs = cf;
+        op->a = a;
+        op->b = b;
+        *out = defer_heavy(c, x, op);
+    } else {
+        *out = wrap(c, run_heavy(c, x, [&](const CtPtr& in) { return c->ev.eval_chebyshev(in, cf, a, b); }));
+    }
     FHELIN_CATCH
 }
 int fhelin_eval_chebyshev_batch(fhelin_ctx* c, const fhelin_ct* const* xs, int32_t n, const double* coeffs, int32_t n_coeffs, double a,
@@ -342,11 +433,52 @@ int fhelin_bootstrap(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out) {
     // a bootstrap is a terminal for its input (two limbs are all it reads) and a source of the level plan for its output
     const int drop = c->plan.next_drop(c->boot.out_ell());
     if (c->plan.live(a->node, a->node_epoch)) c->plan.terminal(a->node, 2);
+    if (defer_ok(c)) {
+        if (!c->boot.ready()) throw Error(FHELIN_ERR_STATE, "EvalBootstrapSetup has not been called");
+        auto op = std::make_shared<LazyHeavy>();
+        op->kind = LazyHeavy::Boot;
+        op->drop = drop;
+        *out = defer_heavy(c, a, op);
+        return FHELIN_OK;
+    }
     *out = wrap(c, run_heavy(c, a, [&](const CtPtr& in) { return c->boot.bootstrap(in, drop); }));
     if (c->plan.live((*out)->node, (*out)->node_epoch)) {
         LevelPlan::Node& nd = c->plan.nodes[(*out)->node];
         nd.in.clear();
         nd.ordinal = c->plan.next_ordinal - 1;
+    }
+    FHELIN_CATCH
+}
+int fhelin_bootstrap_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** outs) {
+    NEED(c && v && outs && n >= 0);
+    FHELIN_TRY
+    // every ciphertext is a source of the level plan of its own (call order); those with the same planned drop share a batch
+    CtVec in = vec_of(c, v, n);
+    std::vector<int> drop(n);
+    for (int i = 0; i < n; ++i) {
+        drop[i] = c->plan.next_drop(c->boot.out_ell());
+        if (c->plan.live(v[i]->node, v[i]->node_epoch)) c->plan.terminal(v[i]->node, 2);
+    }
+    const int first_ordinal = c->plan.next_ordinal - n;
+    CtVec r(n);
+    std::vector<char> done(n, 0);
+    for (int i = 0; i < n; ++i) {
+        if (done[i]) continue;
+        std::vector<int> pick;
+        CtVec sub;
+        for (int k = i; k < n; ++k)
+            if (!done[k] && drop[k] == drop[i]) {
+                pick.push_back(k);
+                sub.push_back(in[k]);
+                done[k] = 1;
+            }
+        CtVec o = c->boot.bootstrap_batch(sub, drop[i]);
+        for (size_t k = 0; k < pick.size(); ++k) r[pick[k]] = o[k];
+    }
+    plan_inputs().clear();
+    for (int i = 0; i < n; ++i) {
+        outs[i] = wrap(c, r[i]);
+        if (c->plan.live(outs[i]->node, outs[i]->node_epoch)) c->plan.nodes[outs[i]->node].ordinal = first_ordinal + i;
     }
     FHELIN_CATCH
 }

@@ -208,7 +208,7 @@ int fhelin_ct_import_device(fhelin_ctx* c, const uint64_t* d_limbs, int32_t npol
 }
 int fhelin_ct_scale(const fhelin_ct* ct, double* scale_hi, double* scale_lo) {
     NEED(ct && scale_hi && scale_lo);
-    if (!ct->p && ct->lazy) {
+    if (!ct->p && (ct->lazy || ct->heavy)) {
         try {
             force(ct->owner, ct);
         } catch (const std::exception& e) {
@@ -222,7 +222,7 @@ int fhelin_ct_scale(const fhelin_ct* ct, double* scale_hi, double* scale_lo) {
 }
 int fhelin_ct_info(const fhelin_ct* ct, int32_t* npoly, int32_t* ell, int32_t* level, int32_t* deg, double* scale, int32_t* slots) {
     NEED(ct);
-    if (!ct->p && ct->lazy) {  // a deferred row: its shape is known only once evaluated
+    if (!ct->p && (ct->lazy || ct->heavy)) {  // a deferred row / heavy operation: its shape is known only once evaluated
         try {
             force(ct->owner, ct);
         } catch (const fhelin::Error& e) {

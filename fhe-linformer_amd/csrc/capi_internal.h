@@ -62,6 +62,25 @@ struct LevelPlan {
 std::vector<int>& plan_inputs();
 }  // namespace fhelin
 
+// Heavy single-ciphertext operations (bootstrap, Chebyshev evaluation) whose evaluation is DEFERRED until the result is read:
+// the reference's drivers issue them in loops over independent ciphertexts (the GELU containers, src/main.cpp:354-358: eval_gelu
+// then bootstrap per container; the two halves of affine-1, :313-314) and read the results only after the loop.  When the first
+// result is read, everything pending is evaluated in dependency order with the operations of one kind, one parameter set and
+// one input shape BATCHED (Evaluator::eval_chebyshev_many, Bootstrapper::bootstrap_batch): every launch then carries all of
+// them and the switching keys / plaintext diagonals are read once.  Each result holds exactly the residues the single call gives.
+// FHELIN_LAZY_HEAVY=0 (or a recording level-plan pass) evaluates at the call, on alternating worker lanes (run_heavy).
+namespace fhelin {
+struct LazyHeavy {
+    enum Kind { Cheb, Boot } kind = Boot;
+    CtPtr in;                               // the input, once it exists ...
+    std::shared_ptr<LazyHeavy> in_heavy;    // ... or the deferred operation that will produce it
+    std::vector<double> coeffs;             // Cheb
+    double a = 0, b = 0;
+    int drop = 0;                           // Boot: limbs left out under a level plan
+    CtPtr result;
+    bool done = false, failed = false;
+};
+}
 // opaque handle behind include/fhelin.h's `fhelin_ctx`
 struct fhelin_ctx {
     fhelin::Context ctx;
@@ -70,6 +89,8 @@ struct fhelin_ctx {
     fhelin::Composite comp;
     fhelin::Bootstrapper boot;
     bool lazy_rows = true;      // FHELIN_LAZY_ROWS
+    bool lazy_heavy = true;     // FHELIN_LAZY_HEAVY
+    std::vector<std::shared_ptr<fhelin::LazyHeavy>> pending_heavy;
     fhelin::LevelPlan plan;
     explicit fhelin_ctx(const fhelin::Params& p);
 };
@@ -97,6 +118,7 @@ struct LazyRows {
 struct fhelin_ct {
     mutable fhelin::CtPtr p;                          // null while the row is still deferred
     mutable std::shared_ptr<fhelin::LazyRows> lazy;
+    mutable std::shared_ptr<fhelin::LazyHeavy> heavy;   // a deferred bootstrap / Chebyshev evaluation
     int lazy_idx = 0;
     fhelin_ctx* owner = nullptr;
     int node = -1;                                    // level-plan recording: this value's node ...
@@ -114,7 +136,17 @@ void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx);
 // uses Q[0] only); a second one means the driver is walking over the rows (for (i...) output[i] = add(output[i],
 // inputs[i]), src/main.cpp:237-239): everything that is left is evaluated in one batched call instead of row by row.
 void force_group(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx);
+// evaluate every pending deferred heavy operation, batched (capi_composite.cpp)
+void flush_heavy(fhelin_ctx* c);
 inline void force(fhelin_ctx* c, const fhelin_ct* h) {
+    if (!h->p && h->heavy) {
+        if (!h->heavy->done) flush_heavy(c);
+        if (h->heavy->failed || !h->heavy->result)
+            throw Error(FHELIN_ERR_STATE, "a deferred bootstrap / polynomial evaluation this value depends on failed earlier");
+        h->p = h->heavy->result;
+        h->heavy.reset();
+        return;
+    }
     if (h->p || !h->lazy) return;
     LazyRows& g = *h->lazy;
     if (!g.done[h->lazy_idx]) force_group(c, g, std::vector<int>{h->lazy_idx});

@@ -666,6 +666,20 @@ std::vector<CtPtr> Evaluator::rotate_batch_impl(const std::vector<CtPtr>& vin, i
     auto it = rot_keys.find(g);
     if (it == rot_keys.end())
         throw Error(FHELIN_ERR_KEY, "no rotation key for index " + std::to_string(index) + " (EvalRotateKeyGen list)");
+    return rotate_galois_batch(vin, g, *it->second, accumulate);
+}
+
+std::vector<CtPtr> Evaluator::conjugate_batch(const std::vector<CtPtr>& v) {
+    if (!conj_key) throw Error(FHELIN_ERR_KEY, "no conjugation key");
+    return rotate_galois_batch(v, 2ull * c_.N - 1, *conj_key, false);
+}
+
+std::vector<CtPtr> Evaluator::rotate_galois_batch(const std::vector<CtPtr>& vin, u64 g, const EvalKey& key, bool accumulate) {
+    std::vector<CtPtr> out(vin.size());
+    if (vin.size() == 1) {
+        out[0] = raw_rotate(vin[0], g, key, accumulate);
+        return out;
+    }
     const u32* map = c_.automorph_map(g);
     // rows that share (level, degree, scale) go through one batched key switch; others form their own groups
     std::vector<char> done(vin.size(), 0);
@@ -686,12 +700,126 @@ std::vector<CtPtr> Evaluator::rotate_batch_impl(const std::vector<CtPtr>& vin, i
         const size_t pn = (size_t)ell * c_.N, ctw = 2 * pn;
         std::vector<CtPtr> o = new_ct_batch(B, 2, ell, chunk[0]->deg, chunk[0]->scale, chunk[0]->slots);
         const u64* base = chunk[0]->d;  // contiguous by construction (or a single ciphertext)
-        keyswitch_batch(B, base + pn, ctw, ell, *it->second, o[0]->d, ctw, base, nullptr, ctw, map, accumulate ? base : nullptr, ctw);
+        keyswitch_batch(B, base + pn, ctw, ell, key, o[0]->d, ctw, base, nullptr, ctw, map, accumulate ? base : nullptr, ctw);
         for (int b = 0; b < B; ++b) {
             o[b]->scale = vin[idx[b]]->scale;
             out[idx[b]] = o[b];
             done[idx[b]] = 1;
         }
+    }
+    return out;
+}
+
+std::vector<std::vector<CtPtr>> Evaluator::rotate_many_batch(const std::vector<CtPtr>& xs, const std::vector<int>& indices) {
+    std::vector<std::vector<CtPtr>> out(xs.size());
+    if (xs.empty()) return out;
+    bool uniform = xs.size() >= 2 && !c_.fuse_moddown && c_.K >= 1;
+    for (const CtPtr& x : xs)
+        uniform = uniform && x->npoly == 2 && x->ell == xs[0]->ell && x->deg == xs[0]->deg && x->slots == xs[0]->slots;
+    if (!uniform) {
+        for (size_t i = 0; i < xs.size(); ++i) out[i] = rotate_many(xs[i], indices);
+        return out;
+    }
+    const int ns = xs[0]->slots > 0 ? xs[0]->slots : (1 << c_.prm.log_slots);
+    std::vector<size_t> todo;
+    for (size_t i = 0; i < xs.size(); ++i) out[i].resize(indices.size());
+    for (size_t k = 0; k < indices.size(); ++k) {
+        if (indices[k] % ns == 0)
+            for (size_t i = 0; i < xs.size(); ++i) out[i][k] = xs[i];
+        else
+            todo.push_back(k);
+    }
+    const int R = (int)todo.size();
+    if (R == 0) return out;
+    std::vector<const EvalKey*> keys;
+    std::vector<const u32*> maps;
+    for (size_t k : todo) {
+        const u64 g = c_.galois_element(indices[k]);
+        auto it = rot_keys.find(g);
+        if (it == rot_keys.end())
+            throw Error(FHELIN_ERR_KEY, "no rotation key for index " + std::to_string(indices[k]) + " (EvalRotateKeyGen list)");
+        keys.push_back(it->second.get());
+        maps.push_back(c_.automorph_map(g));
+    }
+    const size_t N = c_.N;
+    const int K = c_.K, L1 = c_.L + 1, ell = xs[0]->ell;
+    const size_t pn = (size_t)ell * N, ctw = 2 * pn;
+    const LevelTables& lt = c_.lvl[ell];
+    const int nt = ell + K;
+    hipStream_t s = c_.stream;
+    // inputs per pass: the ModDown of a pass works on (inputs x R) rows
+    const size_t per_pass = (size_t)std::max(1, 160 / R);
+    for (size_t lo = 0; lo < xs.size(); lo += per_pass) {
+        const size_t hi = std::min(xs.size(), lo + per_pass);
+        const int B = (int)(hi - lo);
+        std::vector<CtPtr> in = make_contiguous(std::vector<CtPtr>(xs.begin() + lo, xs.begin() + hi), 6);
+        const u64* base = in[0]->d;
+        const int rows = B * R;
+        c_.stats.keyswitch += (u64)rows;
+        c_.stats.keyswitch_limbs += (u64)rows * ell;
+        // ModUp of the B inputs' c1, once
+        KsShape up{ell, K, c_.alpha, lt.beta, L1, B, ctw, 0, 0, 0};
+        u64* cc = c_.dalloc<u64>((size_t)B * ell * N);
+        {
+            LimbBatch ib{cc, B * ell, nullptr, 0, ell, base + pn};
+            if (B > 1) {
+                ib.src_group = ell;
+                ib.src_group_stride = ctw;
+            }
+            c_.ntt(ib, true);
+        }
+        u64* ext = c_.dalloc<u64>((size_t)B * lt.beta * nt * N);
+        launch_modup_conv(c_.dt, up, ext, cc, base + pn, lt.up_hatinv, lt.up_hatmod, s);
+        LimbBatch eb{ext, B * lt.beta * nt, lt.ext_limb_tab, 0, 1};
+        eb.tab_len = lt.beta * nt;
+        eb.lazy_out = true;
+        c_.ntt(eb, false, B * (lt.beta * nt - ell));
+        // inner products: per input, rows of <= MAX_ROWS indices with their own keys, all reading that input's digits
+        u64* accQ = c_.dalloc<u64>((size_t)rows * 2 * ell * N);
+        u64* accP = c_.dalloc<u64>((size_t)rows * 2 * K * N);
+        auto row_shape = [&](int first, int cnt) {
+            KsShape sh{ell, K, c_.alpha, lt.beta, L1, cnt, 0, ctw, 0, 0};
+            sh.per_row = 1;
+            sh.shared_input = 1;
+            for (int b = 0; b < cnt; ++b) {
+                sh.evk_row[b] = keys[first + b]->d;
+                sh.map_row[b] = maps[first + b];
+            }
+            return sh;
+        };
+        for (int i = 0; i < B; ++i)
+            for (int first = 0; first < R; first += KsShape::MAX_ROWS) {
+                const int cnt = std::min(R - first, (int)KsShape::MAX_ROWS);
+                const size_t row0 = (size_t)i * R + first;
+                launch_ks_inner(c_.dt, row_shape(first, cnt), accQ + row0 * 2 * ell * N, accP + row0 * 2 * K * N,
+                                ext + (size_t)i * lt.beta * nt * N, nullptr, base + pn + (size_t)i * ctw, s);
+            }
+        // ONE ModDown over all rows
+        KsShape dn{ell, K, c_.alpha, lt.beta, L1, rows, 0, ctw, 0, 0};
+        c_.ntt(LimbBatch{accP, rows * 2 * K, nullptr, L1, K}, true);
+        u64* conv = c_.dalloc<u64>((size_t)rows * 2 * ell * N);
+        launch_moddown_conv(c_.dt, dn, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
+        c_.ntt(LimbBatch{conv, rows * 2 * ell, nullptr, 0, ell}, false);
+        std::vector<CtPtr> o = new_ct_batch(rows, 2, ell, xs[lo]->deg, xs[lo]->scale, xs[lo]->slots);
+        for (int i = 0; i < B; ++i)
+            for (int first = 0; first < R; first += KsShape::MAX_ROWS) {
+                const int cnt = std::min(R - first, (int)KsShape::MAX_ROWS);
+                const size_t row0 = (size_t)i * R + first;
+                // the epilogue adds the input's c0 (gathered through each row's map): add_stride 0 = the same c0 for every row
+                launch_moddown_finish(c_.dt, row_shape(first, cnt), o[row0]->d, accQ + row0 * 2 * ell * N, conv + row0 * 2 * ell * N, c_.d_pinv,
+                                      base + (size_t)i * ctw, nullptr, nullptr, nullptr, s);
+            }
+        launch_ok("rotate_many_batch");
+        c_.pool.free(cc);
+        c_.pool.free(ext);
+        c_.pool.free(accQ);
+        c_.pool.free(accP);
+        c_.pool.free(conv);
+        for (int i = 0; i < B; ++i)
+            for (int r = 0; r < R; ++r) {
+                o[(size_t)i * R + r]->scale = xs[lo + i]->scale;
+                out[lo + i][todo[r]] = o[(size_t)i * R + r];
+            }
     }
     return out;
 }
@@ -1042,6 +1170,34 @@ CtPtr Evaluator::raw_modraise(const CtPtr& a, int new_ell) {
     c_.ntt(LimbBatch{up->d, P * new_ell, nullptr, 0, new_ell}, false);
     launch_ok("modraise");
     c_.pool.free(coef);
+    return up;
+}
+
+std::vector<CtPtr> Evaluator::raw_modraise_batch(const std::vector<CtPtr>& vin, int new_ell) {
+    if (vin.size() <= 1) {
+        std::vector<CtPtr> out;
+        for (const CtPtr& a : vin) out.push_back(raw_modraise(a, new_ell));
+        return out;
+    }
+    for (const CtPtr& a : vin)
+        if (a->ell != 1 || a->npoly != vin[0]->npoly) throw Error(FHELIN_ERR_STATE, "modraise: the inputs must have exactly one limb (q0) and one shape");
+    if (new_ell < 1 || new_ell > c_.L + 1) throw Error(FHELIN_ERR_ARG, "modraise: bad target limb count");
+    std::vector<CtPtr> in = make_contiguous(vin, 7);
+    const size_t N = c_.N;
+    const int B = (int)in.size(), P = in[0]->npoly * B;
+    hipStream_t s = c_.stream;
+    u64* coef = c_.dalloc<u64>((size_t)P * N);
+    c_.ntt(LimbBatch{coef, P, nullptr, 0, 1, in[0]->d}, true);
+    std::vector<CtPtr> up = new_ct_batch(B, in[0]->npoly, new_ell, 1, 0, in[0]->slots);
+    launch_modraise(c_.dt, up[0]->d, coef, P, 0, new_ell, s);
+    c_.ntt(LimbBatch{up[0]->d, P * new_ell, nullptr, 0, new_ell}, false);
+    launch_ok("modraise_batch");
+    c_.pool.free(coef);
+    for (int b = 0; b < B; ++b) {
+        up[b]->deg = vin[b]->deg;
+        up[b]->scale = vin[b]->scale;
+        up[b]->slots = vin[b]->slots;
+    }
     return up;
 }
 

@@ -129,6 +129,15 @@ public:
     std::vector<CtPtr> rotate_each_sum_rows(const std::vector<std::vector<CtPtr>>& rows, const std::vector<int>& indices);
     // hoisted rotations: rot(a, i) for every i in `indices` with ONE ModUp of a (results identical to rotate(a, i))
     std::vector<CtPtr> rotate_many(const CtPtr& a, const std::vector<int>& indices);
+    // the same for several ciphertexts of one shape and ONE index list (the baby steps of a batch of bootstraps): one ModUp over
+    // all inputs, per input the inner products of all indices, one ModDown over all inputs x indices.  out[i][k] holds exactly
+    // the residues of rotate(xs[i], indices[k]).
+    std::vector<std::vector<CtPtr>> rotate_many_batch(const std::vector<CtPtr>& xs, const std::vector<int>& indices);
+    // rows of identical shape through one batched key switch with an explicit Galois element and key (conjugation, the SubSum
+    // rotations by multiples of the slot count); accumulate: v_i + sigma_g(v_i)
+    std::vector<CtPtr> rotate_galois_batch(const std::vector<CtPtr>& v, u64 galois, const EvalKey& key, bool accumulate);
+    std::vector<CtPtr> conjugate_batch(const std::vector<CtPtr>& v);
+    std::vector<CtPtr> raw_modraise_batch(const std::vector<CtPtr>& v, int new_ell);   // raw_modraise over many one-limb ciphertexts
     // rot(v[i], indices[i]) for ciphertexts of identical shape, one batched key switch per chunk of rows
     std::vector<CtPtr> rotate_each(const std::vector<CtPtr>& v, const std::vector<int>& indices);
     // batched leveled ops over independent ciphertexts of identical (level, degree, scale): one launch set per op

@@ -14,7 +14,8 @@
  *    (a hipStream_t travels as void*).
  *  - residue data is uint64_t, limb-major: poly[limb][N]; ciphertext = poly 0 then poly 1 (then 2).
  *  - limb ids: Q limbs 0..L, special (P) limbs L+1..L+k.
- *  - device work is asynchronous on the context's stream; fhelin_sync() waits for it.
+ *  - device work is asynchronous on the context's stream; fhelin_sync() waits for it (and first issues the deferred
+ *    bootstraps / polynomial evaluations whose results nobody has read yet, see fhelin_bootstrap_batch).
  *  - there is NO CPU fallback: on a host-only context (device < 0) every evaluation entry point
  *    fails with FHELIN_ERR_NO_DEVICE.
  */
@@ -273,6 +274,11 @@ int fhelin_eval_chebyshev_batch(fhelin_ctx* c, const fhelin_ct* const* xs, int32
 /* CKKS bootstrapping: EvalBootstrapSetup/KeyGen :238-239 and EvalBootstrap :445 */
 int fhelin_bootstrap_setup(fhelin_ctx* c, int32_t level_budget_enc, int32_t level_budget_dec, int32_t slots);
 int fhelin_bootstrap(fhelin_ctx* c, const fhelin_ct* a, fhelin_ct** out);
+/* EvalBootstrap on n independent ciphertexts (the reference's loop over the GELU containers, src/main.cpp:354-358; the two
+ * halves of affine-1, :313-314): every launch of the pipeline carries all of them.  outs[i] holds exactly the residues of
+ * fhelin_bootstrap(v[i]).  fhelin_bootstrap / fhelin_eval_chebyshev calls issued back to back on independent ciphertexts are
+ * batched the same way by themselves: their results are evaluated when first read (FHELIN_LAZY_HEAVY=0: at the call). */
+int fhelin_bootstrap_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, fhelin_ct** outs);
 /* approximation parameters (before setup): |I| bound K, double-angle count R, cosine-fit degree, message correction 2^-c */
 int fhelin_bootstrap_config(fhelin_ctx* c, int32_t K, int32_t R, int32_t cheb_degree, int32_t correction);
 /* test hook: stop after 1 = ModRaise(+SubSum), 2 = CoeffsToSlots (real part), 3 = approximate mod (real part) */

@@ -73,8 +73,11 @@ def test_async_heavy_ops_match_the_synchronous_path(fa, monkeypatch):
     host while its consumer may still be running."""
     cheb = [0.0, 1.0, 0.0, -0.25, 0.0, 0.05, 0.0, -0.01]
 
-    def run(async_on):
-        monkeypatch.setenv("FHELIN_ASYNC", "1" if async_on else "0")
+    def run(mode):
+        # "lanes": at the call, on alternating worker lanes; "sync": at the call, on the main stream; "deferred" (default): when
+        # the results are read, batched (three Chebyshev evaluations in one call, then three bootstraps in one call)
+        monkeypatch.setenv("FHELIN_LAZY_HEAVY", "1" if mode == "deferred" else "0")
+        monkeypatch.setenv("FHELIN_ASYNC", "0" if mode == "sync" else "1")
         eng = _engine(fa, 10)
         try:
             rng = np.random.default_rng(11)
@@ -91,10 +94,11 @@ def test_async_heavy_ops_match_the_synchronous_path(fa, monkeypatch):
         finally:
             eng.close()
 
-    a, dec, ms = run(True)
-    b, _, _ = run(False)
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
+    a, dec, ms = run("lanes")
+    b, _, _ = run("sync")
+    d, _, _ = run("deferred")
+    for x, y, z in zip(a, b, d):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
     u = [np.polynomial.chebyshev.chebval(m, [cheb[0] / 2] + cheb[1:]) for m in ms]
     for d, w in zip(dec, u):
         assert np.max(np.abs(d - w)) < 5e-4
@@ -135,3 +139,37 @@ def test_grouped_inner_sums_give_the_same_residues(fa, monkeypatch):
         finally:
             eng.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("log_slots", [10, 11])
+def test_batched_bootstrap_gives_the_single_bootstraps_residues(fa, log_slots):
+    """fhelin_bootstrap_batch (the GELU containers / the two affine-1 halves of a sample in one pipeline: one ModUp over the batch
+    per baby-step set, batched giant steps, batched EvalMod) == fhelin_bootstrap one by one, residue for residue, for sparse
+    and full packing, inputs at different levels and scales, with and without a planned drop; the deferred form (bootstraps
+    issued back to back, results read afterwards) takes the same batched path"""
+    eng = _engine(fa, log_slots)
+    try:
+        n = 1 << log_slots
+        rng = np.random.default_rng(21)
+        ms = [rng.uniform(-1, 1, n) for _ in range(3)]
+        cts = [eng.encrypt(ms[0], level=eng.n_q - 3), eng.encrypt(ms[1], level=eng.n_q - 2), eng.mult_real(eng.encrypt(ms[2], level=eng.n_q - 4), 0.5)]
+        ms[2] = 0.5 * ms[2]
+        single = [eng.bootstrap_drop(c, 0).export() for c in cts]
+        got = eng.bootstrap_batch(cts)
+        for g, s, m in zip(got, single, ms):
+            assert np.array_equal(g.export(), s)
+            assert np.max(np.abs(eng.decrypt(g) - m)) < 2e-4
+        lazy = [eng.bootstrap(c) for c in cts]                   # deferred: nothing runs until a result is read
+        before = eng.stats()["bootstrap"]
+        assert np.array_equal(lazy[1].export(), single[1])      # ... then all three, as one batch
+        assert eng.stats()["bootstrap"] == before + 3
+        assert np.array_equal(lazy[0].export(), single[0]) and np.array_equal(lazy[2].export(), single[2])
+        dropped = [eng.bootstrap_drop(c, 3).export() for c in cts[:2]]
+        eng.set_level_plan([eng.n_q - 15 - 3] * 2)
+        eng.level_plan_begin("apply")
+        planned = eng.bootstrap_batch(cts[:2])
+        eng.level_plan_begin("off")
+        for g, s in zip(planned, dropped):
+            assert np.array_equal(g.export(), s)
+    finally:
+        eng.close()
