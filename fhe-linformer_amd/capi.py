@@ -80,6 +80,7 @@ def load_library():
         "fhelin_ctx_scaling_factors": (i32, [vp, C.POINTER(C.c_double), i32]),
         "fhelin_ctx_set_stream": (i32, [vp, vp]),
         "fhelin_ctx_set_lazy_rows": (i32, [vp, i32]),
+        "fhelin_ct_force": (i32, [vp, C.POINTER(vp), i32]),
         "fhelin_level_plan_begin": (i32, [vp, i32]),
         "fhelin_level_plan_seek": (i32, [vp, i32]),
         "fhelin_level_plan_end": (i32, [vp, C.POINTER(i32)]),
@@ -268,6 +269,12 @@ class Engine:
         self._ck(self.lib.fhelin_ctx_set_lazy_rows(self.h, 1 if on else 0))
 
     # level plan (include/fhelin.h fhelin_level_plan_*): record one pass of a straight-line driver, apply to later ones
+    def force(self, cts):
+        """evaluate exactly the deferred rows among `cts` now, one batched call per producing call"""
+        cts = list(cts)
+        if cts:
+            self._ck(self.lib.fhelin_ct_force(self.h, self._harr(cts), len(cts)))
+
     def level_plan_begin(self, mode, first_source=0):
         """mode: "record", "apply" or "off"; the pass starts at the program's first source unless first_source says otherwise
         (apply only: a server pass that starts after the client's encryptions)"""

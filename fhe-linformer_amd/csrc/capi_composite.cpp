@@ -172,6 +172,23 @@ static PtPtr opt(const fhelin_pt* p) { return p ? p->p : PtPtr(); }
 
 extern "C" {
 
+int fhelin_ct_force(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n) {
+    NEED(c && (v || n == 0) && n >= 0);
+    FHELIN_TRY
+    std::vector<std::pair<LazyRows*, std::vector<int>>> groups;
+    for (int i = 0; i < n; ++i) {
+        const fhelin_ct* h = v[i];
+        if (!h) throw Error(FHELIN_ERR_ARG, "null ciphertext handle in array");
+        if (!h->p && h->heavy) force(c, h);
+        if (h->p || !h->lazy) continue;
+        LazyRows* g = h->lazy.get();
+        auto it = std::find_if(groups.begin(), groups.end(), [&](const auto& e) { return e.first == g; });
+        if (it == groups.end()) it = groups.insert(groups.end(), {g, {}});
+        if (std::find(it->second.begin(), it->second.end(), h->lazy_idx) == it->second.end()) it->second.push_back(h->lazy_idx);
+    }
+    for (auto& e : groups) force_rows(c, *e.first, e.second);   // exactly these rows (force_group would widen a second partial read)
+    FHELIN_CATCH
+}
 int fhelin_rotate_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t index, fhelin_ct** outs) {
     NEED(c && v && outs && n >= 0);
     FHELIN_TRY

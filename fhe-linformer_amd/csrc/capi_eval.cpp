@@ -113,8 +113,11 @@ int fhelin_encrypt_batch(fhelin_ctx* c, const double* vals, int32_t n_vec, int32
     FHELIN_TRY
     // every vector is a source of the level plan of its own: vectors that the plan starts at the same level go through
     // the batched encryptor together
+    if (n_vec < 0 || n_per < 0) throw Error(FHELIN_ERR_ARG, "encrypt_batch: negative count");
+    if (level < 0 || level > c->ctx.L) throw Error(FHELIN_ERR_ARG, "encrypt_batch: level out of range");
     std::vector<int> drop(n_vec);
-    for (int i = 0; i < n_vec; ++i) drop[i] = std::min(c->ctx.L - level, c->plan.next_drop(c->ctx.L + 1 - level));
+    for (int i = 0; i < n_vec; ++i)
+        drop[i] = std::max(0, std::min(c->ctx.L - level, c->plan.next_drop(c->ctx.L + 1 - level)));
     const int first_ordinal = c->plan.next_ordinal - n_vec;
     std::vector<CtPtr> r(n_vec);
     std::vector<char> seen(n_vec, 0);

@@ -509,6 +509,8 @@ void Client::encrypt_encoded(const u64* enc, size_t enc_stride, int n_vec, int e
     launch_encrypt_combine(c.dt, cts[0]->d, pk, rnd, rnd + (size_t)n_vec * pn, rnd + (size_t)2 * n_vec * pn, enc, ell, L1, enc_stride, n_vec,
                            c.stream);
     hip_check(hipGetLastError(), "encrypt kernels");
+    // the encryption randomness (u, e0, e1) does not stay behind in a recycled pool block
+    hip_check(hipMemsetAsync(rnd, 0, (size_t)3 * n_vec * pn * sizeof(u64), c.stream), "hipMemsetAsync(encryption randomness)");
     c.pool.free(rnd);
     for (auto& ct : cts) out.push_back(ct);
 }

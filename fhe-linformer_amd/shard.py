@@ -35,6 +35,14 @@ def gather_results(dist, local, max_rows):
     return [o.cpu().numpy()[: int(m[0])] for o, m in zip(out, metas)]
 
 
+def _payload_ready(dev):
+    """the engine imports gathered residues on ITS OWN HIP stream: the collective's output must be complete on torch's
+    stream first (fhelin_ct_import_device / _export_device are host-synchronous on the library stream only)"""
+    if dev.type == "cuda":
+        import torch
+        torch.cuda.current_stream().synchronize()
+
+
 def max_over_ranks(dist, value):
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=_device(dist))
@@ -61,6 +69,10 @@ class EngineTransport:
 
     def __init__(self, eng, device=False):
         self.eng, self.device = eng, device
+
+    def force(self, cts):
+        """the rows this rank owns are evaluated in ONE batched call, and only they (deferred rows of the engine)"""
+        self.eng.force(cts)
 
     def pack(self, ct):
         inf = ct.info()
@@ -91,6 +103,8 @@ def all_gather_rows(dist, transport, local, n_rows, world):
     rank = dist.get_rank()
     per = -(-n_rows // world)
     ids = sample_ids(n_rows, world, rank)
+    if hasattr(transport, "force"):
+        transport.force([local[i] for i in ids])
     packed = [transport.pack(local[i]) for i in ids]
     dev = _device(dist)
     meta = torch.zeros((per, 8), dtype=torch.float64, device=dev)
@@ -108,6 +122,7 @@ def all_gather_rows(dist, transport, local, n_rows, world):
     bufs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(metas, meta)
     dist.all_gather(bufs, buf)
+    _payload_ready(dev)
     out = [None] * n_rows
     for r in range(world):
         for k, i in enumerate(sample_ids(n_rows, world, r)):
@@ -116,19 +131,73 @@ def all_gather_rows(dist, transport, local, n_rows, world):
     return out
 
 
+class _ShardedRows(list):
+    """Rows of a row loop whose evaluation is deferred by the engine (plaintext-weight matmulRE / matmulCR, unwrapExpanded): the
+    sharded evaluation + all-gather happens only when the driver turns out to read the rows.  The reference's CLS-only driver
+    computes all S query projections and all S final token expansions and reads ONE of each (src/main.cpp:183,:196,:416-424):
+    a single row read is evaluated locally (every rank runs the same driver, so every rank evaluates that one row), nothing is
+    split, nothing is gathered.  The second distinct access — another index, a slice, an iteration, a hand-over to another
+    call — means the driver walks the rows: each rank then evaluates the rows it owns (one batched call) and ONE all-gather puts
+    all of them on every rank."""
+
+    def __init__(self, ctl, rows):
+        super().__init__(rows)
+        self._ctl, self._single, self._done = ctl, None, False
+
+    def _materialize(self):
+        if not self._done:
+            self._done = True
+            n = super().__len__()
+            ids = self._ctl._mine(n)
+            got = self._ctl._gather({i: list.__getitem__(self, i) for i in ids}, n)
+            for i in range(n):
+                list.__setitem__(self, i, got[i])
+
+    def __getitem__(self, i):
+        if not self._done:
+            if isinstance(i, int) and self._single in (None, i % super().__len__()):
+                self._single = i % super().__len__()
+                return list.__getitem__(self, i)
+            self._materialize()
+        return list.__getitem__(self, i)
+
+    def __iter__(self):
+        self._materialize()
+        return list.__iter__(self)
+
+    def __add__(self, other):
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+
 class RowShardedController:
     """Batch-1 latency on `world` GPUs: every rank holds the same keys and runs the same driver; the row loops of the
     reference's matmul* / unwrap* methods (src/FHEController.cpp:872,888,904,918,949,963,985,1001,1089,1115) are split
     over the ranks with `sample_ids`, each rank evaluates only its rows, and one all-gather per call puts all rows back on
     every rank (the driver's next call — a wrapUp*, a bootstrap, the next matmul — is replicated).  With the engine's
-    deferred rows the split costs nothing extra: a rank simply never reads the rows it does not own.
+    deferred rows a rank evaluates exactly the rows it owns (fhelin_ct_force: one batched call) before it packs them; calls
+    whose rows are deferred return _ShardedRows: nothing is split or gathered until the driver reads more than one row.
     Calls with fewer rows than `min_rows` stay replicated."""
 
-    def __init__(self, inner, dist, transport, min_rows=8):
+    def __init__(self, inner, dist, transport, min_rows=8, counter=None):
         self.c, self.dist, self.t = inner, dist, transport
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.min_rows = min_rows
         self.gathers = 0
+        self.gather_rows = []      # rows per gather, in call order
+        # counter() -> a running operation count (e.g. the engine's key switches): row_ops accumulates what this rank spent
+        # evaluating the rows it owns, so that a test can check the split against an unsharded pass
+        self.counter, self.row_ops = counter, 0
+
+    def _counted(self, fn):
+        if self.counter is None:
+            return fn()
+        before = self.counter()
+        r = fn()
+        self.row_ops += self.counter() - before
+        return r
 
     def __getattr__(self, name):            # everything that is not a row loop: replicated, as the inner controller does it
         return getattr(self.c, name)
@@ -138,6 +207,9 @@ class RowShardedController:
 
     def _gather(self, local, n):
         self.gathers += 1
+        self.gather_rows.append(n)
+        if hasattr(self.t, "force"):
+            self._counted(lambda: self.t.force(list(local.values())))
         return all_gather_rows(self.dist, self.t, local, n, self.world)
 
     def _rows(self, n, all_rows_fn, subset_fn=None):
@@ -147,9 +219,11 @@ class RowShardedController:
             return all_rows_fn()
         ids = self._mine(n)
         if subset_fn is not None:
-            got = subset_fn(ids)
+            got = self._counted(lambda: subset_fn(ids))
             return self._gather(dict(zip(ids, got)), n)
         rows = all_rows_fn()
+        if hasattr(self.t, "force"):            # the engine defers these rows: split and gather only if the driver reads them
+            return _ShardedRows(self, rows)
         return self._gather({i: rows[i] for i in ids}, n)
 
     def matmulRE(self, rows, w, bias=None, row_size=128, padding=128):
@@ -177,7 +251,7 @@ class RowShardedController:
             return self.c.unwrapRepeatedLarge(cs, n)
         ids = self._mine(n)
         if hasattr(self.c, "unwrapRepeatedLarge_range"):
-            mine = self.c.unwrapRepeatedLarge_range(cs, n, ids[0], len(ids)) if ids else []
+            mine = self._counted(lambda: self.c.unwrapRepeatedLarge_range(cs, n, ids[0], len(ids))) if ids else []
         else:
             allr = self.c.unwrapRepeatedLarge(cs, n)
             mine = [allr[i] for i in ids]
@@ -185,6 +259,7 @@ class RowShardedController:
         # 4 ciphertexts per token: gather them as 4n rows owned in blocks of 4
         out = all_gather_rows_blocked(self.dist, self.t, flat, n, self.world, 4)
         self.gathers += 1
+        self.gather_rows.append(4 * n)
         return [out[4 * i: 4 * i + 4] for i in range(n)]
 
 
@@ -214,6 +289,7 @@ def all_gather_rows_blocked(dist, transport, local, n_groups, world, group):
     bufs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(metas, meta)
     dist.all_gather(bufs, buf)
+    _payload_ready(dev)
     out = [None] * (n_groups * group)
     for r in range(world):
         idx = [g * group + k for g in sample_ids(n_groups, world, r) for k in range(group)]

@@ -29,7 +29,10 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <fcntl.h>
 #include <fstream>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <functional>
 #include <iomanip>
 #include <iostream>
@@ -201,7 +204,15 @@ public:
         // the secret goes to its own file, as in the reference (:80-86)
         uint8_t seed[32];
         fhelin_shim::check(fhelin_ctx_secret_seed(context, seed), "Serialize(secret)");
-        ofstream sk("../" + parameters_folder + "/secret-key.txt", ios::out | ios::binary);
+        const string sk_path = "../" + parameters_folder + "/secret-key.txt";
+        {   // owner-only from the start (the reference leaves its secret-key.txt to the umask)
+            const int fd = ::open(sk_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+            if (fd >= 0) {
+                (void)::fchmod(fd, 0600);
+                ::close(fd);
+            }
+        }
+        ofstream sk(sk_path, ios::out | ios::binary);
         if (!sk.is_open()) {
             cerr << "Error writing serialization of private key to secret-key.txt" << endl;
             exit(1);

@@ -82,6 +82,9 @@ int fhelin_ctx_set_stream(fhelin_ctx* c, void* hip_stream);                     
  * operation takes) and never if nobody reads them: the reference's drivers compute whole row sets and then use one row
  * (src/main.cpp:183,:196; :416-424).  A forced row holds exactly the residues eager evaluation gives. */
 int fhelin_ctx_set_lazy_rows(fhelin_ctx* c, int32_t on);
+/* evaluate EXACTLY the deferred rows among v[0..n) now, in one batched call per producing call (a rank of a row-sharded run
+ * evaluates the rows it owns and nothing else); handles that are not deferred are left alone */
+int fhelin_ct_force(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n);
 /* Level plan (profile-guided; off unless asked for).  The reference's drivers are straight-line programs (src/main.cpp:145-475):
  * which ciphertext meets which, and how many limbs every call consumes, does not depend on the data.  A pass run with
  * fhelin_level_plan_begin(ctx, 1) RECORDS, for every handle this boundary gives out, the handles the producing call read

@@ -14,6 +14,11 @@ def short(n):
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 want = sys.argv[2:]
+# TRACE_WINDOW_S=<seconds>: only the launches of the last so many seconds of the trace (the timed passes of a bench run)
+import os
+if os.environ.get("TRACE_WINDOW_S"):
+    tend = max(int(r['End_Timestamp']) for r in rows)
+    rows = [r for r in rows if int(r['Start_Timestamp']) > tend - float(os.environ["TRACE_WINDOW_S"]) * 1e9]
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     k = short(r['Kernel_Name'])
@@ -32,3 +37,16 @@ for k in sorted(tot, key=lambda x: -tot[x]):
     for (kk, g, w), (c, us) in sorted(agg.items(), key=lambda x: -x[1][1]):
         if kk == k:
             print(f"    grid {str(g):20s} wg {w:4d} launches {c:6d} avg {us/c:8.1f} us  total {us/1e3:8.2f} ms")
+
+# size classes over the selected kernels: where the launches sit and what a workgroup costs there
+cls = collections.defaultdict(lambda: [0, 0, 0.0])
+for (k, g, w), (c, us) in agg.items():
+    n = g[0] * g[1] * g[2]
+    b = 0 if n < 512 else 1 if n < 1024 else 2 if n < 2048 else 3 if n < 4096 else 4 if n < 8192 else 5
+    cls[b][0] += c
+    cls[b][1] += c * n
+    cls[b][2] += us
+names = ["<512", "512-1023", "1024-2047", "2048-4095", "4096-8191", ">=8192"]
+print("workgroups per launch: launches, total ms, ns per workgroup")
+for b in sorted(cls):
+    print(f"    {names[b]:10s} {cls[b][0]:7d} {cls[b][2]/1e3:9.2f} ms {cls[b][2]*1e3/max(1, cls[b][1]):7.1f} ns/wg")
