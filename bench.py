@@ -52,6 +52,8 @@ def parse():
                     "unwrap loops split over the ranks (all-gather of ciphertext rows over RCCL/xGMI per row loop)")
     ap.add_argument("--no-ops", action="store_true", help="skip the short leaf-op section of a forward run")
     ap.add_argument("--no-level-plan", action="store_true", help="run every pass at the levels the driver asks for (no recorded level plan)")
+    ap.add_argument("--inflight", type=int, default=2, help="after the timed region (one sample in flight: `value`), also measure the "
+                    "throughput with this many samples in flight on the GPU, one engine (context, stream, host thread) each; 0/1: skip")
     ap.add_argument("--forward-only", action="store_true", help="profiling runs: only the timed forward passes (no eager comparison, "
                     "no NTT / op sections, no CPU leg); prints a reduced line without `roofline`")
     ap.add_argument("--key-seed", type=int, default=2024, help="deterministic key seed, the same on every rank (replicated keys)")
@@ -187,7 +189,38 @@ def cpu_forward_baseline(eng, orc, np, stats, seconds, cores):
             "ct_x_pt": (lambda: [orc.mul(c_pt[p], c_pt[0], eng.q[:ell_pt]) for p in range(2)], stats["ct_pt_mult"], ell_pt),
         }
         out = {}
-        for label, threads, budget in (("all", cores, 0.6 * seconds), ("single", 1, 0.4 * seconds)):
+        # one REAL composite stage timed end to end on the CPU port (not extrapolated): a matmulRE row as the library runs it by
+        # default - ct x pt, rescale, rotsum(128,128) as merged key switches {s..7s},{8s..56s},{64s}, + bias
+        # (reference src/FHEController.cpp:869-883) - through oracle/residue_eval.py on the exported rotation keys
+        try:
+            from oracle.residue_eval import ResidueEvaluator, RCt
+            idx = [128 * m for m in range(1, 8)] + [1024 * m for m in range(1, 8)] + [8192]
+            keys = {r: eng.key_export(1, r) for r in idx}
+            rev = ResidueEvaluator(eng.q, eng.p, eng.psi_q, eng.psi_p, eng.alpha, eng.log_n, keys, eng.params.log_slots)
+            ns = 1 << eng.params.log_slots
+            wpt, bpt = eng.encode(rng.uniform(-1, 1, ns) / 8), eng.encode(rng.uniform(-1, 1, ns))
+            cache = {}
+
+            def enc_of(pt):
+                def f(ell, sc):
+                    k = (id(pt), ell, float(sc))
+                    if k not in cache:
+                        cache[k] = eng.pt_export(pt, ell, sc)
+                    return cache[k]
+                return f
+            ell_row = min(eng.n_q, ell_ks + 1)
+            row = RCt(ct(ell_row), 1, rev.sf[eng.n_q - ell_row])
+            orc.set_threads(cores)
+            fn = lambda: rev.matmul_pt([row], enc_of(wpt), enc_of(bpt), 128, 128)
+            per, n = _timed(fn, 0.15 * seconds)
+            out["composite"] = {"stage": "matmulRE row: ct x pt, rescale, rotsum(128,128) as three merged key switches, + bias "
+                                         "(src/FHEController.cpp:869-883), timed end to end on the CPU port",
+                                "ell": ell_row, "cores": cores, "ms_per_row": round(per * 1e3, 2), "rows_timed": n,
+                                "ms_for_the_130_rows_of_one_call": round(per * 1e3 * 130, 1)}
+            del keys, rev, cache
+        except Exception as ex:           # a diagnostic leg: never fail the bench line over it
+            out["composite"] = {"error": repr(ex)}
+        for label, threads, budget in (("all", cores, 0.5 * seconds), ("single", 1, 0.35 * seconds)):
             orc.set_threads(threads)
             total, detail = 0.0, {}
             for name, (fn, count, ell) in ops.items():
@@ -263,6 +296,64 @@ def ops_section(eng, np, ells=(24, 16, 8), batch=8, reps=10, big_rows=128, short
             del rows
         del xs, ys, prods
     return recs
+
+
+def inflight_section(fa, lf, pf, np, eng, ctl, w, S, args, use_plan, n_src, plan, passes=3):
+    """K samples in flight on ONE GPU: K engines (contexts with their own HIP stream, the same replicated keys), one host
+    thread each, every engine running the same driver on its own samples.  The single-ciphertext chains of one sample
+    (Chebyshev evaluations, the pooler's bootstrap: launches that fill a fraction of the GPU) overlap with the batched row
+    loops of another.  Returns ms per sample over K x passes samples, and the same engines one after the other."""
+    import threading
+    K = args.inflight
+    eng.trim()                                   # the first engine's pool holds the timed region's samples: hand the memory back
+    engines = [(eng, ctl)]
+    for k in range(1, K):
+        e = fa.Engine("bench", device=eng.params.device, seed=args.key_seed, log_n=args.log_n, n_q=eng.n_q, n_p=eng.n_p)
+        e.keygen()
+        e.gen_relin_key()
+        e.gen_rotation_keys(fa.circuit_rotation_indices())
+        e.bootstrap_setup(3, 3, 16384)
+        if use_plan:
+            e.set_level_plan(plan)               # the plan is a property of the driver program, not of the engine
+        engines.append((e, lf.GpuController(e)))
+    work = []
+    for k, (e, c) in enumerate(engines):
+        enc = []
+        for i in range(passes + 1):
+            if use_plan:
+                e.level_plan_begin("apply")
+            enc.append(lf.encrypt_inputs(c, *pf.client_inputs(w, pf.synthetic_tokens(S, 8000 + 100 * k + i))))
+        e.sync()
+        work.append(enc)
+
+    def run(k, lo, hi):
+        e, c = engines[k]
+        for i in range(lo, hi):
+            if use_plan:
+                e.level_plan_begin("apply", first_source=n_src)
+            e.decrypt(lf.forward_encrypted(c, w, work[k][i]))
+        e.sync()
+
+    for k in range(K):
+        run(k, 0, 1)
+    t0 = time.perf_counter()
+    for k in range(K):
+        run(k, 1, passes + 1)
+    serial = (time.perf_counter() - t0) * 1e3 / (K * passes)
+    th = [threading.Thread(target=run, args=(k, 1, passes + 1)) for k in range(K)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    conc = (time.perf_counter() - t0) * 1e3 / (K * passes)
+    work = None
+    for e, _ in engines[1:]:
+        e.close()
+    return {"samples_in_flight": K, "ms_per_sample": round(conc, 2), "same_engines_one_at_a_time_ms_per_sample": round(serial, 2),
+            "samples": K * passes,
+            "note": "throughput figure: K engines (context + HIP stream + host thread each, replicated keys) on ONE GPU; per-sample latency is "
+                    "about K x this.  `value` is the one-sample-at-a-time pass."}
 
 
 def main():
@@ -472,6 +563,10 @@ def main():
         for _, enc in samples:
             del enc
         samples = None
+        # ---- secondary figure: K samples in flight on the one GPU (throughput; `value` above stays the one-sample-at-a-time pass)
+        fwd["inflight"] = None
+        if args.inflight > 1 and world == 1 and not row_mode:
+            fwd["inflight"] = inflight_section(fa, lf, pf, np, eng, ctl, w, S, args, use_plan, n_client_sources, plan)
 
     # ---- NTT section (second headline metric + roofline of the dominant kernel) -------------------------
     if dist:
@@ -554,6 +649,7 @@ def main():
                                "deferred_rows=off,level_plan=off (the reference's literal op sequence at its own levels)": round(fwd["literal_ms"], 2),
                                "how": "value: the timed region (steps x passes, max over ranks); the other cells: 2 passes each after one untimed "
                                       "pass, same build, same process, after the timed region"},
+                           "throughput_with_samples_in_flight": fwd["inflight"],
                            "client_ingest_ms_per_sample": round(fwd["client_ms"], 2),
                            "client_ingest_note": "encode + encrypt of the sample's 194 inputs into pool-owned memory (3 timed repeats); "
                                                  "first-touch figure below = the same while the pool grows through hipMalloc because "
@@ -593,7 +689,7 @@ def main():
                               f"rotation, rescale and ct x pt product timed for {args.cpu_seconds:.0f}s in all at N=2^{eng.log_n} at the mean level "
                               "the GPU run executed each at, multiplied by the GPU run's per-sample operation counts (merged rotations counted "
                               "in the reference's units); plaintext encodes, additions and host orchestration not counted (lower bound)",
-                    "ops": detail, "ops_single_thread": detail_one}
+                    "ops": detail, "ops_single_thread": detail_one, "timed_composite_stage": res.get("composite")}
             else:
                 rate, n, dt = cpu_ntt_baseline(eng, orc, np, one, nq, args.cpu_seconds, cores)
                 line["cpu_baseline"] = {"value": round(rate, 1), "unit": "limb-NTT/s", "cores": cores, "kind": "port",

@@ -87,6 +87,7 @@ def load_library():
         "fhelin_level_plan_get": (i32, [vp, C.POINTER(i32), i32, C.POINTER(i32)]),
         "fhelin_level_plan_set": (i32, [vp, C.POINTER(i32), i32]),
         "fhelin_sync": (i32, [vp]),
+        "fhelin_ctx_trim": (i32, [vp]),
         "fhelin_timer_start": (i32, [vp]),
         "fhelin_timer_stop": (i32, [vp, f32p]),
         "fhelin_dev_alloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
@@ -325,6 +326,10 @@ class Engine:
 
     def sync(self):
         self._ck(self.lib.fhelin_sync(self.h))
+
+    def trim(self):
+        """release the device memory the caching pool holds but does not use"""
+        self._ck(self.lib.fhelin_ctx_trim(self.h))
 
     def timer_start(self):
         self._ck(self.lib.fhelin_timer_start(self.h))

@@ -214,6 +214,16 @@ int fhelin_sync(fhelin_ctx* c) {
     FHELIN_CATCH
 }
 
+int fhelin_ctx_trim(fhelin_ctx* c) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    FHELIN_TRY
+    c->ctx.require_device();
+    if (!c->pending_heavy.empty()) flush_heavy(c);
+    c->ctx.sync();
+    c->ctx.pool.trim();
+    FHELIN_CATCH
+}
+
 int fhelin_timer_start(fhelin_ctx* c) {
     if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
     FHELIN_TRY

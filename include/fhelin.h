@@ -105,6 +105,9 @@ int fhelin_level_plan_end(fhelin_ctx* c, int32_t* n_sources);        /* record: 
 int fhelin_level_plan_get(fhelin_ctx* c, int32_t* target, int32_t cap, int32_t* n);   /* *n = length; fills min(cap, *n) */
 int fhelin_level_plan_set(fhelin_ctx* c, const int32_t* target, int32_t n);
 int fhelin_sync(fhelin_ctx* c);
+/* give the device memory the context's caching pool holds but does not use back to the driver (another context / process
+ * on the same GPU can then have it); synchronises first */
+int fhelin_ctx_trim(fhelin_ctx* c);
 /* HIP-event timer on the context's stream (bench.py measures kernel time with these) */
 int fhelin_timer_start(fhelin_ctx* c);
 int fhelin_timer_stop(fhelin_ctx* c, float* ms);
