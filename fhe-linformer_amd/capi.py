@@ -114,6 +114,7 @@ def load_library():
         "fhelin_encrypt": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_encrypt_batch": (i32, [vp, C.POINTER(C.c_double), i32, i32, i32, i32, C.POINTER(vp)]),
         "fhelin_ctx_set_host_encode": (i32, [vp, i32]),
+        "fhelin_client_ingest": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(vp), vp]),
         "fhelin_debug_sample": (i32, [vp, i32, i32, vp, C.c_size_t]),
         "fhelin_decrypt": (i32, [vp, vp, C.POINTER(C.c_double), i32]),
         "fhelin_ct_import": (i32, [vp, vp, i32, i32, i32, C.c_double, i32, C.POINTER(vp)]),
@@ -414,6 +415,30 @@ class Engine:
         outs = self._outs(a.shape[0])
         self._ck(self.lib.fhelin_encrypt_batch(self.h, a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[0], a.shape[1], level, slots, outs))
         return self._cts(outs, a.shape[0])
+
+    def client_ingest(self, cls, pos, E_w, E_b, F_w, F_b, emb=None, tokens=None, table=None, level=0, want_proj=False):
+        """one sample's client side on the device: (embedding gather,) positional embedding, Linformer projections, expanded packing,
+        encode + encrypt.  Returns {"inputs_E": 32 cts, "inputs_F": 32 cts, "inputs": S+1 cts} (+ x_in, proj if want_proj)"""
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        cls, pos, E_w, E_b, F_w, F_b = f(cls), f(pos), f(E_w), f(E_b), f(F_w), f(F_b)
+        p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        if emb is not None:
+            emb = f(emb)
+            S, tok, tab, vocab = emb.shape[0], None, None, 0
+        else:
+            tok = np.ascontiguousarray(tokens, dtype=np.int32)
+            tab = f(table)
+            S, vocab = tok.shape[0], tab.shape[0]
+        n = 64 + S + 1
+        outs = self._outs(n)
+        proj = np.empty((S + 1 + 64, 128)) if want_proj else None
+        self._ck(self.lib.fhelin_client_ingest(self.h, p(emb), p(tok), p(tab), vocab, S, p(cls), p(pos), p(E_w), p(E_b), p(F_w), p(F_b),
+                                               E_w.shape[1], level, outs, p(proj)))
+        cts = self._cts(outs, n)
+        res = {"inputs_E": cts[:32], "inputs_F": cts[32:64], "inputs": cts[64:]}
+        if want_proj:
+            res["x_in"], res["proj"] = proj[:S + 1], proj[S + 1:]
+        return res
 
     def set_host_encode(self, on):
         self._ck(self.lib.fhelin_ctx_set_host_encode(self.h, 1 if on else 0))

@@ -145,6 +145,27 @@ int fhelin_encrypt_batch(fhelin_ctx* c, const double* vals, int32_t n_vec, int32
     }
     FHELIN_CATCH
 }
+int fhelin_client_ingest(fhelin_ctx* c, const double* emb, const int32_t* tokens, const double* table, int32_t vocab, int32_t S,
+                         const double* cls, const double* pos, const double* E_w, const double* E_b, const double* F_w, const double* F_b,
+                         int32_t w_cols, int32_t level, fhelin_ct** outs, double* proj_out) {
+    NEED(c && (emb || (tokens && table)) && cls && pos && E_w && E_b && F_w && F_b && outs);
+    FHELIN_TRY
+    if (S < 1) throw Error(FHELIN_ERR_ARG, "ingest: need at least one token");
+    if (level < 0 || level > c->ctx.L) throw Error(FHELIN_ERR_ARG, "ingest: level out of range");
+    const int n_vec = 64 + S + 1;
+    std::vector<int> drop(n_vec);
+    for (int i = 0; i < n_vec; ++i) drop[i] = std::max(0, std::min(c->ctx.L - level, c->plan.next_drop(c->ctx.L + 1 - level)));
+    const int first_ordinal = c->plan.next_ordinal - n_vec;
+    std::vector<double> po;
+    std::vector<CtPtr> r = c->cl.ingest_sample(emb, tokens, table, vocab, S, cls, pos, E_w, E_b, F_w, F_b, w_cols, level, drop,
+                                               proj_out ? &po : nullptr);
+    if (proj_out) std::memcpy(proj_out, po.data(), po.size() * sizeof(double));
+    for (int i = 0; i < n_vec; ++i) {
+        outs[i] = wrap(c, r[i]);
+        if (c->plan.live(outs[i]->node, outs[i]->node_epoch)) c->plan.nodes[outs[i]->node].ordinal = first_ordinal + i;
+    }
+    FHELIN_CATCH
+}
 int fhelin_ctx_set_host_encode(fhelin_ctx* c, int32_t on) {
     NEED(c);
     c->ctx.host_encode = on != 0;

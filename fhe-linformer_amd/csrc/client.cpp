@@ -220,7 +220,6 @@ void encode_batch_device(Context& c, u64* dst, const double* re, const double* i
     if (slots < 2 || (slots & (slots - 1)) || slots > c.N / 2) throw Error(FHELIN_ERR_ARG, "encode: slots must be a power of two in [2, N/2]");
     if (ell < 1 || ell > c.L + 1) throw Error(FHELIN_ERR_ARG, "encode: level out of range");
     if (n_vec < 1) return;
-    const Context::FftDev& tab = fft_dev_tables(c, slots);
     const size_t words = (size_t)2 * slots;                 // one complex vector, in doubles
     double* dv = reinterpret_cast<double*>(c.dalloc<u64>(words * n_vec));
     std::vector<u64> host(words);
@@ -232,6 +231,13 @@ void encode_batch_device(Context& c, u64* dst, const double* re, const double* i
         }
         c.upload_async(reinterpret_cast<u64*>(dv) + words * b, host.data(), words);
     }
+    encode_complex_on_device(c, dst, dv, n_vec, slots, ell, scale);
+    c.pool.free(dv);
+}
+
+// dv [n_vec][slots][2] complex slot values already on the device (overwritten) -> dst [n_vec][ell][N] encodings, NTT form
+void encode_complex_on_device(Context& c, u64* dst, double* dv, int n_vec, int slots, int ell, long double scale) {
+    const Context::FftDev& tab = fft_dev_tables(c, slots);
     launch_fft_special_inv(dv, tab.rot, tab.ksi, slots, n_vec, c.stream);
     // scale = mant * 2^exp with a 64-bit significand, exactly (the host code multiplies in x87 extended precision)
     int e2 = 0;
@@ -241,7 +247,6 @@ void encode_batch_device(Context& c, u64* dst, const double* re, const double* i
     c.stats.encode += (u64)n_vec;
     c.ntt(LimbBatch{dst, n_vec * ell, nullptr, 0, ell}, false);
     hip_check(hipGetLastError(), "encode kernels (device)");
-    c.pool.free(dv);
 }
 
 std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>& values, const std::vector<double>& imag, int slots,
@@ -542,6 +547,84 @@ std::vector<CtPtr> Client::encrypt_batch(const double* vals, int n_vec, int n_pe
         encrypt_encoded(enc, pn, n, ell, scale, slots, out);
         c_.pool.free(enc);
     }
+    return out;
+}
+
+// One sample's client side on the device (kernels_client.h "sample ingestion"): embedding rows (given, or gathered from a table by
+// token id) + positional embedding, the two Linformer projections, the expanded packing, encoding and encryption.  drop[v]:
+// limbs vector v starts lower by (level plan); vectors of one level share the batched encryptor.
+std::vector<CtPtr> Client::ingest_sample(const double* emb, const int* tokens, const double* table, int vocab, int S, const double* cls,
+                                         const double* pos, const double* E_w, const double* E_b, const double* F_w, const double* F_b,
+                                         int w_cols, int level, const std::vector<int>& drop, std::vector<double>* proj_out) {
+    if (!pk) throw Error(FHELIN_ERR_KEY, "keygen() has not been called");
+    const int slots = 1 << c_.prm.log_slots, S1 = S + 1, n_vec = 64 + S1;
+    if (slots != 16384) throw Error(FHELIN_ERR_ARG, "ingest: the expanded layout needs 16384 slots (128 x 128)");
+    if (S < 1 || S1 > w_cols || (!emb && !(tokens && table && vocab > 0))) throw Error(FHELIN_ERR_ARG, "ingest: bad token count / inputs");
+    if (level < 0 || level > c_.L || (int)drop.size() != n_vec) throw Error(FHELIN_ERR_ARG, "ingest: level out of range");
+    hipStream_t s = c_.stream;
+    auto up = [&](const void* h, size_t bytes) {
+        void* d = c_.pool.alloc(bytes);
+        hip_check(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s), "ingest upload");
+        return d;
+    };
+    if (tokens)
+        for (int t = 0; t < S; ++t)
+            if (tokens[t] < 0 || tokens[t] >= vocab) throw Error(FHELIN_ERR_ARG, "ingest: token id outside the embedding table");
+    double* d_emb = emb ? (double*)up(emb, (size_t)S * 128 * 8) : nullptr;
+    int* d_tok = tokens ? (int*)up(tokens, (size_t)S * 4) : nullptr;
+    double* d_tab = tokens ? (double*)up(table, (size_t)vocab * 128 * 8) : nullptr;
+    double* d_cls = (double*)up(cls, 128 * 8);
+    double* d_pos = (double*)up(pos, (size_t)S * 128 * 8);
+    double* d_Ew = (double*)up(E_w, (size_t)32 * w_cols * 8);
+    double* d_Fw = (double*)up(F_w, (size_t)32 * w_cols * 8);
+    double* d_Eb = (double*)up(E_b, 32 * 8);
+    double* d_Fb = (double*)up(F_b, 32 * 8);
+    double* x_in = (double*)c_.pool.alloc((size_t)S1 * 128 * 8);
+    double* proj = (double*)c_.pool.alloc((size_t)64 * 128 * 8);
+    launch_ingest_xin(x_in, d_emb, d_tok, d_tab, d_cls, d_pos, S, s);
+    launch_ingest_project(proj, x_in, d_Ew, d_Eb, d_Fw, d_Fb, w_cols, S1, s);
+    double* dv = (double*)c_.pool.alloc((size_t)n_vec * slots * 16);
+    launch_ingest_expand(dv, proj, x_in, S1, slots, s);
+    hip_check(hipGetLastError(), "ingest kernels");
+    if (proj_out) {   // test hook: x_in rows then the 64 projected rows, as computed on the device
+        proj_out->resize((size_t)(S1 + 64) * 128);
+        hip_check(hipMemcpyAsync(proj_out->data(), x_in, (size_t)S1 * 128 * 8, hipMemcpyDeviceToHost, s), "ingest download");
+        hip_check(hipMemcpyAsync(proj_out->data() + (size_t)S1 * 128, proj, (size_t)64 * 128 * 8, hipMemcpyDeviceToHost, s), "ingest download");
+    }
+    hip_check(hipStreamSynchronize(s), "ingest sync");   // the host buffers are the caller's: done with them
+    std::vector<CtPtr> out(n_vec);
+    std::vector<char> seen(n_vec, 0);
+    for (int i = 0; i < n_vec; ++i) {
+        if (seen[i]) continue;
+        const int lvl = std::min(c_.L, level + std::max(0, drop[i]));
+        const int ell = c_.L + 1 - lvl;
+        const size_t pn = (size_t)ell * c_.N;
+        const long double scale = c_.sf_real[lvl];
+        // runs of consecutive vectors that start at this level, in chunks of 32 (bounds the temporaries)
+        int j = i;
+        while (j < n_vec) {
+            if (seen[j] || std::min(c_.L, level + std::max(0, drop[j])) != lvl) {
+                ++j;
+                continue;
+            }
+            int hi = j;
+            while (hi < n_vec && hi - j < 32 && !seen[hi] && std::min(c_.L, level + std::max(0, drop[hi])) == lvl) ++hi;
+            const int n = hi - j;
+            u64* enc = c_.dalloc<u64>((size_t)n * pn);
+            encode_complex_on_device(c_, enc, dv + (size_t)j * slots * 2, n, slots, ell, scale);
+            std::vector<CtPtr> part;
+            encrypt_encoded(enc, pn, n, ell, scale, slots, part);
+            c_.pool.free(enc);
+            for (int k = 0; k < n; ++k) {
+                out[j + k] = part[k];
+                seen[j + k] = 1;
+            }
+            j = hi;
+        }
+    }
+    for (void* p : {(void*)d_emb, (void*)d_tok, (void*)d_tab, (void*)d_cls, (void*)d_pos, (void*)d_Ew, (void*)d_Fw, (void*)d_Eb, (void*)d_Fb,
+                    (void*)x_in, (void*)proj, (void*)dv})
+        if (p) c_.pool.free(p);
     return out;
 }
 

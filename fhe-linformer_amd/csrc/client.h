@@ -46,6 +46,9 @@ public:
     // n_vec real vectors of n_per values each (row-major) -> n_vec fresh ciphertexts at `level`: encoding (special FFT, scaling,
     // rounding), sampling of (u, e0, e1) and the dyadic combination all on the GPU, in batched launches
     std::vector<CtPtr> encrypt_batch(const double* vals, int n_vec, int n_per, int level, int slots);
+    std::vector<CtPtr> ingest_sample(const double* emb, const int* tokens, const double* table, int vocab, int S, const double* cls,
+                                     const double* pos, const double* E_w, const double* E_b, const double* F_w, const double* F_b,
+                                     int w_cols, int level, const std::vector<int>& drop, std::vector<double>* proj_out = nullptr);
     // test hook: the sampler's raw output, n_poly polynomials of N centred coefficients (kind 0 Gaussian, 1 ternary)
     std::vector<long> debug_sample(int kind, int n_poly);
     std::vector<double> decrypt(const CtPtr& c, int slots);
@@ -77,5 +80,6 @@ std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>
                                            int ell, long double scale);
 // device encoder for n_vec vectors: re / im [n_vec][n_per] (im may be null) -> dst [n_vec][ell][N] NTT form
 void encode_batch_device(Context& c, u64* dst, const double* re, const double* im, int n_vec, int n_per, int slots, int ell, long double scale);
+void encode_complex_on_device(Context& c, u64* dst, double* dv, int n_vec, int slots, int ell, long double scale);
 
 }  // namespace fhelin

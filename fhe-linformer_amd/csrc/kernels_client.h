@@ -21,4 +21,16 @@ void launch_sample_small(const DeviceTables& t, u64* out, const SamplerKey& key,
 void launch_encrypt_combine(const DeviceTables& t, u64* ct, const u64* pk, const u64* u, const u64* e0, const u64* e1, const u64* m, int ell,
                             int L1, size_t m_stride, int n_vec, hipStream_t s);
 
+
+// ---- client-side ingestion of one sample (reference src/python/dimReduce.py:141-160 and the read_expanded_input packing,
+// src/FHEController.cpp:623-650), all in fp64 with the operation order of the NumPy statement and FMA contraction off:
+//   x_in[0] = cls, x_in[t] = emb[t-1] + pos[t-1] / 3   (emb row = table[token[t-1]] when a token-id list is given)
+//   X[i]    = (...((W[i][0] x_in[0]) + W[i][1] x_in[1]) + ...) + b[i]      for the 32 rows of E and of F (sequential sums)
+//   slot j*128 + i of vector v = v[j]  (i < 128; "expanded" layout), written as complex doubles for the encoder's inverse FFT
+// x_in [S1][128]; proj [64][128] (E rows then F rows); out [(64 + S1)][slots][2] in the order E rows, F rows, tokens.
+void launch_ingest_xin(double* x_in, const double* emb, const int* tokens, const double* table, const double* cls, const double* pos,
+                       int S, hipStream_t s);
+void launch_ingest_project(double* proj, const double* x_in, const double* E_w, const double* E_b, const double* F_w, const double* F_b,
+                           int w_cols, int S1, hipStream_t s);
+void launch_ingest_expand(double* out, const double* proj, const double* x_in, int S1, int slots, hipStream_t s);
 }  // namespace fhelin

@@ -254,4 +254,62 @@ void launch_encrypt_combine(const DeviceTables& t, u64* ct, const u64* pk, const
                        ell, L1, m_stride);
 }
 
+
+// ---- sample ingestion (kernels_client.h) ------------------------------------------------------------------------------
+namespace {
+__global__ void ingest_xin_kernel(double* __restrict__ x_in, const double* __restrict__ emb, const int* __restrict__ tokens,
+                                  const double* __restrict__ table, const double* __restrict__ cls, const double* __restrict__ pos, int S) {
+    const int t = blockIdx.x, j = threadIdx.x;           // row t of x_in (0 = CLS), feature j < 128
+    if (t == 0) {
+        x_in[j] = cls[j];
+        return;
+    }
+    const double e = tokens ? table[(size_t)tokens[t - 1] * 128 + j] : emb[(size_t)(t - 1) * 128 + j];
+    {
+#pragma clang fp contract(off)
+        const double p3 = pos[(size_t)(t - 1) * 128 + j] / 3.0;
+        x_in[(size_t)t * 128 + j] = e + p3;
+    }
+}
+__global__ void ingest_project_kernel(double* __restrict__ proj, const double* __restrict__ x_in, const double* __restrict__ E_w,
+                                      const double* __restrict__ E_b, const double* __restrict__ F_w, const double* __restrict__ F_b,
+                                      int w_cols, int S1) {
+    const int r = blockIdx.x, j = threadIdx.x;           // r < 64: rows of E then rows of F
+    const double* w = (r < 32 ? E_w : F_w) + (size_t)(r & 31) * w_cols;
+    // every product and every sum rounded on its own, in this order (the header's __dmul_rn / __dadd_rn are plain operators that
+    // the compiler is free to contract into FMAs; the pragma below is what forbids it)
+    {
+#pragma clang fp contract(off)
+        double acc = w[0] * x_in[j];
+        for (int t = 1; t < S1; ++t) {
+            const double p = w[t] * x_in[(size_t)t * 128 + j];
+            acc = acc + p;
+        }
+        proj[(size_t)r * 128 + j] = acc + (r < 32 ? E_b : F_b)[r & 31];
+    }
+}
+__global__ void ingest_expand_kernel(double* __restrict__ out, const double* __restrict__ proj, const double* __restrict__ x_in, int S1, int slots) {
+    const int v = blockIdx.y;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= slots) return;
+    const double* src = v < 64 ? proj + (size_t)v * 128 : x_in + (size_t)(v - 64) * 128;
+    const int j = slot >> 7;
+    double2 o;
+    o.x = j < 128 ? src[j] : 0.0;
+    o.y = 0.0;
+    reinterpret_cast<double2*>(out)[(size_t)v * slots + slot] = o;
+}
+}  // namespace
+void launch_ingest_xin(double* x_in, const double* emb, const int* tokens, const double* table, const double* cls, const double* pos,
+                       int S, hipStream_t s) {
+    hipLaunchKernelGGL(ingest_xin_kernel, dim3(S + 1), dim3(128), 0, s, x_in, emb, tokens, table, cls, pos, S);
+}
+void launch_ingest_project(double* proj, const double* x_in, const double* E_w, const double* E_b, const double* F_w, const double* F_b,
+                           int w_cols, int S1, hipStream_t s) {
+    hipLaunchKernelGGL(ingest_project_kernel, dim3(64), dim3(128), 0, s, proj, x_in, E_w, E_b, F_w, F_b, w_cols, S1);
+}
+void launch_ingest_expand(double* out, const double* proj, const double* x_in, int S1, int slots, hipStream_t s) {
+    hipLaunchKernelGGL(ingest_expand_kernel, dim3((slots + 255) / 256, 64 + S1), dim3(256), 0, s, out, proj, x_in, S1, slots);
+}
+
 }  // namespace fhelin

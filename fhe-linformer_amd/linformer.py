@@ -79,6 +79,9 @@ class GpuController:
         """all inputs of a sample in one batched client call (encode + sample + encrypt on the GPU)"""
         return self.e.encrypt_batch(np.stack([expanded(np.asarray(v) * scale) for v in rows]), 0, SLOTS)
 
+    def client_ingest(self, w, x_emb):
+        return self.e.client_ingest(w["cls_token"], w["posEmb"], w["E_w"], w["E_b"], w["F_w"], w["F_b"], emb=x_emb)
+
     def read_plain_input(self, m, level=0, scale=1.0):
         return self.encode(np.asarray(m, dtype=np.float64).reshape(-1) * scale, level)
 
@@ -176,6 +179,20 @@ def encrypt_inputs(ctl, x_in, X_E, X_F):
     return {"inputs_E": cts[:32],                                                           # main.cpp:159-162
             "inputs_F": cts[32:64],                                                         # :164-167
             "inputs": cts[64:]}                                                             # :169-173
+
+
+def ingest_sample(ctl, w, x_emb):
+    """client side of one sample from its token embeddings x_emb [S,128] (dimReduce.py:141-160 + main.cpp:159-173).  A controller
+    with `client_ingest` (the GPU engine: fhelin_client_ingest) does positional embedding, both Linformer projections, packing,
+    encoding and encryption on the device; any other controller gets the NumPy statement of the same lines."""
+    if hasattr(ctl, "client_ingest"):
+        return ctl.client_ingest(w, x_emb)
+    S = x_emb.shape[0]
+    x_in = np.vstack([np.asarray(w["cls_token"]).reshape(1, -1), x_emb + w["posEmb"][:S] / 3.0])
+    St = x_in.shape[0]
+    X_E = w["E_w"][:, :St] @ x_in + w["E_b"].reshape(-1, 1)
+    X_F = w["F_w"][:, :St] @ x_in + w["F_b"].reshape(-1, 1)
+    return encrypt_inputs(ctl, x_in, X_E, X_F)
 
 
 def encoder1(ctl, w, enc, trace=None, full_attention=False):

@@ -161,6 +161,17 @@ int fhelin_encrypt(fhelin_ctx* c, const fhelin_pt* p, fhelin_ct** out);         
  * rounding), the sampling of the encryption randomness (ChaCha20 on the GPU, keyed from the client's generator) and the
  * dyadic combination run as batched kernels. */
 int fhelin_encrypt_batch(fhelin_ctx* c, const double* vals, int32_t n_vec, int32_t n_per, int32_t level, int32_t slots, fhelin_ct** outs);
+/* The client side of ONE sample on the device: what the reference does in NumPy before the server sees anything
+ * (src/python/dimReduce.py:141-160: x_in = [cls; emb + pos/3], X_E = E[:, :S+1] x_in + b_E, X_F likewise) followed by the 64 + S + 1
+ * read_expanded_input calls of the driver (src/main.cpp:159-173, src/FHEController.cpp:623-650) - gather / projection / packing /
+ * encoding / sampling / encryption as GPU kernels, fp64 with the operation order of the NumPy statement (sequential sums, no FMA).
+ * Give the S token embeddings as emb [S][128], or token ids tokens [S] into table [vocab][128].  pos [>= S][128], cls [128],
+ * E_w / F_w [32][w_cols] row-major (w_cols >= S + 1), E_b / F_b [32].  outs: 64 + S + 1 handles in the order of the driver's reads:
+ * the 32 E-projected rows, the 32 F-projected rows, then the S + 1 tokens (CLS first).  Every output is a source of the level plan.
+ * proj_out (optional, (S + 1 + 64) * 128 doubles): x_in rows then the projected rows as the device computed them (parity tests). */
+int fhelin_client_ingest(fhelin_ctx* c, const double* emb, const int32_t* tokens, const double* table, int32_t vocab, int32_t S,
+                         const double* cls, const double* pos, const double* E_w, const double* E_b, const double* F_w, const double* F_b,
+                         int32_t w_cols, int32_t level, fhelin_ct** outs, double* proj_out);
 /* 1: the special FFT of CKKS encoding runs on the host (the original encoder, the reference the device encoder is compared
  * with bit for bit); 0 (default): on the GPU.  Both produce identical residues. */
 int fhelin_ctx_set_host_encode(fhelin_ctx* c, int32_t on);

@@ -73,3 +73,46 @@ def test_encrypt_batch_decrypts(fa, preset):
         assert np.max(np.abs(eng.decrypt(single)[:200] - rows[5])) < 1e-9
     finally:
         eng.close()
+
+
+def test_device_ingestion_of_a_sample_matches_the_numpy_statement(fa):
+    """fhelin_client_ingest: embedding gather + positional embedding + the Linformer projections X_E = E x + b_E,
+    X_F = F x + b_F (reference src/python/dimReduce.py:141-160) + the driver's 64 + S + 1 read_expanded_input calls
+    (src/main.cpp:159-173) on the device.  Floating point (fp64): the device's sums run in the stated order (t = 0..S, no FMA), so
+    x_in and the projections are BIT-IDENTICAL to the same order in NumPy and within 1e-13 of NumPy's BLAS product (stated
+    tolerance: summation order only); the ciphertexts decrypt to the expanded packing of those rows to encoder precision (1e-9);
+    token ids into a table give the same ciphertext values as the gathered embeddings."""
+    from oracle import plain_forward as pf
+    from fhe_linformer_amd import linformer as lf
+    w = pf.synthetic_model(1234)
+    S = 37
+    x = pf.synthetic_tokens(S, 4321)
+    eng = fa.Engine("reference", seed=5, n_q=4, n_p=2, dnum=2)
+    try:
+        eng.keygen()
+        got = eng.client_ingest(w["cls_token"], w["posEmb"], w["E_w"], w["E_b"], w["F_w"], w["F_b"], emb=x, level=1, want_proj=True)
+        x_in, X_E, X_F = pf.client_inputs(w, x)                               # the reference statement (BLAS matmul)
+        assert np.array_equal(got["x_in"], x_in)                             # element-wise: bit-identical
+        seq = np.zeros((64, 128))
+        for r in range(64):
+            W, b = (w["E_w"], w["E_b"]) if r < 32 else (w["F_w"], w["F_b"])
+            acc = W[r % 32, 0] * x_in[0]
+            for t in range(1, S + 1):
+                acc = acc + W[r % 32, t] * x_in[t]
+            seq[r] = acc + b[r % 32]
+        assert np.array_equal(got["proj"], seq)                              # the stated summation order: bit-identical
+        assert np.max(np.abs(got["proj"] - np.vstack([X_E, X_F]))) < 1e-13   # vs the BLAS product
+        assert len(got["inputs_E"]) == len(got["inputs_F"]) == 32 and len(got["inputs"]) == S + 1
+        for ct, row in ((got["inputs_E"][3], X_E[3]), (got["inputs_F"][31], X_F[31]), (got["inputs"][0], x_in[0]), (got["inputs"][S], x_in[S])):
+            assert ct.info()["ell"] == 3 and ct.info()["slots"] == 16384
+            assert np.max(np.abs(eng.decrypt(ct) - lf.expanded(row))) < 1e-9
+        # token ids into an embedding table: the same rows
+        table = np.random.default_rng(2).normal(0, 0.3, (50, 128))
+        tok = np.random.default_rng(3).integers(0, 50, S)
+        a = eng.client_ingest(w["cls_token"], w["posEmb"], w["E_w"], w["E_b"], w["F_w"], w["F_b"], tokens=tok, table=table, want_proj=True)
+        b = eng.client_ingest(w["cls_token"], w["posEmb"], w["E_w"], w["E_b"], w["F_w"], w["F_b"], emb=table[tok], want_proj=True)
+        assert np.array_equal(a["x_in"], b["x_in"]) and np.array_equal(a["proj"], b["proj"])
+        with pytest.raises(fa.FhelinError):
+            eng.client_ingest(w["cls_token"], w["posEmb"], w["E_w"], w["E_b"], w["F_w"], w["F_b"], tokens=[0, 50], table=table)
+    finally:
+        eng.close()
