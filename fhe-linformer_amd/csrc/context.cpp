@@ -203,6 +203,7 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
         if (const char* e = std::getenv("FHELIN_HOST_ENCODE")) host_encode = std::atoi(e) != 0;
         if (const char* e = std::getenv("FHELIN_FUSE_GATHER")) fuse_gather = std::atoi(e) != 0;
         if (const char* e = std::getenv("FHELIN_FUSE_LIFT")) fuse_lift = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FHELIN_LDS_DIGITS")) lds_digits = std::atoi(e) != 0;
     }
     hip_check(hipEventCreate(&ev_start), "hipEventCreate");
     stage_words = (size_t)2 << p.log_n;

@@ -189,6 +189,7 @@ struct Context {
     // the ModDown epilogue (bit-identical; kept for A/B measurements)
     bool fuse_gather = true;
     bool fuse_lift = true;      // rescale: centred lift formed in the NTT's first-pass load (FHELIN_FUSE_LIFT)
+    bool lds_digits = true;     // merged rotate-and-sum: digit tiles staged once in LDS when every rotation keeps tiles in place (FHELIN_LDS_DIGITS)
     struct FftDev {
         const u32* rot = nullptr;     // [slots]      5^j mod 4 slots
         const double* ksi = nullptr;  // [4 slots + 1][2]

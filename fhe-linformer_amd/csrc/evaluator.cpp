@@ -215,7 +215,7 @@ const u64* Evaluator::permuted(const EvalKey& key, const u32* map) {
     if (key.d_perm) return key.d_perm;
     const int nvec = key.digits * 2 * (c_.L + 1 + c_.K);
     key.d_perm = c_.dalloc<u64>(key.words());
-    launch_automorph(c_.dt, key.d_perm, key.d, map, nvec, c_.stream);
+    launch_automorph_pack30(c_.dt, key.d_perm, key.d, map, nvec, c_.stream);
     launch_ok("key permutation");
     // built once, read from every stream afterwards: finish it before anyone else can see the pointer
     hip_check(hipStreamSynchronize(c_.stream), "key permutation sync");
@@ -260,9 +260,13 @@ std::vector<CtPtr> Evaluator::rotate_sum_batch(const std::vector<CtPtr>& vin, co
         const u64* base = chunk[0]->d;
         KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, ctw, ctw, pn, ctw};
         sh.n_rot = R;
+        sh.lds_digits = c_.lds_digits ? 1 : 0;
         for (int r = 0; r < R; ++r) {
             sh.evk_rot[r] = permuted(*keys[r], maps[r]);
             sh.map_rot[r] = maps[r];
+            // the automorphism of g keeps every 512-coefficient tile in place iff g = 1 mod N/256 (index bits above the tile
+            // correspond to the low bits of the odd exponent 2 bitrev(j) + 1, which multiplication by such a g leaves alone)
+            if (c_.galois_element(indices[r]) % (u64)(c_.N / 256) != 1) sh.lds_digits = 0;
         }
         // accounting in units of the reference's rotations: R = 2^k - 1 merged terms stand for k tree steps
         int steps = 0;

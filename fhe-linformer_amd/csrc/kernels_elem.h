@@ -32,6 +32,8 @@ struct LinComb {
 void launch_ew_lincomb(const DeviceTables& t, u64* out, const LinComb& lc, const u64* scal, int ell, hipStream_t s, int in_limbs = 0);
 void launch_tensor(const DeviceTables& t, u64* d, const u64* a, const u64* b, int ell, hipStream_t s);
 void launch_automorph(const DeviceTables& t, u64* out, const u64* in, const u32* map, int nvec, hipStream_t s);
+// the same gather, every word stored as pack30(word) (low 30 bits | next 30 bits << 32): operands of launch_ks_inner_multi
+void launch_automorph_pack30(const DeviceTables& t, u64* out, const u64* in, const u32* map, int nvec, hipStream_t s);
 void launch_rescale_lift(const DeviceTables& t, u64* lifted, const u64* last, int npoly, int ell, const u64* qlmod_row, hipStream_t s);
 void launch_rescale_finish(const DeviceTables& t, u64* out, const u64* c, const u64* lifted, int npoly, int ell, const u64* qlinv_row,
                            hipStream_t s);
@@ -92,12 +94,13 @@ struct KsShape {
     // merged rotations (launch_ks_inner_multi): n_rot <= MAX_ROT rotations of every row are accumulated before ONE ModDown
     static constexpr int MAX_ROT = 7;
     int n_rot = 0;
-    const u64* evk_rot[MAX_ROT] = {};   // the keys in PERMUTED layout (EvalKey::d_perm): evk_rot[r][v][n] = key_r[v][map_rot[r][n]]
+    const u64* evk_rot[MAX_ROT] = {};   // the keys in PERMUTED, PRE-SPLIT layout (EvalKey::d_perm): evk_rot[r][v][n] = pack30(key_r[v][map_rot[r][n]])
     const u32* map_rot[MAX_ROT] = {};
     // rot_input_stride > 0: rotation r acts on its OWN input (digits at ext + r * rot_ext_stride, polynomial at c + r *
     // rot_input_stride): a sum of rotations of different ciphertexts (giant steps) shares the one ModDown
     size_t rot_ext_stride = 0;
     size_t rot_input_stride = 0;
+    int lds_digits = 0;           // launch_ks_inner_multi: every map_rot keeps each 512-coefficient tile in place (see the kernel)
     size_t ext_batch_stride = 0;  // digits of batch row b at ext + b * ext_batch_stride (0: beta * (ell + k) * N, one input per row)
     // K8b epilogue of a merged rotation sum: component 0 additionally receives sum_r gsrc[bi][tt][map_rot[r][n]] (the rotated
     // c0 parts, gathered in place of a separate gather-and-sum pass); rotation r reads gsrc + r * rot_input_stride

@@ -179,8 +179,14 @@ __device__ __forceinline__ u32 sel_mask(u32 a, u32 b, unsigned long long mask) {
 // automorphism map satisfies map[2m+1] = map[2m] ^ 1 (the two slots differ by psi^N = -1 in the evaluation point, which
 // multiplication of the exponent by the odd g preserves): a pair is gathered with ONE 16-byte load and swapped in
 // registers when map[2m] is odd.  The keys come pre-permuted (KsShape::evk_rot): their loads are contiguous.
+// STAGE (KsShape::lds_digits): every rotation of the launch maps a 512-coefficient tile onto ITSELF (Galois element = 1 mod
+// N/256: rotations by multiples of 64 slots at N = 2^16 - the 128 s and 512 s units of the matmul trees) and all rotations read
+// the same digits: the workgroup's beta digit tiles are loaded ONCE, coalesced, into LDS and every rotation gathers from there.
+// Without it each rotation re-gathers the tile through L2, where the key stream (112 KB per tile) keeps evicting it.
+template <bool STAGE>
 __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsShape sh, u64* __restrict__ accQ, u64* __restrict__ accP,
                                                              const u64* __restrict__ ext, const u64* __restrict__ c_ntt) {
+    __shared__ u64x2 dl[STAGE ? 4 : 1][256];
     const int nt = sh.ell + sh.k;
     const KsBlock kb_ = ks_block(sh);
     const int bi = kb_.bi, tt = kb_.tt;
@@ -197,29 +203,65 @@ __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsS
     u64 lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};      // b.x, b.y, a.x, a.y
     Acc30 b0 = {0, 0, 0}, b1 = {0, 0, 0}, a0 = {0, 0, 0}, a1 = {0, 0, 0};
     int pending = 0, folded = 0;
-    for (int r = 0; r < sh.n_rot; ++r) {
-        const u32 m0 = sh.map_rot[r] ? sh.map_rot[r][2 * n2] : (u32)(2 * n2);
+    if constexpr (STAGE) {
+        const u64x2* __restrict__ e0 = reinterpret_cast<const u64x2*>(ext);
+        const u64x2* __restrict__ c0 = reinterpret_cast<const u64x2*>(c_ntt);
+        for (int j = 0; j < sh.beta; ++j) dl[j][threadIdx.x] = j == own ? c0[(size_t)tt * row + n2] : e0[((size_t)j * nt + tt) * row + n2];
+        __syncthreads();
+    }
+    // The (rotation, digit) iterations form ONE software-pipelined loop: the loads of iteration i+1 (a 16-byte digit gather and two
+    // key words) are issued before the multiply-accumulates of iteration i, and the map entry of rotation r+1 one rotation ahead.  A wave
+    // then keeps six loads in flight instead of three; with three the kernel ran at the pace of one HBM round trip per iteration
+    // (152 waves per SIMD in rounds of 8 x 14 iterations x ~1.4 us = the 387 us measured in round 2).
+    struct Operands {
+        u64x2 d, kb, ka;
+    };
+    auto map_of = [&](int r) -> u32 { return sh.map_rot[r] ? sh.map_rot[r][2 * n2] : (u32)(2 * n2); };
+    auto issue = [&](int r, int j, u32 m0) {
         const size_t mp = m0 >> 1;
-        const unsigned long long swp = __ballot((m0 & 1) != 0);
         const u64x2* __restrict__ K = reinterpret_cast<const u64x2*>(sh.evk_rot[r]) + (size_t)limb * row + n2;
-        const u64x2* __restrict__ er = reinterpret_cast<const u64x2*>(ext + (size_t)r * sh.rot_ext_stride);
-        const u64x2* __restrict__ cr = reinterpret_cast<const u64x2*>(c_ntt + (size_t)r * sh.rot_input_stride);
-        for (int j = 0; j < sh.beta; ++j) {
-            const u64x2 d = j == own ? cr[(size_t)tt * row + mp] : er[((size_t)j * nt + tt) * row + mp];
-            const u64x2 kb = K[(size_t)(2 * j) * kstride], ka = K[(size_t)(2 * j + 1) * kstride];
-            u32 p0, p1, q0, q1, k0, k1;
+        Operands o;
+        if constexpr (STAGE) {
+            o.d = dl[j][mp & 255];
+        } else {
+            const u64x2* __restrict__ er = reinterpret_cast<const u64x2*>(ext + (size_t)r * sh.rot_ext_stride);
+            const u64x2* __restrict__ cr = reinterpret_cast<const u64x2*>(c_ntt + (size_t)r * sh.rot_input_stride);
+            o.d = j == own ? cr[(size_t)tt * row + mp] : er[((size_t)j * nt + tt) * row + mp];
+        }
+        o.kb = K[(size_t)(2 * j) * kstride];
+        o.ka = K[(size_t)(2 * j + 1) * kstride];
+        return o;
+    };
+    const int total = sh.n_rot * sh.beta;
+    int r = 0, j = 0;
+    u32 m_cur = map_of(0), m_nxt = sh.n_rot > 1 ? map_of(1) : 0;
+    Operands cur = issue(0, 0, m_cur);
+    for (int it = 0; it < total; ++it) {
+        int rn = r, jn = j + 1;
+        u32 mn = m_cur;
+        if (jn == sh.beta) {
+            jn = 0;
+            rn = r + 1;
+            mn = m_nxt;
+        }
+        Operands nxt = cur;
+        if (it + 1 < total) {
+            nxt = issue(rn, jn, mn);
+            if (jn == 0 && rn + 1 < sh.n_rot) m_nxt = map_of(rn + 1);
+        }
+        {
+            const unsigned long long swp = __ballot((m_cur & 1) != 0);
+            const u64x2 d = cur.d, kb = cur.kb, ka = cur.ka;
+            u32 p0, p1, q0, q1;
             split30(d.x, p0, p1);
             split30(d.y, q0, q1);
             // element 2m of the rotated digit is d.x, or d.y when the map sends 2m to an odd position
             const u32 dx0 = sel_mask(p0, q0, swp), dx1 = sel_mask(p1, q1, swp), dy0 = sel_mask(q0, p0, swp), dy1 = sel_mask(q1, p1, swp);
-            split30(kb.x, k0, k1);
-            mac30(b0, dx0, dx1, k0, k1);
-            split30(kb.y, k0, k1);
-            mac30(b1, dy0, dy1, k0, k1);
-            split30(ka.x, k0, k1);
-            mac30(a0, dx0, dx1, k0, k1);
-            split30(ka.y, k0, k1);
-            mac30(a1, dy0, dy1, k0, k1);
+            // the key words come pre-split (pack30: low half in the low dword, high half in the high dword)
+            mac30(b0, dx0, dx1, (u32)kb.x, (u32)(kb.x >> 32));
+            mac30(b1, dy0, dy1, (u32)kb.y, (u32)(kb.y >> 32));
+            mac30(a0, dx0, dx1, (u32)ka.x, (u32)(ka.x >> 32));
+            mac30(a1, dy0, dy1, (u32)ka.y, (u32)(ka.y >> 32));
             if (++pending == 8) {  // at most 8 products of 60-bit halves fit the 64-bit columns
                 acc30_flush(b0, lo[0], hi[0]);
                 acc30_flush(b1, lo[1], hi[1]);
@@ -240,6 +282,10 @@ __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsS
                 }
             }
         }
+        cur = nxt;
+        r = rn;
+        j = jn;
+        m_cur = mn;
     }
     acc30_flush(b0, lo[0], hi[0]);
     acc30_flush(b1, lo[1], hi[1]);
@@ -403,7 +449,10 @@ void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* a
 void launch_ks_inner_multi(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* c_ntt,
                            hipStream_t s) {
     dim3 g((1u << t.log_n) / 512, (unsigned)(sh.batch * (sh.ell + sh.k)));
-    hipLaunchKernelGGL(ks_inner_multi_kernel, g, dim3(256), 0, s, t, sh, accQ, accP, ext, c_ntt);
+    if (sh.lds_digits && sh.rot_ext_stride == 0 && sh.beta <= 4)
+        hipLaunchKernelGGL(ks_inner_multi_kernel<true>, g, dim3(256), 0, s, t, sh, accQ, accP, ext, c_ntt);
+    else
+        hipLaunchKernelGGL(ks_inner_multi_kernel<false>, g, dim3(256), 0, s, t, sh, accQ, accP, ext, c_ntt);
 }
 void launch_gather_sum(const DeviceTables& t, const KsShape& sh, u64* out, const u64* in, size_t in_stride, hipStream_t s) {
     dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * sh.ell));
