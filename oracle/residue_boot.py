@@ -56,7 +56,7 @@ class ResidueBootstrapper:
             if len(chunk) < 2:
                 t = self._rot(chunk[0], idx[0], ns)
             else:
-                evks = np.stack([rev.keys[r] for r in idx])
+                evks = rev._stack(idx)
                 d = orc.rotate_each_sum(np.stack([c.d for c in chunk]), evks, [orc.galois(rev.log_n, r) for r in idx], rev.alpha,
                                         rev.q, rev.p, rev.psi_q, rev.psi_p)
                 t = RCt(d, chunk[0].deg, chunk[0].scale)

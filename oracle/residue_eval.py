@@ -155,9 +155,19 @@ class ResidueEvaluator:
             return self.add(a, a)
         return self.add(self.rotate(a, index), a)
 
+    def _stack(self, indices):
+        """the keys of a merged key switch as one array; cached per index set (a whole-pass run asks for the same dozen sets
+        thousands of times, and one stack of seven 73 MB keys is a 0.5 GB copy)"""
+        if not hasattr(self, "_stacks"):
+            self._stacks = {}
+        k = tuple(int(r) for r in indices)
+        if k not in self._stacks:
+            self._stacks[k] = np.stack([self.keys[r] for r in indices])
+        return self._stacks[k]
+
     def rotate_sum(self, a, indices):
         """merged tree steps: a + sum_r rot(a, r), one ModUp / one ModDown (Evaluator::rotate_sum_batch)"""
-        evks = np.stack([self.keys[r] for r in indices])
+        evks = self._stack(indices)
         gs = [self._g(r) for r in indices]
         d = orc.rotate_sum(a.d, evks, gs, self.alpha, self.q, self.p, self.psi_q, self.psi_p)
         return RCt(d, a.deg, a.scale)
@@ -177,7 +187,7 @@ class ResidueEvaluator:
             if len(chunk) < 2:
                 t = self.rotate(chunk[0], idx[0])
             else:
-                evks = np.stack([self.keys[r] for r in idx])
+                evks = self._stack(idx)
                 d = orc.rotate_each_sum(np.stack([c.d for c in chunk]), evks, [self._g(r) for r in idx], self.alpha,
                                         self.q, self.p, self.psi_q, self.psi_p)
                 t = RCt(d, chunk[0].deg, chunk[0].scale)

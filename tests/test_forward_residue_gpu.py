@@ -1,0 +1,90 @@
+"""The COMPLETE encrypted forward pass, residue for residue against the CPU oracle.
+
+One pass of the driver (fhe-linformer_amd/linformer.py = the call sequence of reference src/main.cpp:145-475: Q/K/V projections, scores,
+Taylor^8 exp, Chebyshev 1/x, attention, W_O, affine-1, 2 bootstraps, FFN 128->512, 5 Chebyshev GELUs + 5 bootstraps, FFN 512->128,
+affine-2, pooler with a bootstrap and the degree-300 tanh, classifier) runs on the GPU through the C ABI with every knob at its default
+(deferred rows, merged key switches, batched bootstraps, deferred heavy operations) at the reference's literal ring and chain (N=2^15,
+28+7 limbs, 16384 slots = full packing).  The SAME driver then runs on oracle/residue_controller.py (oracle/fhe_oracle.c underneath) with
+the exported keys, the exported plaintext encodings and the run's own fresh encryptions.  The final ciphertext and the traced
+intermediates must be EQUAL: residues, limb count, noise degree and 80-bit scale.  (The oracle is a CPU restatement of published
+algorithms, not OpenFHE: "parity unpinned" - what this pins is that 6.7 k key switches, 8 bootstraps and 7 polynomial evaluations of
+the product compute exactly the stated integer functions, end to end.)"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LD = np.longdouble
+
+
+def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc):
+    from fhe_linformer_amd import linformer as lf
+    from oracle import plain_forward as pf, circuit_sim as cs
+    from oracle.residue_eval import ResidueEvaluator, RCt
+    from oracle.residue_boot import ResidueBootstrapper
+    from oracle.residue_controller import ResidueController, GaloisKeys
+
+    S = 129
+    w = pf.synthetic_model(1234)
+    x_in, X_E, X_F = pf.client_inputs(w, pf.synthetic_tokens(S, 4321))
+    eng = fa.Engine("reference", seed=11, n_q=28, n_p=-1)
+    try:
+        eng.keygen()
+        eng.gen_relin_key()
+        eng.gen_rotation_keys(fa.circuit_rotation_indices())
+        eng.bootstrap_setup(3, 3, 16384)
+
+        def rct(ct):
+            hi, lo = ct.scale_parts()
+            return RCt(ct.export(), ct.info()["deg"], LD(hi) + LD(lo))
+
+        class Recording(lf.GpuController):                      # the run's fresh encryptions, in call order
+            fresh = []
+
+            def encrypt(self, v, level=0):
+                c = super().encrypt(v, level)
+                Recording.fresh.append(rct(c))
+                return c
+
+            def read_expanded_inputs(self, rows, scale=1.0):
+                cts = super().read_expanded_inputs(rows, scale)
+                Recording.fresh.extend(rct(c) for c in cts)
+                return cts
+
+        tr = {}
+        out = lf.forward(Recording(eng), w, x_in, X_E, X_F, tr, "main")
+        got = {k: rct(v) for k, v in tr.items()}
+        got["out"] = rct(out)
+        lg = lf.logits_from_slots(eng.decrypt(out))
+
+        # ---- the oracle side: every switching key of the run, by Galois element
+        desc = eng.bootstrap_describe()
+        keys = GaloisKeys(eng.log_n)
+        keys["relin"], keys["conj"] = eng.key_export(0), eng.key_export(2)
+        idx = set(fa.circuit_rotation_indices())
+        for st in desc["c2s"] + desc["s2c"]:
+            for (g, b, _) in st["terms"]:
+                idx.update((g, b))
+        for r in sorted(idx):
+            if r % 16384 and r not in keys:
+                keys[r] = eng.key_export(1, r)
+        rev = ResidueEvaluator(eng.q, eng.p, eng.psi_q, eng.psi_p, eng.alpha, eng.log_n, keys, eng.params.log_slots)
+        boot = ResidueBootstrapper(rev, desc, lambda pt: (lambda ell, sc: eng.pt_export(pt, ell, sc)))
+        ctl = ResidueController(eng, rev, boot, Recording.fresh)
+        orc.use_fast(True)            # Barrett build of the same C file (identical residues: test_fast_build_equals_definition_build)
+        try:
+            tw = {}
+            want = lf.forward_encrypted(ctl, w, lf.encrypt_inputs(ctl, x_in, X_E, X_F), tw, "main")
+        finally:
+            orc.use_fast(False)
+        assert ctl.n_boot == 8 and not ctl.fresh                  # all 8 bootstraps, every fresh encryption consumed
+        tw["out"] = want
+        for k in ("scores", "exp", "self_attention", "affine1_0", "encoder_out", "pooled", "out"):
+            g, r = got[k], tw[k]
+            assert (g.npoly, g.ell, g.deg) == (r.npoly, r.ell, r.deg), (k, g.ell, g.deg, r.ell, r.deg)
+            assert g.scale == r.scale, (k, "scale")
+            assert np.array_equal(g.d, r.d), k
+        # ... and it is the forward pass: the logits match the clear-text circuit
+        ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, x_in, X_E, X_F, None, "main"))
+        assert np.max(np.abs(lg - ref)) < 2e-2 and int(np.argmax(lg)) == int(np.argmax(ref))
+    finally:
+        eng.close()
