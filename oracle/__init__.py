@@ -5,7 +5,9 @@ product (fhe-linformer_amd/) never does.  PARITY STATUS: "parity unpinned" (see 
 the arithmetic of this path lives in OpenFHE, an un-pinned, un-vendored dependency of the reference, and
 the reference holds no golden vectors; the oracle is pinned by library-independent known-answer tests.
 
-numpy front-end over libfhe_oracle.so (plain C, oracle/fhe_oracle.c).
+numpy front-end over libfhe_oracle.so (plain C, oracle/fhe_oracle.c).  On top of it (pure Python, exact integer functions):
+residue_eval.py (the evaluator's bookkeeping, composites, polynomial evaluation), residue_boot.py (bootstrapping),
+residue_controller.py (the FHEController surface: the whole driver on residues).
 """
 import ctypes as C
 import os

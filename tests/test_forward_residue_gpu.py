@@ -16,7 +16,16 @@ pytestmark = pytest.mark.gpu
 LD = np.longdouble
 
 
-def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc):
+def desc_depth(eng):
+    return eng.bootstrap_describe()["depth"]
+
+
+@pytest.mark.parametrize("preset,planned", [
+    ("reference", False),      # the reference's literal ring (N=2^15: full packing, two EvalMod ciphertexts), the driver's own levels
+    ("bench", True),           # the headline configuration of bench.py: N=2^16 (sparse packing, one EvalMod ciphertext) under a recorded
+                               # level plan - client encryptions at the planned limbs, bootstraps raising to fewer limbs
+])
+def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc, preset, planned):
     from fhe_linformer_amd import linformer as lf
     from oracle import plain_forward as pf, circuit_sim as cs
     from oracle.residue_eval import ResidueEvaluator, RCt
@@ -26,7 +35,7 @@ def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc):
     S = 129
     w = pf.synthetic_model(1234)
     x_in, X_E, X_F = pf.client_inputs(w, pf.synthetic_tokens(S, 4321))
-    eng = fa.Engine("reference", seed=11, n_q=28, n_p=-1)
+    eng = fa.Engine(preset, seed=11, n_q=28, n_p=-1)
     try:
         eng.keygen()
         eng.gen_relin_key()
@@ -40,6 +49,10 @@ def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc):
         class Recording(lf.GpuController):                      # the run's fresh encryptions, in call order
             fresh = []
 
+            def __init__(self, e):
+                super().__init__(e)
+                Recording.fresh = []
+
             def encrypt(self, v, level=0):
                 c = super().encrypt(v, level)
                 Recording.fresh.append(rct(c))
@@ -50,8 +63,21 @@ def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc):
                 Recording.fresh.extend(rct(c) for c in cts)
                 return cts
 
+        drops = []
+        if planned:                                               # record one pass of the driver on other inputs, then apply the plan
+            eng.level_plan_begin("record")
+            other = pf.client_inputs(w, pf.synthetic_tokens(S, 999))
+            eng.decrypt(lf.forward(lf.GpuController(eng), w, *other, None, "main"))
+            plan = eng.level_plan_end()
+            # sources in call order: 194 client encryptions, the encrypted zero (src/main.cpp:220), 8 bootstraps, the encrypted mask (:472)
+            assert len(plan) == 194 + 1 + 8 + 1
+            out_ell = eng.n_q - desc_depth(eng)
+            drops = [max(0, out_ell - t) if t >= 1 else 0 for t in plan[195:203]]
+            assert any(drops)
+            eng.level_plan_begin("apply")
         tr = {}
         out = lf.forward(Recording(eng), w, x_in, X_E, X_F, tr, "main")
+        eng.level_plan_begin("off")
         got = {k: rct(v) for k, v in tr.items()}
         got["out"] = rct(out)
         lg = lf.logits_from_slots(eng.decrypt(out))
@@ -64,12 +90,16 @@ def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc):
         for st in desc["c2s"] + desc["s2c"]:
             for (g, b, _) in st["terms"]:
                 idx.update((g, b))
+        j = 1
+        while j < (eng.N // 2) // desc["slots"]:                  # SubSum rotations of sparse packing (multiples of the slot count)
+            idx.add(desc["slots"] * j)
+            j <<= 1
         for r in sorted(idx):
-            if r % 16384 and r not in keys:
+            if r % (eng.N // 2) and r not in keys:
                 keys[r] = eng.key_export(1, r)
         rev = ResidueEvaluator(eng.q, eng.p, eng.psi_q, eng.psi_p, eng.alpha, eng.log_n, keys, eng.params.log_slots)
         boot = ResidueBootstrapper(rev, desc, lambda pt: (lambda ell, sc: eng.pt_export(pt, ell, sc)))
-        ctl = ResidueController(eng, rev, boot, Recording.fresh)
+        ctl = ResidueController(eng, rev, boot, Recording.fresh, drops)
         orc.use_fast(True)            # Barrett build of the same C file (identical residues: test_fast_build_equals_definition_build)
         try:
             tw = {}
