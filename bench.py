@@ -693,6 +693,17 @@ def main():
                               "the GPU run executed each at, multiplied by the GPU run's per-sample operation counts (merged rotations counted "
                               "in the reference's units); plaintext encodes, additions and host orchestration not counted (lower bound)",
                     "ops": detail, "ops_single_thread": detail_one, "timed_composite_stage": res.get("composite")}
+                # the WHOLE pass timed on the CPU port (tools/cpu_forward_pass.py, ~2 minutes: too long for this run) - a static record
+                rec = os.path.join(ROOT, "profiles", "r03_r_cpu_forward_pass.json")
+                if os.path.exists(rec):
+                    try:
+                        full = json.load(open(rec))
+                        line["cpu_baseline"]["timed_full_pass_record"] = {
+                            "source": "profiles/r03_r_cpu_forward_pass.json (tools/cpu_forward_pass.py on a GPU box's host cores, round 3; not re-run here)",
+                            "cpu_port_s": full.get("cpu_port_s"), "cpu_threads": full.get("cpu_threads"), "gpu_s_same_run": full.get("gpu_s"),
+                            "ring": full.get("ring"), "same_residues_as_the_gpu_pass": full.get("same_residues_as_the_gpu_pass")}
+                    except Exception:
+                        pass
             else:
                 rate, n, dt = cpu_ntt_baseline(eng, orc, np, one, nq, args.cpu_seconds, cores)
                 line["cpu_baseline"] = {"value": round(rate, 1), "unit": "limb-NTT/s", "cores": cores, "kind": "port",
