@@ -90,7 +90,25 @@ def host_cpus():
 
 
 def micro(fa):
-    eng = fa.Engine("toy", device=0)
+    # the probes live in their own library (tools/probe/, built on demand): they are measurement code, not part of the product .so
+    import ctypes as C
+    import subprocess
+    pdir = os.path.join(ROOT, "tools", "probe")
+    subprocess.check_call(["make", "-s", "-C", pdir])
+    plib = C.CDLL(os.path.join(pdir, "libfhelin_probe.so"))
+    plib.fhelin_probe_microbench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
+
+    class _Probe:
+        def microbench(self, variant, iters, blocks):
+            ms = C.c_float()
+            rc = plib.fhelin_probe_microbench(0, variant, iters, blocks, C.byref(ms))
+            if rc:
+                raise SystemExit(f"probe failed ({rc})")
+            return ms.value
+
+        def close(self):
+            pass
+    eng = _Probe()
     names = ["v_mul_lo_u32 x8", "v_mul_hi_u32 x8", "v_mad_u64_u32 x8", "harvey butterfly x4", "v_fma_f64 x64",
              "add_u64 x8", "mulhi64 x8", "mullo64 x8", "lazy butterfly (approx quotient, no csub) x4", "harvey butterfly (variable twiddle) x4"]
     per_iter = [8, 8, 8, 4, 64, 8, 8, 8, 4, 4]

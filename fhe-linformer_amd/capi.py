@@ -95,7 +95,6 @@ def load_library():
         "fhelin_dev_upload": (i32, [vp, vp, vp, C.c_size_t]),
         "fhelin_dev_download": (i32, [vp, vp, vp, C.c_size_t]),
         "fhelin_ntt": (i32, [vp, vp, i32, i32, i32, i32]),
-        "fhelin_microbench": (i32, [vp, i32, i32, i32, f32p]),
         "fhelin_stats": (i32, [vp, u64p, i32, i32]),
         "fhelin_keygen": (i32, [vp]),
         "fhelin_gen_relin_key": (i32, [vp]),
@@ -351,11 +350,6 @@ class Engine:
         keys = ["limb_ntt", "keyswitch", "keyswitch_limbs", "rescale", "ct_pt_mult", "bootstrap", "encode", "rescale_limbs", "ct_pt_limbs",
                 "pool_malloc_calls", "pool_malloc_bytes", "pool_malloc_ns"]
         return {k: int(v) for k, v in zip(keys, out)}
-
-    def microbench(self, variant, iters=4096, blocks=2048):
-        ms = C.c_float()
-        self._ck(self.lib.fhelin_microbench(self.h, variant, iters, blocks, C.byref(ms)))
-        return ms.value
 
     # ---- keys
     def keygen(self):

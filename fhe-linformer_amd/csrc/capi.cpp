@@ -315,21 +315,4 @@ int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset) {
     return FHELIN_OK;
 }
 
-int fhelin_microbench(fhelin_ctx* c, int32_t variant, int32_t iters, int32_t blocks, float* ms) {
-    if (!c || !ms) return capi_fail(FHELIN_ERR_ARG, "null argument");
-    FHELIN_TRY
-    Context& x = c->ctx;
-    x.require_device();
-    if (variant < 0 || (variant > 9 && (variant < 100 || variant > 123)) || iters < 1 || blocks < 1) throw Error(FHELIN_ERR_ARG, "bad microbench arguments");
-    u64* out = x.dalloc<u64>((size_t)blocks * 256);
-    launch_mulbench(out, 8, variant, blocks, x.stream);  // warm
-    hip_check(hipEventRecord(x.ev_start, x.stream), "hipEventRecord");
-    launch_mulbench(out, iters, variant, blocks, x.stream);
-    hip_check(hipEventRecord(x.ev_stop, x.stream), "hipEventRecord");
-    hip_check(hipEventSynchronize(x.ev_stop), "hipEventSynchronize");
-    hip_check(hipEventElapsedTime(ms, x.ev_start, x.ev_stop), "hipEventElapsedTime");
-    x.pool.free(out);
-    FHELIN_CATCH
-}
-
 }  // extern "C"

@@ -75,7 +75,5 @@ void launch_ntt(const DeviceTables& t, const LimbBatch& b, bool inverse, hipStre
 // forward NTT of b (conv, [batch][2][ell][N]) whose row pass ends in the ModDown epilogue; b.data is scratch afterwards
 void launch_ntt_moddown(const DeviceTables& t, const LimbBatch& b, const NttModDown& md, hipStream_t s);
 
-// micro-benchmark kernels used by bench.py --micro to calibrate the integer-multiply ceiling
-void launch_mulbench(u64* out, int iters, int variant, int blocks, hipStream_t s);
 
 }  // namespace fhelin

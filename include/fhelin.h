@@ -128,9 +128,6 @@ int fhelin_ntt(fhelin_ctx* c, uint64_t* d_data, int32_t nvec, int32_t limb_first
  * device pool: [9] blocks obtained from hipMalloc, [10] their bytes, [11] host nanoseconds spent inside hipMalloc */
 int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset);
 
-/* instruction-rate probe (bench.py --micro): variant 0..7, see csrc/kernels_micro.hip */
-int fhelin_microbench(fhelin_ctx* c, int32_t variant, int32_t iters, int32_t blocks, float* ms);
-
 
 /* ---- keys (client side; sampling on the host, polynomial arithmetic on the GPU) ---------------- */
 int fhelin_keygen(fhelin_ctx* c);                       /* context->KeyGen()                  FHEController.cpp:47  */

@@ -4,7 +4,7 @@
 // which the CDNA4 guides do not list.  bench.py --micro runs these probes and reports ops/clk/CU so that
 // DESIGN.md's roofline argument rests on measured numbers.
 #include <hip/hip_runtime.h>
-#include "kernels.h"
+#include "../../fhe-linformer_amd/csrc/modarith.h"   // the butterflies being probed
 
 namespace fhelin {
 namespace {
@@ -157,3 +157,27 @@ void launch_mulbench(u64* out, int iters, int variant, int blocks, hipStream_t s
 }
 
 }  // namespace fhelin
+
+// ---- self-contained entry point of libfhelin_probe.so (tools/probe/Makefile): not part of the product library ----------------
+extern "C" int fhelin_probe_microbench(int device, int variant, int iters, int blocks, float* ms) {
+    if (!ms || iters < 1 || blocks < 1 || variant < 0 || (variant > 9 && (variant < 100 || variant > 123))) return 1;
+    if (hipSetDevice(device) != hipSuccess) return 2;
+    fhelin::u64* out = nullptr;
+    hipEvent_t a, b;
+    hipStream_t s;
+    if (hipMalloc(&out, (size_t)blocks * 256 * sizeof(fhelin::u64)) != hipSuccess) return 3;
+    (void)hipStreamCreate(&s);
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    fhelin::launch_mulbench(out, 8, variant, blocks, s);  // warm
+    (void)hipEventRecord(a, s);
+    fhelin::launch_mulbench(out, iters, variant, blocks, s);
+    (void)hipEventRecord(b, s);
+    const hipError_t e = hipEventSynchronize(b);
+    (void)hipEventElapsedTime(ms, a, b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipStreamDestroy(s);
+    (void)hipFree(out);
+    return e == hipSuccess ? 0 : 3;
+}
