@@ -440,15 +440,17 @@ def main():
         # level plan (include/fhelin.h fhelin_level_plan_*): ONE untimed pass of the same driver is recorded; every later pass
         # - the client's encryptions and the server's evaluation - starts each fresh encryption / bootstrap output with the
         # limbs the recording shows its consumers read.  Row-sharded runs exchange ciphertexts between ranks: not planned.
-        use_plan = not args.no_level_plan and not row_mode
+        # Row-sharded runs record the plan on the UNSHARDED driver (the plan is a property of the program: its sources - fresh
+        # encryptions and bootstraps - are replicated calls, in the same order on every rank) and apply it to the sharded passes
+        use_plan = not args.no_level_plan
         n_client_sources = 0
         plan = []
         if use_plan:
             x = pf.synthetic_tokens(S, 999)
             eng.level_plan_begin("record")
-            enc_rec = lf.encrypt_inputs(ctl, *pf.client_inputs(w, x))
+            enc_rec = lf.encrypt_inputs(ctl0, *pf.client_inputs(w, x))
             n_client_sources = sum(len(v) for v in enc_rec.values())      # the client's encryptions are the pass's first sources
-            eng.decrypt(lf.forward_encrypted(ctl, w, enc_rec))
+            eng.decrypt(lf.forward_encrypted(ctl0, w, enc_rec))
             plan = eng.level_plan_end()
             del enc_rec
 
@@ -556,7 +558,7 @@ def main():
             # and the pass at the levels the driver asks for (no plan), on inputs encrypted at level 0 as the driver does
             if use_plan:
                 eng.level_plan_begin("off")
-                enc_full = lf.encrypt_inputs(ctl, *pf.client_inputs(w, samples[-1][0]))
+                enc_full = lf.encrypt_inputs(ctl0, *pf.client_inputs(w, samples[-1][0]))
                 unplanned_ms = timed_passes(lambda: lf.forward_encrypted(ctl, w, enc_full))
                 # ... with every row evaluated as well: the reference's literal operation sequence at the reference's own levels
                 eng.set_lazy_rows(False)

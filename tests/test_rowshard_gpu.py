@@ -41,16 +41,25 @@ def _run(rank, world, port, q):
     eng.bootstrap_setup(3, 3, 16384)
     w = pf.synthetic_model(1234)
     x_in, X_E, X_F = pf.client_inputs(w, pf.synthetic_tokens(129, 4321))
-    # the unsharded pass of the same driver on the same engine: what a rank of one executes
+    # the unsharded pass of the same driver on the same engine: what a rank of one executes.  It is also the RECORDING pass of the
+    # level plan: the plan's sources (fresh encryptions, bootstraps) are replicated calls, so the plan of the unsharded program applies
+    # to the sharded passes as it stands
+    eng.level_plan_begin("record")
+    eng.decrypt(lf.forward(lf.GpuController(eng), w, x_in, X_E, X_F, None, "main"))
+    plan = eng.level_plan_end()
+    eng.level_plan_begin("apply")
     eng.stats(reset=True)
     eng.decrypt(lf.forward(lf.GpuController(eng), w, x_in, X_E, X_F, None, "main"))
     ks_full = eng.stats()["keyswitch"]
     ctl = shard.RowShardedController(lf.GpuController(eng), dist, shard.EngineTransport(eng, device=False),
                                      counter=lambda: eng.stats()["keyswitch"])
+    eng.level_plan_begin("apply")
     eng.stats(reset=True)
     out = lf.forward(ctl, w, x_in, X_E, X_F, None, "main")
     slots = eng.decrypt(out)
     st = eng.stats()
+    eng.level_plan_begin("off")
+    assert min(t for t in plan if t > 0) < 28
     dist.barrier()
     q.put((rank, slots.tolist(), out.export().tobytes(), (st["keyswitch"], ctl.row_ops, ks_full), ctl.gather_rows))
     eng.close()
