@@ -356,6 +356,18 @@ __device__ __forceinline__ void rows_body(const NttArgs& a, u64* lds, int vec, i
             for (int k = 0; k < 16; ++k)
                 x[k] = csub_mask(reduce_lazy_2q(x[k], c.q, c.sh, c.rr), c.q);   // from < 86q (lazy) or < 10q (semi-lazy)
         }
+#if defined(FHELIN_ROWS_DIRECT_STORE)   // A/B builds only: 16-byte stores straight from the bit-0 window (128-byte lane stride), no exchange
+        if constexpr (!MODDOWN) {
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                u64x2 v;
+                v.x = x[k];
+                v.y = x[k + 1];
+                reinterpret_cast<u64x2*>(base + 16 * tau)[k >> 1] = v;
+            }
+            return;
+        }
+#endif
         // window at bit 0 leaves 16 consecutive residues per thread (128-byte lane stride); one more LDS exchange
         // to the bit-8 window makes every store instruction a contiguous 512-byte wave access
         exchange(x, lds, tau, 0, 8, true);
