@@ -20,12 +20,16 @@ def desc_depth(eng):
     return eng.bootstrap_describe()["depth"]
 
 
-@pytest.mark.parametrize("preset,planned", [
-    ("reference", False),      # the reference's literal ring (N=2^15: full packing, two EvalMod ciphertexts), the driver's own levels
-    ("bench", True),           # the headline configuration of bench.py: N=2^16 (sparse packing, one EvalMod ciphertext) under a recorded
-                               # level plan - client encryptions at the planned limbs, bootstraps raising to fewer limbs
+@pytest.mark.parametrize("preset,planned,variant", [
+    ("reference", False, "main"),    # the reference's literal ring (N=2^15: full packing, two EvalMod ciphertexts), the driver's own levels
+    ("bench", True, "main"),         # the headline configuration of bench.py: N=2^16 (sparse packing, one EvalMod ciphertext) under a recorded
+                                     # level plan - client encryptions at the planned limbs, bootstraps raising to fewer limbs
+    pytest.param("reference", False, "main_2", marks=pytest.mark.skipif(
+        not __import__("os").environ.get("FHELIN_SLOW_TESTS"),
+        reason="src/main_2.cpp (attention for every token: 11.8 k key switches, +2 minutes of CPU oracle time); last run recorded in "
+               "profiles/r03_u_cpu_forward_pass_main2_n15.json (same residues: true); FHELIN_SLOW_TESTS=1 runs it")),
 ])
-def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc, preset, planned):
+def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc, preset, planned, variant):
     from fhe_linformer_amd import linformer as lf
     from oracle import plain_forward as pf, circuit_sim as cs
     from oracle.residue_eval import ResidueEvaluator, RCt
@@ -67,7 +71,7 @@ def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc, preset, plan
         if planned:                                               # record one pass of the driver on other inputs, then apply the plan
             eng.level_plan_begin("record")
             other = pf.client_inputs(w, pf.synthetic_tokens(S, 999))
-            eng.decrypt(lf.forward(lf.GpuController(eng), w, *other, None, "main"))
+            eng.decrypt(lf.forward(lf.GpuController(eng), w, *other, None, variant))
             plan = eng.level_plan_end()
             # sources in call order: 194 client encryptions, the encrypted zero (src/main.cpp:220), 8 bootstraps, the encrypted mask (:472)
             assert len(plan) == 194 + 1 + 8 + 1
@@ -76,7 +80,7 @@ def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc, preset, plan
             assert any(drops)
             eng.level_plan_begin("apply")
         tr = {}
-        out = lf.forward(Recording(eng), w, x_in, X_E, X_F, tr, "main")
+        out = lf.forward(Recording(eng), w, x_in, X_E, X_F, tr, variant)
         eng.level_plan_begin("off")
         got = {k: rct(v) for k, v in tr.items()}
         got["out"] = rct(out)
@@ -103,7 +107,7 @@ def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc, preset, plan
         orc.use_fast(True)            # Barrett build of the same C file (identical residues: test_fast_build_equals_definition_build)
         try:
             tw = {}
-            want = lf.forward_encrypted(ctl, w, lf.encrypt_inputs(ctl, x_in, X_E, X_F), tw, "main")
+            want = lf.forward_encrypted(ctl, w, lf.encrypt_inputs(ctl, x_in, X_E, X_F), tw, variant)
         finally:
             orc.use_fast(False)
         assert ctl.n_boot == 8 and not ctl.fresh                  # all 8 bootstraps, every fresh encryption consumed
@@ -114,7 +118,7 @@ def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc, preset, plan
             assert g.scale == r.scale, (k, "scale")
             assert np.array_equal(g.d, r.d), k
         # ... and it is the forward pass: the logits match the clear-text circuit
-        ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, x_in, X_E, X_F, None, "main"))
+        ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, x_in, X_E, X_F, None, variant))
         assert np.max(np.abs(lg - ref)) < 2e-2 and int(np.argmax(lg)) == int(np.argmax(ref))
     finally:
         eng.close()

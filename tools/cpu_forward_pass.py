@@ -2,7 +2,8 @@
 """The whole encrypted forward pass TIMED on the CPU port (oracle/residue_controller.py over oracle/fhe_oracle.c, Barrett build,
 OpenMP over limbs), beside the same pass on the GPU: the real counterpart of bench.py's extrapolated `cpu_baseline`.
 The oracle replays the GPU run's fresh encryptions and must end in the GPU's residues (checked).  Usage (GPU box):
-    python tools/cpu_forward_pass.py [log_n=16] [threads=16] [plan=1] > profiles/rNN_cpu_forward_pass.json"""
+    python tools/cpu_forward_pass.py [log_n=16] [threads=16] [plan=1] [variant=main] > profiles/rNN_cpu_forward_pass.json
+variant main_2 = src/main_2.cpp (attention for every token); run it without a plan (plan=0)."""
 import json
 import os
 import sys
@@ -24,6 +25,8 @@ LD = np.longdouble
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 planned = (int(sys.argv[3]) if len(sys.argv) > 3 else 1) != 0
+variant = sys.argv[4] if len(sys.argv) > 4 else "main"
+assert variant == "main" or not planned
 S = 129
 w = pf.synthetic_model(1234)
 x_in, X_E, X_F = pf.client_inputs(w, pf.synthetic_tokens(S, 4321))
@@ -54,7 +57,7 @@ class Recording(lf.GpuController):
 drops = []
 if planned:
     eng.level_plan_begin("record")
-    eng.decrypt(lf.forward(lf.GpuController(eng), w, *pf.client_inputs(w, pf.synthetic_tokens(S, 999)), None, "main"))
+    eng.decrypt(lf.forward(lf.GpuController(eng), w, *pf.client_inputs(w, pf.synthetic_tokens(S, 999)), None, variant))
     plan = eng.level_plan_end()
     out_ell = eng.n_q - desc["depth"]
     drops = [max(0, out_ell - t) if t >= 1 else 0 for t in plan[195:203]]
@@ -67,13 +70,13 @@ for _ in range(2):
     if planned:
         eng.level_plan_begin("apply", first_source=194)
     eng.sync(); t0 = time.perf_counter()
-    eng.decrypt(lf.forward_encrypted(ctl0, w, enc)); eng.sync()
+    eng.decrypt(lf.forward_encrypted(ctl0, w, enc, None, variant)); eng.sync()
     gpu_s = time.perf_counter() - t0
 del enc
 if planned:
     eng.level_plan_begin("apply")
 eng.stats(reset=True)
-out = lf.forward(Recording(eng), w, x_in, X_E, X_F, None, "main")
+out = lf.forward(Recording(eng), w, x_in, X_E, X_F, None, variant)
 got = rct(out)
 stats = eng.stats()
 eng.level_plan_begin("off")
@@ -97,10 +100,10 @@ orc.use_fast(True)
 orc.set_threads(threads)
 encs = lf.encrypt_inputs(ctl, x_in, X_E, X_F)
 t0 = time.perf_counter()
-want = lf.forward_encrypted(ctl, w, encs, None, "main")
+want = lf.forward_encrypted(ctl, w, encs, None, variant)
 cpu_s = time.perf_counter() - t0
 same = bool(np.array_equal(got.d, want.d) and got.scale == want.scale)
-print(json.dumps({"what": "one encrypted Linformer-d128 forward pass (src/main.cpp call sequence, S=129+CLS, 8 bootstraps), server side",
+print(json.dumps({"what": f"one encrypted Linformer-d128 forward pass (src/{variant}.cpp call sequence, S=129+CLS, 8 bootstraps), server side",
                   "ring": f"N=2^{log_n}, 28+{eng.n_p} limbs, 16384 slots", "level_plan": planned,
                   "cpu_port_s": round(cpu_s, 1), "cpu_threads": threads,
                   "cpu_port": "oracle/residue_controller.py over oracle/fhe_oracle.c (-DORC_FAST Barrett build, OpenMP over limbs); includes the "
