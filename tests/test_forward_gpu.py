@@ -18,6 +18,8 @@ pytestmark = pytest.mark.gpu
     ("main", "bench", 28, 200),           # SURVEY 8(d)'s second input size: 201 rows = 128 + a ragged 73 (src/main.cpp:300-309), 7 GELU
                                           # containers (:354-358) -> 10 bootstraps
     ("main_2", "reference", 28, 200),
+    ("main", "reference", 28, 128),       # the smallest input the driver accepts (128 < S + 1): the second wrapped half holds ONE token
+    ("main", "reference", 28, 255),       # the largest (S + 1 = 256 rows: two full halves, 8 GELU containers, 11 bootstraps)
 ])
 def test_encrypted_forward_matches_plaintext_circuit(fa, variant, preset, n_q, S):
     from fhe_linformer_amd import linformer as lf
