@@ -1097,7 +1097,16 @@ std::vector<CtPtr> Evaluator::mult_batch(const std::vector<CtPtr>& a, const std:
         const int B = (int)idx.size(), ell = x[first]->ell;
         const size_t pn = (size_t)ell * c_.N;
         std::vector<CtPtr> d = new_ct_batch(B, 3, ell, 2, 0, x[first]->slots);   // tensor products, contiguous [B][3][ell][N]
-        for (int k = 0; k < B; ++k) launch_tensor(c_.dt, d[k]->d, x[idx[k]]->d, y[idx[k]]->d, ell, c_.stream);
+        for (int k0 = 0; k0 < B; k0 += EwItems::MAX_ITEMS) {   // all tensor products of the batch in one launch per 32 pairs
+            EwItems it;
+            it.n = std::min(B - k0, (int)EwItems::MAX_ITEMS);
+            for (int k = 0; k < it.n; ++k) {
+                it.out[k] = d[k0 + k]->d;
+                it.a[k] = x[idx[k0 + k]]->d;
+                it.b[k] = y[idx[k0 + k]]->d;
+            }
+            launch_tensor_items(c_.dt, it, ell, c_.stream);
+        }
         std::vector<CtPtr> o = new_ct_batch(B, 2, ell, 2, 0, x[first]->slots);
         keyswitch_batch(B, d[0]->d + 2 * pn, 3 * pn, ell, *relin_key, o[0]->d, 2 * pn, d[0]->d, d[0]->d + pn, 3 * pn, nullptr, nullptr, 0);
         for (int k = 0; k < B; ++k) {

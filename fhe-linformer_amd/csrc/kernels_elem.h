@@ -31,6 +31,9 @@ struct LinComb {
 };
 void launch_ew_lincomb(const DeviceTables& t, u64* out, const LinComb& lc, const u64* scal, int ell, hipStream_t s, int in_limbs = 0);
 void launch_tensor(const DeviceTables& t, u64* d, const u64* a, const u64* b, int ell, hipStream_t s);
+struct EwItems;
+// it.out[k] [3][ell][N] = tensor(it.a[k], it.b[k]) for the it.n pairs of one batched multiplication, in ONE launch
+void launch_tensor_items(const DeviceTables& t, const EwItems& it, int ell, hipStream_t s);
 void launch_automorph(const DeviceTables& t, u64* out, const u64* in, const u32* map, int nvec, hipStream_t s);
 // the same gather, every word stored as pack30(word) (low 30 bits | next 30 bits << 32): operands of launch_ks_inner_multi
 void launch_automorph_pack30(const DeviceTables& t, u64* out, const u64* in, const u32* map, int nvec, hipStream_t s);

@@ -245,6 +245,30 @@ __global__ __launch_bounds__(256) void tensor_kernel(DeviceTables t, u64* d, con
     D[2 * poly + l * row + n2] = d2;
 }
 
+// the same for up to EwItems::MAX_ITEMS independent pairs in one launch (the products of a batched multiplication): grid.z = pair
+__global__ __launch_bounds__(256) void tensor_items_kernel(DeviceTables t, EwItems it, int ell) {
+    const int l = blockIdx.y, k = blockIdx.z;
+    const Barrett br = load_barrett(t, l);
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const size_t poly = (size_t)ell * row;
+    const u64x2* A = reinterpret_cast<const u64x2*>(it.a[k]);
+    const u64x2* B = reinterpret_cast<const u64x2*>(it.b[k]);
+    const u64x2 a0 = A[l * row + n2], a1 = A[poly + l * row + n2];
+    const u64x2 b0 = B[l * row + n2], b1 = B[poly + l * row + n2];
+    u64x2 d0, d1, d2;
+    d0.x = mul_mod(a0.x, b0.x, br);
+    d0.y = mul_mod(a0.y, b0.y, br);
+    d2.x = mul_mod(a1.x, b1.x, br);
+    d2.y = mul_mod(a1.y, b1.y, br);
+    d1.x = add_mod(mul_mod(a0.x, b1.x, br), mul_mod(a1.x, b0.x, br), br.q);
+    d1.y = add_mod(mul_mod(a0.y, b1.y, br), mul_mod(a1.y, b0.y, br), br.q);
+    u64x2* D = reinterpret_cast<u64x2*>(it.out[k]);
+    D[l * row + n2] = d0;
+    D[poly + l * row + n2] = d1;
+    D[2 * poly + l * row + n2] = d2;
+}
+
 // K4: out[v][j] = in[v][map[j]]
 __global__ __launch_bounds__(256) void automorph_kernel(int log_n, u64* out, const u64* in, const u32* map) {
     const int v = blockIdx.y;
@@ -409,6 +433,10 @@ void launch_ew_lincomb(const DeviceTables& t, u64* out, const LinComb& lc, const
 }
 void launch_tensor(const DeviceTables& t, u64* d, const u64* a, const u64* b, int ell, hipStream_t s) {
     hipLaunchKernelGGL(tensor_kernel, grid2(t.log_n, ell), dim3(256), 0, s, t, d, a, b, ell);
+}
+void launch_tensor_items(const DeviceTables& t, const EwItems& it, int ell, hipStream_t s) {
+    if (it.n <= 0) return;
+    hipLaunchKernelGGL(tensor_items_kernel, dim3((1u << t.log_n) / 512, (unsigned)ell, (unsigned)it.n), dim3(256), 0, s, t, it, ell);
 }
 void launch_automorph(const DeviceTables& t, u64* out, const u64* in, const u32* map, int nvec, hipStream_t s) {
     if (nvec <= 0) return;
