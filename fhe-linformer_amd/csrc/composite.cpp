@@ -400,16 +400,48 @@ CtVec Composite::matmulCRlarge(const std::vector<CtVec>& rows, const std::vector
 }
 
 // sum_i rot(terms[i], step * i).  The reference builds these sums as a Horner chain (rotate the running sum by `step`,
-// add the next term: n-1 DEPENDENT key switches); the same sum as a binary tree needs the same n-1 rotations but
-// only ceil(log2 n) dependent steps, each a batched key switch with one key (step * 2^level): every launch fills the
-// GPU and the noise passes through log n instead of n key switches.
+// add the next term: n-1 DEPENDENT key switches).  Default form (round 3): radix-8 levels with a SHARED ModDown -
+//   i = 8 m + k:  sum_i rot(t_i, step i) = sum_m rot( sum_{k<8} rot(t_{8m+k}, step k), 8 step m )
+// every inner sum of eight terms is ONE key switch of seven rotated terms accumulated in the extended basis plus the unrotated one
+// (Evaluator::rotate_each_sum_rows: a ModUp per term, one ModDown per sum), all inner sums of a level batched; the next level does
+// the same with the unit 8 step.  128 terms: 127 ModUps as before but 16 + 2 + 1 = 19 ModDowns instead of 127, and every term passes
+// through 3 key switches instead of 7.  Needs the keys of unit * {1..7} per level (the client's key set has them for the units
+// 1, 8, 512; the last level of <= 128 terms needs 64 only); otherwise - or with FHELIN_MERGE_ROT=0 - the binary tree of round 1
+// (ceil(log2 n) dependent levels, one batched key switch with one key per level).
 CtPtr Composite::shift_sum(const CtVec& terms, int step) {
     if (terms.empty()) throw Error(FHELIN_ERR_ARG, "shift_sum: empty vector");
     CtVec cur = terms;
+    int unit = step;
+    while (cur.size() > 1 && merge_rot_) {
+        const int width = (int)std::min<size_t>(8, cur.size());
+        std::vector<int> need;
+        for (int k = 1; k < width; ++k) need.push_back(unit * k);
+        if (!ev_.have_rotation_keys(need, cur[0]->slots)) break;
+        // full groups of eight go through one batched call, a shorter last group through its own
+        const size_t full = cur.size() / 8;
+        CtVec nxt;
+        if (full) {
+            std::vector<CtVec> rows(full);
+            for (size_t m = 0; m < full; ++m) rows[m].assign(cur.begin() + 8 * m, cur.begin() + 8 * m + 8);
+            std::vector<int> idx;
+            for (int k = 0; k < 8; ++k) idx.push_back(unit * k);
+            nxt = ev_.rotate_each_sum_rows(rows, idx);
+        }
+        if (cur.size() % 8) {
+            CtVec tail(cur.begin() + 8 * full, cur.end());
+            std::vector<int> idx;
+            for (size_t k = 0; k < tail.size(); ++k) idx.push_back(unit * (int)k);
+            nxt.push_back(tail.size() == 1 ? tail[0] : ev_.rotate_each_sum(tail, idx));
+        }
+        cur.swap(nxt);
+        unit *= 8;
+    }
+    if (cur.size() == 1) return cur[0];
+    // binary tree over what is left (all of it when the radix-8 keys are missing), rotations by unit * 2^level
     for (int level = 0; cur.size() > 1; ++level) {
         CtVec odd;
         for (size_t j = 1; j < cur.size(); j += 2) odd.push_back(cur[j]);
-        CtVec rot = ev_.rotate_batch(odd, step * (1 << level));
+        CtVec rot = ev_.rotate_batch(odd, unit * (1 << level));
         CtVec even;
         for (size_t j = 0; j + 1 < cur.size(); j += 2) even.push_back(cur[j]);
         CtVec nxt = ev_.add_batch(even, rot);
@@ -419,19 +451,96 @@ CtPtr Composite::shift_sum(const CtVec& terms, int step) {
     return cur[0];
 }
 
-// rot(c, step * i) for i = 0..n-1 by doubling: level b rotates everything known so far by step * 2^b (one batched key
-// switch per level) instead of n-1 dependent rotations by `step`.
-CtVec Composite::shift_fan(const CtPtr& c, int n, int step) {
-    CtVec out(n);
-    if (n < 1) return out;
-    out[0] = c;
-    for (int have = 1; have < n; have *= 2) {
-        const int cnt = std::min(have, n - have);
-        CtVec src(out.begin(), out.begin() + cnt);
-        CtVec rot = ev_.rotate_batch(src, step * have);
-        for (int i = 0; i < cnt; ++i) out[have + i] = rot[i];
+// rot(c, step * i) for the listed i (all below n).  Default form (round 3): i = 64 a + 8 b + k, three levels of HOISTED rotations -
+// rot(c, 64 step a) from c, rot(., 8 step b) from each of those, rot(., step k) from each of those: every level is one ModUp per
+// input for all its indices (Evaluator::rotate_many / rotate_many_batch), 1 + 2 + 16 = 19 ModUps for 128 rows instead of 127, and
+// every row passes through at most 3 key switches.  Row i is the same composition whichever rows are asked for.  Needs the keys of
+// step {1..7}, 8 step {1..7}, 64 step a; otherwise the doubling fan of round 1 (rot(c, j) = rot(rot(c, j - 2^h), 2^h)).
+CtVec Composite::shift_fan_rows(const CtPtr& c, int n, int step, const std::vector<int>& idx) {
+    CtVec out(idx.size());
+    if (idx.empty()) return out;
+    for (int i : idx)
+        if (i < 0 || i >= n) throw Error(FHELIN_ERR_ARG, "shift_fan: row out of range");
+    const int top = n - 1;   // the form (hoisted levels or doubling chain) is a property of the call, not of the rows that are read
+    std::vector<int> need;
+    for (int k = 1; k < 8 && k <= top; ++k) need.push_back(step * k);
+    for (int b = 1; b < 8 && 8 * b <= top; ++b) need.push_back(8 * step * b);
+    for (int a = 1; 64 * a <= top; ++a) need.push_back(64 * step * a);
+    const bool hoisted = merge_rot_ && (need.empty() || ev_.have_rotation_keys(need, c->slots));
+    if (!hoisted) {
+        std::map<int, CtPtr> fan;
+        fan[0] = c;
+        std::vector<char> want(std::max(n, 1), 0);
+        for (int i : idx)
+            for (int j = i; j > 0;) {
+                want[j] = 1;
+                int h = 0;
+                while ((2 << h) <= j) ++h;
+                j -= 1 << h;
+            }
+        for (int have = 1; have < n; have *= 2) {
+            CtVec src;
+            std::vector<int> dst;
+            for (int j = have; j < std::min(2 * have, n); ++j)
+                if (want[j]) {
+                    src.push_back(fan.at(j - have));
+                    dst.push_back(j);
+                }
+            if (src.empty()) continue;
+            CtVec rot = ev_.rotate_batch(src, step * have);
+            for (size_t k = 0; k < dst.size(); ++k) fan[dst[k]] = rot[k];
+        }
+        for (size_t k = 0; k < idx.size(); ++k) out[k] = fan.at(idx[k]);
+        return out;
+    }
+    // level 1: the 64-blocks that hold a wanted row
+    std::vector<int> as;
+    for (int i : idx)
+        if (std::find(as.begin(), as.end(), i / 64) == as.end()) as.push_back(i / 64);
+    std::sort(as.begin(), as.end());
+    std::vector<int> a_idx;
+    for (int a : as) a_idx.push_back(64 * step * a);
+    const CtVec A = ev_.rotate_many(c, a_idx);                         // index 0 -> c itself
+    // level 2: per 64-block the 8-blocks that hold a wanted row (the union over the blocks: one index list for the batch)
+    std::vector<int> bs;
+    for (int i : idx)
+        if (std::find(bs.begin(), bs.end(), (i % 64) / 8) == bs.end()) bs.push_back((i % 64) / 8);
+    std::sort(bs.begin(), bs.end());
+    std::vector<int> b_idx;
+    for (int b : bs) b_idx.push_back(8 * step * b);
+    const std::vector<CtVec> Bm = ev_.rotate_many_batch(A, b_idx);     // [a][b]
+    // level 3: the (a, b) pairs that hold a wanted row, all their k at once
+    std::vector<std::pair<int, int>> ab;
+    for (int i : idx) {
+        const std::pair<int, int> key{i / 64, (i % 64) / 8};
+        if (std::find(ab.begin(), ab.end(), key) == ab.end()) ab.push_back(key);
+    }
+    std::vector<int> ks;
+    for (int i : idx)
+        if (std::find(ks.begin(), ks.end(), i % 8) == ks.end()) ks.push_back(i % 8);
+    std::sort(ks.begin(), ks.end());
+    std::vector<int> k_idx;
+    for (int k : ks) k_idx.push_back(step * k);
+    CtVec Bsel;
+    for (const auto& e : ab) {
+        const size_t ai = std::find(as.begin(), as.end(), e.first) - as.begin();
+        const size_t bi = std::find(bs.begin(), bs.end(), e.second) - bs.begin();
+        Bsel.push_back(Bm[ai][bi]);
+    }
+    const std::vector<CtVec> Km = ev_.rotate_many_batch(Bsel, k_idx);  // [(a, b)][k]
+    for (size_t r = 0; r < idx.size(); ++r) {
+        const int i = idx[r];
+        const size_t abi = std::find(ab.begin(), ab.end(), std::pair<int, int>{i / 64, (i % 64) / 8}) - ab.begin();
+        const size_t ki = std::find(ks.begin(), ks.end(), i % 8) - ks.begin();
+        out[r] = Km[abi][ki];
     }
     return out;
+}
+
+CtVec Composite::shift_fan(const CtPtr& c, int n, int step) {
+    std::vector<int> all(std::max(n, 0));
+    for (int i = 0; i < n; ++i) all[i] = i;
+    return shift_fan_rows(c, n, step, all);
 }
 
 CtPtr Composite::matmulScores(const CtVec& queries, const CtPtr& key) {
@@ -463,39 +572,8 @@ CtVec Composite::unwrapExpanded(CtPtr c, int n) {
 }
 
 CtVec Composite::unwrapExpanded_rows(CtPtr c, int n, const std::vector<int>& idx) {
-    if ((int)idx.size() == n) {
-        bool identity = true;
-        for (int i = 0; i < n; ++i) identity = identity && idx[i] == i;
-        if (identity) return unwrapExpanded(c, n);
-    }
-    // shift_fan builds rot(c, i) as rot(rot(c, i - 2^h), 2^h), h = highest set bit of i: the needed rows and their prefixes
-    std::map<int, CtPtr> fan;
-    fan[0] = c;
-    std::vector<char> need(std::max(n, 1), 0);
-    for (int i : idx) {
-        if (i < 0 || i >= n) throw Error(FHELIN_ERR_ARG, "unwrapExpanded_rows: row out of range");
-        for (int j = i; j > 0;) {
-            need[j] = 1;
-            int h = 0;
-            while ((2 << h) <= j) ++h;
-            j -= 1 << h;
-        }
-    }
-    for (int have = 1; have < n; have *= 2) {
-        CtVec src;
-        std::vector<int> dst;
-        for (int j = have; j < std::min(2 * have, n); ++j)
-            if (need[j]) {
-                src.push_back(fan.at(j - have));
-                dst.push_back(j);
-            }
-        if (src.empty()) continue;
-        CtVec rot = ev_.rotate_batch(src, have);
-        for (size_t k = 0; k < dst.size(); ++k) fan[dst[k]] = rot[k];
-    }
-    CtVec sel;
-    for (int i : idx) sel.push_back(fan.at(i));
-    return repeat_batch(ev_.mult_plain_batch(sel, mod_n_mask(128, 0)), 128, 1);
+    // row i of the fan is the same composition whichever rows are asked for (shift_fan_rows)
+    return repeat_batch(ev_.mult_plain_batch(shift_fan_rows(c, n, 1, idx), mod_n_mask(128, 0)), 128, 1);
 }
 
 CtVec Composite::unwrapScoresExpanded(CtPtr c, int n) {

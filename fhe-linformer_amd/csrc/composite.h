@@ -56,6 +56,7 @@ public:
     // shifted sums / fans shared by the layout shuffles (log-depth forms of the reference's rotate-by-one chains)
     CtPtr shift_sum(const CtVec& terms, int step);          // sum_i rot(terms[i], step * i)
     CtVec shift_fan(const CtPtr& c, int n, int step);       // rot(c, step * i), i = 0..n-1
+    CtVec shift_fan_rows(const CtPtr& c, int n, int step, const std::vector<int>& idx);   // the listed rows only
 
     // layout shuffles                                                                         :1060-1205
     CtPtr wrapUpRepeated(const CtVec& v);

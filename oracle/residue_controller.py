@@ -233,15 +233,9 @@ class ResidueController:
         return self.rev.wrapUpExpanded(list(v), self._mod_mask(128, 0).enc)
 
     def unwrapExpanded(self, c, n):
-        """:1086-1100 with the doubling fan of Composite::shift_fan: rot(c, j) = rot(rot(c, j - 2^h), 2^h), h = top bit of j"""
-        rev, mask, fan = self.rev, self._mod_mask(128, 0).enc, {0: c}
-
-        def rot(j):
-            if j not in fan:
-                h = 1 << (j.bit_length() - 1)
-                fan[j] = rev.rotate(rot(j - h), h)
-            return fan[j]
-        return _LazyRows(n, lambda i: rev.repeat(rev.mult_plain(rot(i), mask), 128, 1))
+        """:1086-1100 with the three-level fan of Composite::shift_fan_rows (ResidueEvaluator.fan_row); rows evaluated when read"""
+        rev, mask, memo = self.rev, self._mod_mask(128, 0).enc, {}
+        return _LazyRows(n, lambda i: rev.repeat(rev.mult_plain(rev.fan_row(c, i, 1, memo, n - 1), mask), 128, 1))
 
     def unwrapRepeatedLarge(self, cs, n):
         return self.rev.unwrapRepeatedLarge(list(cs), n, lambda v: self._mask(v).enc)

@@ -416,12 +416,25 @@ class ResidueEvaluator:
     def repeat(self, a, slots, padding=1, early_rescale=True, merge=True):
         return self.rotsum(a, slots, -padding, early_rescale, merge)
 
-    def shift_sum(self, terms, step):
-        """sum_i rot(terms[i], step * i) as the binary tree of Composite::shift_sum"""
-        cur = list(terms)
+    def shift_sum(self, terms, step, merge=True):
+        """sum_i rot(terms[i], step * i) as Composite::shift_sum builds it: radix-8 levels, every group of eight consecutive terms one
+        shared-ModDown key switch (seven rotated terms + the unrotated one), then the same with the unit 8 * step; the binary tree
+        of round 1 over what is left when the keys of a level are missing"""
+        cur, unit = list(terms), step
+        while len(cur) > 1 and merge:
+            width = min(8, len(cur))
+            if not self.have([unit * k for k in range(1, width)]):
+                break
+            full, nxt = len(cur) // 8, []
+            for m in range(full):
+                nxt.append(self.rotate_each_sum(cur[8 * m:8 * m + 8], [unit * k for k in range(8)]))
+            if len(cur) % 8:
+                tail = cur[8 * full:]
+                nxt.append(tail[0] if len(tail) == 1 else self.rotate_each_sum(tail, [unit * k for k in range(len(tail))]))
+            cur, unit = nxt, unit * 8
         level = 0
         while len(cur) > 1:
-            odd = [self.rotate(c, step * (1 << level)) for c in cur[1::2]]
+            odd = [self.rotate(c, unit * (1 << level)) for c in cur[1::2]]
             even = cur[0:len(cur) - 1:2]
             nxt = [self.add(e, o) for e, o in zip(even, odd)]
             if len(cur) & 1:
@@ -430,15 +443,29 @@ class ResidueEvaluator:
             level += 1
         return cur[0]
 
+    def fan_row(self, c, i, step, memo, top=None, merge=True):
+        """rot(c, step * i) as Composite::shift_fan_rows composes it: i = 64 a + 8 b + k, rot(rot(rot(c, 64 step a), 8 step b), step k)
+        (three hoisted levels in the library; a hoisted rotation equals the separate one); the doubling chain of round 1 when the
+        keys are missing.  memo: shared between the rows of one fan."""
+        top = i if top is None else top
+        need = [step * k for k in range(1, 8) if k <= top] + [8 * step * b for b in range(1, 8) if 8 * b <= top] + \
+               [64 * step * a for a in range(1, top // 64 + 1)]
+        if not (merge and (not need or self.have(need))):
+            if i not in memo:
+                h = 1 << (i.bit_length() - 1) if i else 0
+                memo[i] = c if i == 0 else self.rotate(self.fan_row(c, i - h, step, memo, top, merge), step * h)
+            return memo[i]
+        a, b, k = i // 64, (i % 64) // 8, i % 8
+        if ("a", a) not in memo:
+            memo[("a", a)] = self.rotate(c, 64 * step * a) if a else c
+        if ("b", a, b) not in memo:
+            memo[("b", a, b)] = self.rotate(memo[("a", a)], 8 * step * b) if b else memo[("a", a)]
+        return self.rotate(memo[("b", a, b)], step * k) if k else memo[("b", a, b)]
+
     def shift_fan(self, c, n, step):
-        """rot(c, step * i), i < n, by doubling (Composite::shift_fan)"""
-        out = [c]
-        have = 1
-        while have < n:
-            cnt = min(have, n - have)
-            out += [self.rotate(x, step * have) for x in out[:cnt]]
-            have *= 2
-        return out[:n]
+        """rot(c, step * i), i < n (Composite::shift_fan)"""
+        memo = {}
+        return [self.fan_row(c, i, step, memo, n - 1) for i in range(n)]
 
     def matmul_pt(self, rows, w_enc, bias_enc, slots, padding):
         out = [self.rotsum(self.mult_plain(r, w_enc), slots, padding) for r in rows]
