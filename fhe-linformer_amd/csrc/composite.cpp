@@ -666,22 +666,53 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
         Ball.insert(Ball.end(), B.begin(), B.end());
     }
     const CtVec Dall = repeat_batch(Ball, 4, -4096);   // [k][group]
-    // stage 2: per wanted token and block, the token's 512 slots of D replicated over the 8 positions of a range
-    CtVec src;
-    std::vector<PtPtr> masks;
-    for (size_t gi = 0; gi < groups.size(); ++gi) {
-        const int i = groups[gi].first, a = groups[gi].second;
-        for (int j = 8 * a; j < 8 * a + 8 && j < quantities[i]; ++j) {
-            const int token = i * 32 + j;
-            if (token < first || token >= first + count) continue;
-            for (int k = 0; k < 4; ++k) {
-                src.push_back(Dall[(size_t)k * groups.size() + gi]);
-                masks.push_back(mod_range_mask(4096, 512 * (j - 8 * a), 512 * (j - 8 * a + 1)));
+    // stage 2 (round 3 form): out_{8a+b, k} = sum_{m<8} rot(D * mask_b, 512 m) with mask_b = (slot mod 4096 in [512b, 512b+512)).  A rotation
+    // commutes with the mask: rot(D * mask_b, 512 m) = rot(D, 512 m) * mask_{(b-m) mod 8}, so the eight rotations of D - ONE hoisted key
+    // switch per (container, range, block): one ModUp, seven inner products - serve all eight tokens of the range, and every output is an
+    // inner sum of eight ciphertext x plaintext products (Evaluator::dot_plain_groups: the rotated ciphertexts are read once for all
+    // tokens).  Before: one merged key switch of seven rotations PER OUTPUT (520 ModUps + 520 ModDowns + 3640 gathered inner products
+    // per pass); now 80 ModUps, 560 ModDowns, 560 inner products.  The outputs leave with noise degree 2 (rescaled by their consumer).
+    std::vector<size_t> d_of;                       // indices into Dall that hold a wanted token, and per such input the wanted b's
+    std::vector<std::vector<int>> bs_of;
+    for (int k = 0; k < 4; ++k)
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const int i = groups[gi].first, a = groups[gi].second;
+            std::vector<int> bs;
+            for (int j = 8 * a; j < 8 * a + 8 && j < quantities[i]; ++j) {
+                const int token = i * 32 + j;
+                if (token >= first && token < first + count) bs.push_back(j - 8 * a);
             }
+            if (bs.empty()) continue;
+            d_of.push_back((size_t)k * groups.size() + gi);
+            bs_of.push_back(bs);
         }
+    CtVec dsel;
+    for (size_t x : d_of) dsel.push_back(Dall[x]);
+    std::vector<int> ridx;
+    for (int m = 0; m < 8; ++m) ridx.push_back(512 * m);
+    const std::vector<CtVec> rot = ev_.rotate_many_batch(dsel, ridx);      // [input][m], m = 0: the input itself
+    std::map<std::pair<int, int>, CtPtr> made;                             // (token, k) -> output
+    for (size_t x = 0; x < d_of.size(); ++x) {
+        const int k = (int)(d_of[x] / groups.size());
+        const size_t gi = d_of[x] % groups.size();
+        const int i = groups[gi].first, a = groups[gi].second;
+        const std::vector<int>& bs = bs_of[x];
+        std::vector<std::vector<PtPtr>> pts(bs.size(), std::vector<PtPtr>(8));
+        for (size_t q = 0; q < bs.size(); ++q)
+            for (int m = 0; m < 8; ++m) {
+                const int bb = ((bs[q] - m) % 8 + 8) % 8;
+                pts[q][m] = mod_range_mask(4096, 512 * bb, 512 * (bb + 1));
+            }
+        CtVec dest = ev_.new_ct_batch((int)bs.size(), 2, rot[x][0]->ell, 2, 0, rot[x][0]->slots);
+        if (!ev_.dot_plain_groups(rot[x], pts, 0, dest))
+            for (size_t q = 0; q < bs.size(); ++q) dest[q] = ev_.dot_plain(rot[x], pts[q], 0, dest[q]);
+        for (size_t q = 0; q < bs.size(); ++q) made[{i * 32 + 8 * a + bs[q], k}] = dest[q];
     }
-    CtVec rep = repeat_batch(ev_.mult_plain_each(src, masks), 8, -512);
-    for (size_t i = 0; i + 3 < rep.size(); i += 4) out.push_back(CtVec(rep.begin() + i, rep.begin() + i + 4));
+    for (int token = first; token < first + count; ++token) {
+        CtVec four;
+        for (int k = 0; k < 4; ++k) four.push_back(made.at({token, k}));
+        out.push_back(four);
+    }
     return out;
 }
 

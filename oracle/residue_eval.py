@@ -491,8 +491,8 @@ class ResidueEvaluator:
     def unwrapRepeatedLarge(self, containers, n_tokens, enc_of_values):
         """composite.cpp unwrapRepeatedLarge (two-stage shared form): per container, block k and range a (8 tokens = 4096
         slots) one mask (slot mod 512 in block k, slot in range a), one merged key switch copying block k of every token of
-        the range over the token's own 512 slots, and repeat(., 4, -4096); per (token, k) a mask (slot mod 4096 in the
-        token's 512 slots of its range) and repeat(., 8, -512).  enc_of_values(vector) -> enc callback for that vector."""
+        the range over the token's own 512 slots, and repeat(., 4, -4096); per (token, k) the inner sum of the eight rotations of that
+        result with the token's shifted masks.  enc_of_values(vector) -> enc callback for that vector."""
         ns = self.slots
         idx = np.arange(ns)
         D = {}
@@ -507,12 +507,24 @@ class ResidueEvaluator:
                 B = self.rotate_sum(A, [128 * (k - mm) for mm in range(4) if mm != k])
                 row.append(self.repeat(B, 4, -4096))
             D[(i, a)] = row
+        # stage 2: out_{8a+b, k} = sum_{m<8} rot(D_k, 512 m) * mask_{(b - m) mod 8}  (== sum_m rot(D_k * mask_b, 512 m): the rotation
+        # commutes with the mask), the eight rotations of D_k shared by the tokens of the range; exact sums of dyadic products, noise degree 2
+        masks = [((idx % 4096 >= 512 * bb) & (idx % 4096 < 512 * (bb + 1))).astype(np.float64) for bb in range(8)]
+        rot = {}
         out = []
         for t in range(n_tokens):
             i, j = divmod(t, 32)
             a, b = divmod(j, 8)
-            tm = ((idx % 4096 >= 512 * b) & (idx % 4096 < 512 * (b + 1))).astype(np.float64)
-            out.append([self.repeat(self.mult_plain(D[(i, a)][k], enc_of_values(tm)), 8, -512) for k in range(4)])
+            four = []
+            for k in range(4):
+                if (i, a, k) not in rot:
+                    rot[(i, a, k)] = [D[(i, a)][k]] + [self.rotate(D[(i, a)][k], 512 * m) for m in range(1, 8)]
+                acc = None
+                for m in range(8):
+                    term = self.mult_plain(rot[(i, a, k)][m], enc_of_values(masks[(b - m) % 8]))
+                    acc = term if acc is None else self.add(acc, term)
+                four.append(acc)
+            out.append(four)
         return out
 
     def wrap_containers(self, cts, n):
