@@ -73,6 +73,8 @@ void flush_heavy(fhelin_ctx* c) {
                     h.done = h.failed = true;
                     h.in.reset();
                     h.in_heavy.reset();
+                    h.in2.reset();
+                    h.in2_heavy.reset();
                     continue;
                 }
                 if (h.in_heavy && h.in_heavy->done) {
@@ -80,7 +82,12 @@ void flush_heavy(fhelin_ctx* c) {
                     h.in = h.in_heavy->result;
                     h.in_heavy.reset();
                 }
-                if (h.in) ready.push_back(&h);
+                if (h.in2_heavy && h.in2_heavy->done) {
+                    if (h.in2_heavy->failed || !h.in2_heavy->result) throw Error(FHELIN_ERR_STATE, "a deferred operation's input failed earlier");
+                    h.in2 = h.in2_heavy->result;
+                    h.in2_heavy.reset();
+                }
+                if (h.in && (h.kind != LazyHeavy::Add || h.in2)) ready.push_back(&h);
                 else waiting = true;
             }
             if (ready.empty()) {
@@ -88,6 +95,26 @@ void flush_heavy(fhelin_ctx* c) {
                 break;
             }
             std::vector<char> taken(ready.size(), 0);
+            {   // every ready addition of the round in ONE batched call (Evaluator::add_batch aligns levels per group of rows)
+                CtVec as, bs;
+                std::vector<LazyHeavy*> adds;
+                for (size_t k = 0; k < ready.size(); ++k)
+                    if (ready[k]->kind == LazyHeavy::Add) {
+                        adds.push_back(ready[k]);
+                        as.push_back(ready[k]->in);
+                        bs.push_back(ready[k]->in2);
+                        taken[k] = 1;
+                    }
+                if (!adds.empty()) {
+                    CtVec out = adds.size() == 1 ? CtVec{c->ev.add(as[0], bs[0])} : c->ev.add_batch(as, bs);
+                    for (size_t k = 0; k < adds.size(); ++k) {
+                        adds[k]->result = out[k];
+                        adds[k]->done = true;
+                        adds[k]->in.reset();
+                        adds[k]->in2.reset();
+                    }
+                }
+            }
             for (size_t first = 0; first < ready.size(); ++first) {
                 if (taken[first]) continue;
                 LazyHeavy& f = *ready[first];
@@ -118,6 +145,8 @@ void flush_heavy(fhelin_ctx* c) {
                 sp->done = sp->failed = true;
                 sp->in.reset();
                 sp->in_heavy.reset();
+                sp->in2.reset();
+                sp->in2_heavy.reset();
             }
         throw;
     }
@@ -135,6 +164,21 @@ static fhelin_ct* defer_heavy(fhelin_ctx* c, const fhelin_ct* a, const std::shar
     h->owner = c;
     return h;
 }
+// a handle to the deferred sum a + b (either operand possibly deferred itself); capi_eval.cpp's fhelin_add
+fhelin_ct* defer_add(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b) {
+    auto op = std::make_shared<LazyHeavy>();
+    op->kind = LazyHeavy::Add;
+    if (!a->p && a->heavy && !a->heavy->done) op->in_heavy = a->heavy;
+    else op->in = ct_in(c, a);
+    if (!b->p && b->heavy && !b->heavy->done) op->in2_heavy = b->heavy;
+    else op->in2 = ct_in(c, b);
+    c->pending_heavy.push_back(op);
+    auto* h = new fhelin_ct;
+    h->heavy = op;
+    h->owner = c;
+    return h;
+}
+bool defer_allowed(fhelin_ctx* c) { return c->lazy_heavy && c->plan.mode != 1 && c->ctx.stream == c->ctx.main_stream; }
 static bool defer_ok(fhelin_ctx* c) { return c->lazy_heavy && c->plan.mode != 1 && c->ctx.stream == c->ctx.main_stream; }
 
 void force_many(fhelin_ctx* c, const fhelin_ct* const* v, int n) {

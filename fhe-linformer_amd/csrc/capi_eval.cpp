@@ -282,7 +282,22 @@ void fhelin_ct_free(fhelin_ct* ct) { delete ct; }
         *out = wrap(c, expr);                                                                  \
         FHELIN_CATCH                                                                        \
     }
-BINOP(fhelin_add, c->ev.add(ct_in(c, a), ct_in(c, b)))
+int fhelin_add(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b, fhelin_ct** out) {
+    NEED(c && a && b && out);
+    FHELIN_TRY
+    const fhelin_ct* both[2] = {a, b};
+    // deferred rows among the operands are evaluated now (their own batching rules apply); the SUM is deferred: additions issued
+    // in a loop over independent rows are aligned and added as one batch when a result is first read (capi_internal.h LazyHeavy)
+    for (const fhelin_ct* h : both)
+        if (!h->p && h->lazy) force(c, h);
+    if (defer_allowed(c)) {
+        *out = defer_add(c, a, b);
+        return FHELIN_OK;
+    }
+    force_many(c, both, 2);
+    *out = wrap(c, c->ev.add(ct_in(c, a), ct_in(c, b)));
+    FHELIN_CATCH
+}
 BINOP(fhelin_sub, c->ev.sub(ct_in(c, a), ct_in(c, b)))
 BINOP(fhelin_mult, c->ev.mult(ct_in(c, a), ct_in(c, b)))
 BINOP(fhelin_raw_mult_relin, (c->ev.relin_key ? c->ev.raw_mult_relin(ct_in(c, a), ct_in(c, b), *c->ev.relin_key)

@@ -68,12 +68,17 @@ std::vector<int>& plan_inputs();
 // result is read, everything pending is evaluated in dependency order with the operations of one kind, one parameter set and
 // one input shape BATCHED (Evaluator::eval_chebyshev_many, Bootstrapper::bootstrap_batch): every launch then carries all of
 // them and the switching keys / plaintext diagonals are read once.  Each result holds exactly the residues the single call gives.
+// EvalAdd(ct, ct) is deferred the same way: the drivers' residual additions are loops of 130 single calls (src/main.cpp:237-239,
+// output[i] = add(output[i], inputs[i])), each with a FLEXIBLEAUTO level adjustment of its own; read together they are ONE batched
+// adjustment (integer multiply + rescale over all rows) and one batched addition.
 // FHELIN_LAZY_HEAVY=0 (or a recording level-plan pass) evaluates at the call, on alternating worker lanes (run_heavy).
 namespace fhelin {
 struct LazyHeavy {
-    enum Kind { Cheb, Boot } kind = Boot;
+    enum Kind { Cheb, Boot, Add } kind = Boot;
     CtPtr in;                               // the input, once it exists ...
     std::shared_ptr<LazyHeavy> in_heavy;    // ... or the deferred operation that will produce it
+    CtPtr in2;                              // Add: the second operand, likewise
+    std::shared_ptr<LazyHeavy> in2_heavy;
     std::vector<double> coeffs;             // Cheb
     double a = 0, b = 0;
     int drop = 0;                           // Boot: limbs left out under a level plan
@@ -138,6 +143,8 @@ void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx);
 void force_group(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx);
 // evaluate every pending deferred heavy operation, batched (capi_composite.cpp)
 void flush_heavy(fhelin_ctx* c);
+fhelin_ct* defer_add(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b);
+bool defer_allowed(fhelin_ctx* c);
 inline void force(fhelin_ctx* c, const fhelin_ct* h) {
     if (!h->p && h->heavy) {
         if (!h->heavy->done) flush_heavy(c);

@@ -2,6 +2,7 @@
 #include <map>
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstring>
 
 namespace fhelin {
 
@@ -1044,7 +1045,46 @@ std::vector<CtPtr> Evaluator::sub_batch(const std::vector<CtPtr>& a, const std::
 std::vector<CtPtr> Evaluator::add_sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b, int op) {
     if (a.size() != b.size()) throw Error(FHELIN_ERR_ARG, "add_batch: operand count mismatch");
     std::vector<CtPtr> x(a.size()), y(a.size()), out(a.size());
+    // FLEXIBLEAUTO alignment.  The common case of a row loop - a degree-1 operand with more limbs meets a degree-1 operand with
+    // fewer (the driver's residual additions output[i] + inputs[i], src/main.cpp:237-239) - goes through ONE batched integer
+    // multiply + rescale per (target limbs, target scale) instead of one per pair (adjust_deg1_batch: the residues of adjust());
+    // everything else through match() as before
+    std::vector<char> aligned(a.size(), 0);
+    for (int side = 0; side < 2; ++side) {
+        // side 0: b is brought down to a; side 1: a is brought down to b
+        std::map<std::pair<int, long long>, std::vector<size_t>> groups;   // (target ell, bits of the target scale) -> pairs
+        for (size_t i = 0; i < a.size(); ++i) {
+            if (aligned[i]) continue;
+            const CtPtr& lo = side == 0 ? a[i] : b[i];
+            const CtPtr& hi = side == 0 ? b[i] : a[i];
+            if (a[i]->npoly != b[i]->npoly) throw Error(FHELIN_ERR_STATE, "add: component count mismatch");
+            if (lo->deg == 1 && hi->deg == 1 && lo->ell < hi->ell) {
+                long long bits;
+                const double sd = (double)lo->scale;
+                std::memcpy(&bits, &sd, sizeof bits);
+                groups[{lo->ell, bits}].push_back(i);
+            }
+        }
+        for (auto& g : groups) {
+            if (g.second.size() < 2) continue;
+            // the 80-bit scales of a group must agree exactly (they do for rows of one call); else leave the pairs to match()
+            const long double sc = (side == 0 ? a[g.second[0]] : b[g.second[0]])->scale;
+            bool same = true;
+            for (size_t i : g.second) same = same && (side == 0 ? a[i] : b[i])->scale == sc;
+            if (!same) continue;
+            std::vector<CtPtr> hi;
+            for (size_t i : g.second) hi.push_back(side == 0 ? b[i] : a[i]);
+            std::vector<CtPtr> adj = adjust_deg1_batch(hi, g.first.first, sc);
+            for (size_t k = 0; k < g.second.size(); ++k) {
+                const size_t i = g.second[k];
+                x[i] = side == 0 ? a[i] : adj[k];
+                y[i] = side == 0 ? adj[k] : b[i];
+                aligned[i] = 1;
+            }
+        }
+    }
     for (size_t i = 0; i < a.size(); ++i) {
+        if (aligned[i]) continue;
         if (a[i]->npoly != b[i]->npoly) throw Error(FHELIN_ERR_STATE, "add: component count mismatch");
         match(a[i], b[i], x[i], y[i]);
     }
