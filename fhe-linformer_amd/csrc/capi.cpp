@@ -104,9 +104,9 @@ int fhelin_prng_block(const uint8_t* seed32, uint64_t counter, uint64_t stream, 
 void fhelin_ctx_destroy(fhelin_ctx* c) {
     if (c && std::getenv("FHELIN_COPY_STATS")) {
         // diagnostics: ciphertext copies made to line operands up for a batched key switch, per call site of make_contiguous
-        // (0 rotate_sum_batch, 1 rotate_each_sum, 2 rotate_each_sum_rows, 3 rotate_each, 4 rotate_batch, 5 rescale_batch)
+        // (0 rotate_sum_batch, 1 rotate_each_sum, 2 rotate_each_sum_rows, 3 rotate_each, 4 rotate_batch, 5 rescale_batch, 6 hoisted batches, 7 modraise)
         std::fprintf(stderr, "fhelin gather copies:");
-        for (int i = 0; i < 6; ++i) std::fprintf(stderr, " %llu", (unsigned long long)c->ev.gather_copies[i]);
+        for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %llu", (unsigned long long)c->ev.gather_copies[i]);
         std::fprintf(stderr, "\n");
     }
     delete c;

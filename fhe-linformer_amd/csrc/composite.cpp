@@ -691,6 +691,9 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
     std::vector<int> ridx;
     for (int m = 0; m < 8; ++m) ridx.push_back(512 * m);
     const std::vector<CtVec> rot = ev_.rotate_many_batch(dsel, ridx);      // [input][m], m = 0: the input itself
+    // all outputs in ONE block in the order their consumer reads them ([token][k]: matmulCRlarge rescales and multiplies them in that
+    // order, so its batched rescale takes them as they stand - no gather copies)
+    CtVec all_out = rot.empty() ? CtVec() : ev_.new_ct_batch(count * 4, 2, rot[0][0]->ell, 2, 0, rot[0][0]->slots);
     std::map<std::pair<int, int>, CtPtr> made;                             // (token, k) -> output
     for (size_t x = 0; x < d_of.size(); ++x) {
         const int k = (int)(d_of[x] / groups.size());
@@ -703,7 +706,8 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
                 const int bb = ((bs[q] - m) % 8 + 8) % 8;
                 pts[q][m] = mod_range_mask(4096, 512 * bb, 512 * (bb + 1));
             }
-        CtVec dest = ev_.new_ct_batch((int)bs.size(), 2, rot[x][0]->ell, 2, 0, rot[x][0]->slots);
+        CtVec dest;
+        for (int b : bs) dest.push_back(all_out[(size_t)(i * 32 + 8 * a + b - first) * 4 + k]);
         if (!ev_.dot_plain_groups(rot[x], pts, 0, dest))
             for (size_t q = 0; q < bs.size(); ++q) dest[q] = ev_.dot_plain(rot[x], pts[q], 0, dest[q]);
         for (size_t q = 0; q < bs.size(); ++q) made[{i * 32 + 8 * a + bs[q], k}] = dest[q];

@@ -1292,7 +1292,7 @@ CtPtr Evaluator::mult_int(const CtPtr& a, u64 k, bool raise_deg, long double new
 // FLEXIBLEAUTO level adjustment of several degree-1 ciphertexts to ONE (limb count, scale): integer scalar x, the limbs above
 // ell + 1 left out, and ONE batched rescale for all of them.  Same residues as adjust() one by one.
 std::vector<CtPtr> Evaluator::adjust_deg1_batch(const std::vector<CtPtr>& v, int ell, long double scale) {
-    std::vector<CtPtr> out(v.size()), pending;
+    std::vector<CtPtr> out(v.size()), pending, src;
     std::vector<size_t> pos;
     for (size_t i = 0; i < v.size(); ++i) {
         CtPtr cur = v[i];
@@ -1302,10 +1302,37 @@ std::vector<CtPtr> Evaluator::adjust_deg1_batch(const std::vector<CtPtr>& v, int
             out[i] = cur;
             continue;
         }
-        const long double qdrop = (long double)c_.chain.q[ell];
-        const u64 k = (u64)llroundl(scale * qdrop / cur->scale);
-        pending.push_back(mult_int(cur, k, true, cur->scale * (long double)k, ell + 1));
+        src.push_back(cur);
         pos.push_back(i);
+    }
+    if (!src.empty()) {
+        // the integer products land in ONE block (ell + 1 limbs each: only what the rescale reads), so that the batched rescale takes
+        // them as they stand
+        bool same = true;
+        for (const CtPtr& c : src) same = same && c->npoly == src[0]->npoly;
+        std::vector<CtPtr> blk = same ? new_ct_batch((int)src.size(), src[0]->npoly, ell + 1, 2, 0, src[0]->slots) : std::vector<CtPtr>();
+        for (size_t j = 0; j < src.size(); ++j) {
+            const CtPtr& cur = src[j];
+            const long double qdrop = (long double)c_.chain.q[ell];
+            const u64 k = (u64)llroundl(scale * qdrop / cur->scale);
+            if (!same) {
+                pending.push_back(mult_int(cur, k, true, cur->scale * (long double)k, ell + 1));
+                continue;
+            }
+            ScalarSet sc;
+            for (int l = 0; l <= ell; ++l) {
+                const u64 q = c_.chain.q[l], r = k % q;
+                sc.v[2 * l] = r;
+                sc.v[2 * l + 1] = h_shoup(r, q);
+            }
+            CtPtr o = blk[j];
+            o->deg = cur->deg + 1;
+            o->scale = cur->scale * (long double)k;
+            o->slots = cur->slots;
+            launch_ew_scalar(c_.dt, o->d, cur->d, sc, cur->npoly * (ell + 1), 0, ell + 1, c_.stream, ell + 1 < cur->ell ? cur->ell : 0);
+            pending.push_back(o);
+        }
+        launch_ok("adjust_deg1_batch");
     }
     if (!pending.empty()) {
         std::vector<CtPtr> r = rescale_batch(pending);
