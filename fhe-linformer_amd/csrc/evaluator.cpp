@@ -453,7 +453,27 @@ std::vector<CtPtr> Evaluator::rotate_each_sum_rows(const std::vector<std::vector
         std::vector<CtPtr> flat;
         for (size_t b = lo; b < hi; ++b)
             for (int r : rot_pos) flat.push_back(rows[b][r]);
-        flat = make_contiguous(flat, 2);
+        // the rotated terms where they stand when every row holds them consecutively and the rows are equally spaced (the groups of
+        // a shift sum: seven rotated terms, then the next group's unrotated one): the transforms read them with a row stride;
+        // a gather copy otherwise
+        size_t row_stride = (size_t)R * ctw;
+        bool regular = B >= 1 && flat[0]->block != nullptr;
+        for (int b = 0; b < B && regular; ++b) {
+            for (int r = 0; r < R && regular; ++r) {
+                const CtPtr& c = flat[(size_t)b * R + r];
+                regular = c->block == flat[0]->block && c->words() == (size_t)ctw &&
+                          c->d == flat[(size_t)b * R]->d + (size_t)r * ctw;
+            }
+            if (regular && b == 1) {
+                regular = flat[R]->d > flat[0]->d;
+                if (regular) row_stride = (size_t)(flat[R]->d - flat[0]->d);
+            }
+            if (regular && b >= 1) regular = flat[(size_t)b * R]->d == flat[0]->d + (size_t)b * row_stride;
+        }
+        if (!regular) {
+            flat = make_contiguous(flat, 2);
+            row_stride = (size_t)R * ctw;
+        }
         const u64* base = flat[0]->d;
         KsShape up{ell, K, c_.alpha, lt.beta, L1, B * R, ctw, 0, 0, 0};
         u64* cc = c_.dalloc<u64>((size_t)B * R * ell * N);
@@ -461,6 +481,10 @@ std::vector<CtPtr> Evaluator::rotate_each_sum_rows(const std::vector<std::vector
             LimbBatch ib{cc, B * R * ell, nullptr, 0, ell, base + pn};
             ib.src_group = ell;
             ib.src_group_stride = ctw;
+            if (row_stride != (size_t)R * ctw) {
+                ib.src_group2 = R;
+                ib.src_group2_stride = row_stride;
+            }
             c_.ntt(ib, true);
         }
         u64* ext = c_.dalloc<u64>((size_t)B * R * lt.beta * nt * N);
@@ -469,7 +493,7 @@ std::vector<CtPtr> Evaluator::rotate_each_sum_rows(const std::vector<std::vector
         eb.tab_len = lt.beta * nt;
         eb.lazy_out = true;
         c_.ntt(eb, false, B * R * (lt.beta * nt - ell));
-        KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, (size_t)R * ctw, ctw, pn, 0};
+        KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, row_stride, ctw, pn, 0};
         sh.n_rot = R;
         sh.rot_ext_stride = (size_t)lt.beta * nt * N;
         sh.rot_input_stride = ctw;
@@ -480,7 +504,7 @@ std::vector<CtPtr> Evaluator::rotate_each_sum_rows(const std::vector<std::vector
             sh.evk_rot[r] = permuted(*rot_keys.at(g), sh.map_rot[r]);
         }
         sh.gsrc = base;
-        sh.gsrc_stride = (size_t)R * ctw;
+        sh.gsrc_stride = row_stride;
         c_.stats.keyswitch += (u64)B * R;
         c_.stats.keyswitch_limbs += (u64)B * R * ell;
         u64* accQ = c_.dalloc<u64>((size_t)B * 2 * ell * N);

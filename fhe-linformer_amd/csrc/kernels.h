@@ -23,6 +23,10 @@ struct LimbBatch {
     // strided out-of-place input: vector v is read from src + (v / src_group) * src_group_stride + (v % src_group) * N
     int src_group = 0;         // 0 = src is dense like data
     size_t src_group_stride = 0;
+    // second level: groups come in rows of src_group2 groups; row r starts at src + r * src_group2_stride and its groups follow
+    // src_group_stride apart (the rotated terms of a batch of rows that each skip their unrotated term)
+    int src_group2 = 0;
+    size_t src_group2_stride = 0;
     // forward only: limbs on the lazy butterfly path (q < 2^53) may leave the transform unreduced, in [0, 86q) < 2^60,
     // when the consumer takes any value below 2^60 (the evaluation-key inner product K7 splits its operands in 30-bit
     // halves and reduces the 128-bit sums once).  Saves the final reduction of the row pass.

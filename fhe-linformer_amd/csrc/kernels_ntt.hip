@@ -50,12 +50,19 @@ struct NttArgs {
     int lazy_out;             // forward: lazy-path limbs below 2^53 skip the final reduction (LimbBatch::lazy_out)
     int src_group;            // > 0: strided first-pass input (see LimbBatch)
     size_t src_group_stride;
+    int src_group2;
+    size_t src_group2_stride;
     const u64* lift_qlm;      // rescale: first-pass input = centred lift of src[vec / limb_count] (LimbBatch::lift_qlm)
     int lift_limb;
 };
 
 __device__ __forceinline__ size_t src_offset(const NttArgs& a, int vec, int log_n) {
-    if (a.src_group > 0) return (size_t)(vec / a.src_group) * a.src_group_stride + ((size_t)(vec % a.src_group) << log_n);
+    if (a.src_group > 0) {
+        const int g = vec / a.src_group;
+        const size_t in = (size_t)(vec % a.src_group) << log_n;
+        if (a.src_group2 > 0) return (size_t)(g / a.src_group2) * a.src_group2_stride + (size_t)(g % a.src_group2) * a.src_group_stride + in;
+        return (size_t)g * a.src_group_stride + in;
+    }
     return (size_t)vec << log_n;
 }
 
@@ -472,6 +479,8 @@ static void launch_ntt_impl(const DeviceTables& t, const LimbBatch& b, bool inve
     a.src = b.src ? b.src : b.data;
     a.src_group = b.src ? b.src_group : 0;
     a.src_group_stride = b.src_group_stride;
+    a.src_group2 = (b.src && b.src_group > 0) ? b.src_group2 : 0;
+    a.src_group2_stride = b.src_group2_stride;
     a.lazy_out = (!inverse && b.lazy_out) ? 1 : 0;
     a.lift_qlm = (!inverse && b.src && b.lift_limb >= 0) ? b.lift_qlm : nullptr;
     a.lift_limb = b.lift_limb;
@@ -505,6 +514,7 @@ static void launch_ntt_impl(const DeviceTables& t, const LimbBatch& b, bool inve
         cols();
         a.src = a.data;
         a.src_group = 0;
+        a.src_group2 = 0;
         if (md)
             hipLaunchKernelGGL((ntt_rows_kernel<false, true>), dim3(blocks), dim3(256), 0, s, a, *md);
         else
@@ -513,6 +523,7 @@ static void launch_ntt_impl(const DeviceTables& t, const LimbBatch& b, bool inve
         hipLaunchKernelGGL((ntt_rows_kernel<true, false>), dim3(blocks), dim3(256), 0, s, a, NttModDown());
         a.src = a.data;
         a.src_group = 0;
+        a.src_group2 = 0;
         cols();
     }
 }
