@@ -24,9 +24,10 @@ def test_reference_driver_compiles_against_shim(driver):
 def test_shim_driver_builds():
     out = os.path.join(ROOT, "tests", "shim", "shim_driver")
     r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "shim", "shim_driver.cpp"),
-                        "-L", os.path.join(ROOT, "fhe-linformer_amd"), "-lfhelin_amd", "-Wl,-rpath," + os.path.join(ROOT, "fhe-linformer_amd"),
-                        "-o", out], capture_output=True, text=True, timeout=300)
+                        "-L", os.path.join(ROOT, "fhe-linformer_amd"), "-lfhelin_amd", "-Wl,-rpath,$ORIGIN/../../fhe-linformer_amd",
+                        "-o", out + ".tmp"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
+    os.replace(out + ".tmp", out)      # atomically: a snapshot of the tree taken meanwhile never sees a half-written binary
     assert os.path.exists(out)
 
 
@@ -49,6 +50,7 @@ def test_reference_driver_links_and_starts(driver):
 def test_shim_forward_builds():
     out = os.path.join(ROOT, "tests", "shim", "shim_forward")
     r = subprocess.run(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "shim", "shim_forward.cpp"),
-                        "-L", os.path.join(ROOT, "fhe-linformer_amd"), "-lfhelin_amd", "-Wl,-rpath," + os.path.join(ROOT, "fhe-linformer_amd"),
-                        "-o", out], capture_output=True, text=True, timeout=300)
+                        "-L", os.path.join(ROOT, "fhe-linformer_amd"), "-lfhelin_amd", "-Wl,-rpath,$ORIGIN/../../fhe-linformer_amd",
+                        "-o", out + ".tmp"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
+    os.replace(out + ".tmp", out)      # atomically: a snapshot of the tree taken meanwhile never sees a half-written binary
