@@ -135,6 +135,7 @@ def load_library():
         "fhelin_rotate_many": (i32, [vp, vp, C.POINTER(i32), i32, C.POINTER(vp)]),
         "fhelin_rotate_each": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(vp)]),
         "fhelin_rotate_sum": (i32, [vp, C.POINTER(vp), i32, C.POINTER(i32), i32, C.POINTER(vp)]),
+        "fhelin_hoisted_dot": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(vp)]),
         "fhelin_rescale": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_rotate_batch": (i32, [vp, C.POINTER(vp), i32, i32, C.POINTER(vp)]),
         "fhelin_rescale_batch": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp)]),
@@ -498,6 +499,16 @@ class Engine:
         self._ck(self.lib.fhelin_rotate_sum(self.h, self._harr(v), len(v), idx, len(indices), outs))
         return self._cts(outs, len(v))
 
+    def hoisted_dot(self, v, pts, indices):
+        """v[i] * pts[0] + sum_r rot(v[i], indices[r]) * pts[r + 1]: one ModUp and one ModDown per row, plaintext products in the
+        extended basis (plaintext-folded rotation keys)"""
+        assert len(pts) == len(indices) + 1
+        idx = (C.c_int32 * len(indices))(*indices)
+        parr = (C.c_void_p * len(pts))(*[p.h for p in pts])
+        outs = self._outs(len(v))
+        self._ck(self.lib.fhelin_hoisted_dot(self.h, self._harr(v), len(v), parr, idx, len(indices), outs))
+        return self._cts(outs, len(v))
+
     def rotate_each_sum(self, v, indices):
         """sum_i rot(v[i], indices[i]): own ModUp per term, one shared ModDown per <= 7 terms"""
         idx = (C.c_int32 * len(indices))(*indices)
@@ -514,7 +525,7 @@ class Engine:
     def pt_export(self, pt, ell, scale=0.0):
         """[ell][N] residues of the plaintext's encoding at (ell limbs, scale); scale 0 = Delta of that level.  `scale`
         may be a numpy longdouble: it travels exactly as hi + lo doubles."""
-        out = np.empty((ell, self.N), dtype=np.uint64)
+        out = np.empty((ell, self.N), dtype=np.uint64)     # ell = n_q + n_p (explicit scale): the encoding over the full key basis
         hi = float(scale)
         lo = float(np.longdouble(scale) - np.longdouble(hi))
         self._ck(self.lib.fhelin_pt_export(self.h, pt.h, ell, hi, lo, out.ctypes.data_as(C.c_void_p), out.size))

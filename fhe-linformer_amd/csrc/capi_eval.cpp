@@ -93,8 +93,10 @@ int fhelin_pt_export(fhelin_ctx* c, const fhelin_pt* p, int32_t ell, double scal
     FHELIN_TRY
     Context& x = c->ctx;
     x.require_device();
-    if (ell < 1 || ell > x.L + 1) throw Error(FHELIN_ERR_ARG, "pt_export: bad limb count");
+    const bool full = ell == x.L + 1 + x.K;      // the encoding over the full key basis (Q limbs, then the special limbs)
+    if (ell < 1 || (ell > x.L + 1 && !full)) throw Error(FHELIN_ERR_ARG, "pt_export: bad limb count");
     if (cap < (size_t)ell * x.N) throw Error(FHELIN_ERR_ARG, "buffer too small");
+    if (full && !(scale_hi > 0)) throw Error(FHELIN_ERR_ARG, "pt_export: the full-basis encoding needs an explicit scale");
     auto enc = p->p->at(ell, scale_hi > 0 ? (long double)scale_hi + (long double)scale_lo : x.sf_real[x.L + 1 - ell]);
     hip_check(hipMemcpyAsync(out, enc->d, (size_t)ell * x.N * 8, hipMemcpyDeviceToHost, x.stream), "pt export");
     x.sync();
@@ -343,6 +345,24 @@ int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* 
     force_many(c, v, n);
     for (int i = 0; i < n; ++i) in.push_back(ct_in(c, v[i]));
     std::vector<CtPtr> r = c->ev.rotate_each(in, std::vector<int>(indices, indices + n));
+    for (int i = 0; i < n; ++i) outs[i] = wrap(c, r[i]);
+    FHELIN_CATCH
+}
+int fhelin_hoisted_dot(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const fhelin_pt* const* pts, const int32_t* indices, int32_t n_rot,
+                       fhelin_ct** outs) {
+    NEED(c && v && pts && indices && outs && n >= 0 && n_rot >= 1);
+    FHELIN_TRY
+    std::vector<CtPtr> in;
+    std::vector<PtPtr> p;
+    for (int i = 0; i < n; ++i)
+        if (!v[i]) throw Error(FHELIN_ERR_ARG, "null ciphertext in array");
+    for (int i = 0; i <= n_rot; ++i) {
+        if (!pts[i]) throw Error(FHELIN_ERR_ARG, "null plaintext in array");
+        p.push_back(pts[i]->p);
+    }
+    force_many(c, v, n);
+    for (int i = 0; i < n; ++i) in.push_back(ct_in(c, v[i]));
+    std::vector<CtPtr> r = c->ev.hoisted_dot_rows(in, p, std::vector<int>(indices, indices + n_rot));
     for (int i = 0; i < n; ++i) outs[i] = wrap(c, r[i]);
     FHELIN_CATCH
 }

@@ -218,7 +218,9 @@ static const Context::FftDev& fft_dev_tables(Context& c, int slots) {
 void encode_batch_device(Context& c, u64* dst, const double* re, const double* im, int n_vec, int n_per, int slots, int ell, long double scale) {
     c.require_device();
     if (slots < 2 || (slots & (slots - 1)) || slots > c.N / 2) throw Error(FHELIN_ERR_ARG, "encode: slots must be a power of two in [2, N/2]");
-    if (ell < 1 || ell > c.L + 1) throw Error(FHELIN_ERR_ARG, "encode: level out of range");
+    // ell = L + 1 + k: the encoding over the FULL key basis (limb ids 0..L+k: Q limbs, then the special limbs), for plaintexts
+    // folded into rotation keys (Evaluator::folded_key); the leveled operations only ever ask for ell <= L + 1
+    if (ell < 1 || ell > c.L + 1 + c.K) throw Error(FHELIN_ERR_ARG, "encode: level out of range");
     if (n_vec < 1) return;
     const size_t words = (size_t)2 * slots;                 // one complex vector, in doubles
     double* dv = reinterpret_cast<double*>(c.dalloc<u64>(words * n_vec));
@@ -253,7 +255,7 @@ std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>
                                            int ell, long double scale) {
     c.require_device();
     if (slots < 1 || (slots & (slots - 1)) || slots > c.N / 2) throw Error(FHELIN_ERR_ARG, "encode: slots must be a power of two <= N/2");
-    if (ell < 1 || ell > c.L + 1) throw Error(FHELIN_ERR_ARG, "encode: level out of range");
+    if (ell < 1 || ell > c.L + 1 + c.K) throw Error(FHELIN_ERR_ARG, "encode: level out of range");   // L + 1 + k: full key basis (see above)
     if (!c.host_encode && slots >= 2) {
         auto e = std::make_shared<Encoding>();
         e->ctx = &c;

@@ -17,6 +17,7 @@ Composite::Composite(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {
     if (const char* e = std::getenv("FHELIN_ROW_LANES")) row_lanes_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_CHEB_ROUNDS")) ev_.cheb_rounds = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_DOT_GROUPS")) ev_.dot_groups = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FHELIN_DOUBLE_HOIST")) ev_.double_hoist = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_CHEB_LEAF_AT")) ev_.cheb_leaf_at_product = std::atoi(e) != 0;
     if (const char* b = std::getenv("FHELIN_BATCH")) {
         int v = std::atoi(b);
@@ -275,10 +276,12 @@ CtVec Composite::matmul_ct(const CtVec& rows, const CtPtr& w, int slots, int pad
     return rotsum_batch(prod, slots, padding);
 }
 
-// W''_t (t = 0..3): block b (128 slots) of W''_t is block b of W_j with j = (b - t) mod 4 — see matmulRElarge
-std::vector<PtPtr> Composite::relarge_weights(const std::vector<PtPtr>& weights) {
+// W''_t (t = 0..3): block b (128 slots) of W''_t is block b of W_j with j = (b - t) mod 4 — see matmulRElarge.
+// rotated: V_t = rot(W''_t, 128 t) instead (slot s of V_t = slot s + 128 t of W''_t): rot(x * W''_t, 128 t) = rot(x, 128 t) * V_t
+std::vector<PtPtr> Composite::relarge_weights(const std::vector<PtPtr>& weights, bool rotated) {
     char key[160];
-    snprintf(key, sizeof key, "%p:%p:%p:%p", (void*)weights[0].get(), (void*)weights[1].get(), (void*)weights[2].get(), (void*)weights[3].get());
+    snprintf(key, sizeof key, "%p:%p:%p:%p:%d", (void*)weights[0].get(), (void*)weights[1].get(), (void*)weights[2].get(), (void*)weights[3].get(),
+             rotated ? 1 : 0);
     auto it = relarge_cache_.find(key);
     if (it != relarge_cache_.end()) return it->second;
     const int ns = num_slots();
@@ -286,9 +289,10 @@ std::vector<PtPtr> Composite::relarge_weights(const std::vector<PtPtr>& weights)
     for (int t = 0; t < 4; ++t) {
         std::vector<double> v(ns, 0.0);
         for (int s = 0; s < ns; ++s) {
-            const int b = s / 128, j = ((b - t) % 4 + 4) % 4;
+            const int src_slot = rotated ? (s + 128 * t) % ns : s;
+            const int b = src_slot / 128, j = ((b - t) % 4 + 4) % 4;
             const auto& src = weights[j]->values;
-            v[s] = s < (int)src.size() ? src[s] : 0.0;
+            v[s] = src_slot < (int)src.size() ? src[src_slot] : 0.0;
         }
         out.push_back(encode_vec(v, weights[0]->level));
     }
@@ -311,7 +315,6 @@ CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& we
     const bool shared = merge_rot_ && weights.size() == 4 && ns == 16384 && !inputs.empty() &&
                         ev_.have_rotation_keys({128, 256, 384, 512, 1024, 2048, 4096, 8192}, inputs[0]->slots);
     if (shared) {
-        const std::vector<PtPtr> w2 = relarge_weights(weights);
         // rescale degree-2 inputs once (each product below would otherwise do it again)
         CtVec x = inputs;
         {
@@ -327,26 +330,35 @@ CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& we
                 for (size_t k = 0; k < pos.size(); ++k) x[pos[k]] = r[k];
             }
         }
-        std::vector<CtVec> y(4);
-        // the four products stay unrescaled through the key switch that sums them: ONE rescale of U (inside rotsum_batch) instead
-        // of four, at the price of running that one key switch a limb higher
-        // the three products of a row that get rotated are produced next to one another (one block, [row][t]): the key switch
-        // takes them where they are
-        CtVec xflat;
-        std::vector<PtPtr> wflat;
-        for (size_t i = 0; i < x.size(); ++i)
-            for (int t = 1; t < 4; ++t) {
-                xflat.push_back(x[i]);
-                wflat.push_back(w2[t]);
+        CtVec u;
+        if (ev_.double_hoist) {
+            // U = x * V_0 + sum_{t=1..3} rot(x, 128 t) * V_t with V_t = rot(W''_t, 128 t): the three rotations share ONE ModUp of the row
+            // and the plaintext products are taken in the extended basis (rotation keys with V_t folded in: Evaluator::hoisted_dot_rows),
+            // so a row costs one ModUp and one ModDown where the products-then-rotations form costs three ModUps and one ModDown
+            u = ev_.hoisted_dot_rows(x, relarge_weights(weights, true), {128, 256, 384});
+        } else {
+            const std::vector<PtPtr> w2 = relarge_weights(weights, false);
+            std::vector<CtVec> y(4);
+            // the four products stay unrescaled through the key switch that sums them: ONE rescale of U (inside rotsum_batch) instead
+            // of four, at the price of running that one key switch a limb higher
+            // the three products of a row that get rotated are produced next to one another (one block, [row][t]): the key switch
+            // takes them where they are
+            CtVec xflat;
+            std::vector<PtPtr> wflat;
+            for (size_t i = 0; i < x.size(); ++i)
+                for (int t = 1; t < 4; ++t) {
+                    xflat.push_back(x[i]);
+                    wflat.push_back(w2[t]);
+                }
+            const CtVec rotated = ev_.mult_plain_each(xflat, wflat);
+            y[0] = ev_.mult_plain_batch(x, w2[0]);
+            std::vector<CtVec> rows(x.size(), CtVec(4));
+            for (size_t i = 0; i < x.size(); ++i) {
+                rows[i][0] = y[0][i];
+                for (int t = 1; t < 4; ++t) rows[i][t] = rotated[3 * i + (t - 1)];
             }
-        const CtVec rotated = ev_.mult_plain_each(xflat, wflat);
-        y[0] = ev_.mult_plain_batch(x, w2[0]);
-        std::vector<CtVec> rows(x.size(), CtVec(4));
-        for (size_t i = 0; i < x.size(); ++i) {
-            rows[i][0] = y[0][i];
-            for (int t = 1; t < 4; ++t) rows[i][t] = rotated[3 * i + (t - 1)];
+            u = ev_.rotate_each_sum_rows(rows, {0, 128, 256, 384});
         }
-        CtVec u = ev_.rotate_each_sum_rows(rows, {0, 128, 256, 384});
         CtVec z = rotsum_batch(u, 32, 512);
         CtVec res = ev_.mult_plain_batch(z, block_mask(0, 512, mask_val));
         if (bias) res = ev_.add_plain_batch(res, bias);

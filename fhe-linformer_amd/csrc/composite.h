@@ -78,7 +78,7 @@ private:
     std::map<std::string, PtPtr> mask_cache_;
     // matmulRElarge: the four 128x128 weight blocks re-arranged block-wise (W''_t, t = 0..3), cached per weight set
     std::map<std::string, std::vector<PtPtr>> relarge_cache_;
-    std::vector<PtPtr> relarge_weights(const std::vector<PtPtr>& weights);
+    std::vector<PtPtr> relarge_weights(const std::vector<PtPtr>& weights, bool rotated);
     bool early_rescale_ = true;   // FHELIN_EARLY_RESCALE: rescale a fresh product before its rotation tree
     bool merge_rot_ = true;       // FHELIN_MERGE_ROT: two tree steps as one merged key switch when the 3s key exists
     bool row_lanes_ = false;      // FHELIN_ROW_LANES: row chunks of a tree on separate streams (off: measured slower)

@@ -324,6 +324,150 @@ std::vector<CtPtr> Evaluator::rotate_sum_batch(const std::vector<CtPtr>& vin, co
     return out;
 }
 
+const Evaluator::FoldedKey& Evaluator::folded_key(const PtPtr& p, int index, long double scale) {
+    const u64 g = c_.galois_element(index);
+    auto kit = rot_keys.find(g);
+    if (kit == rot_keys.end()) throw Error(FHELIN_ERR_KEY, "no rotation key for index " + std::to_string(index) + " (EvalRotateKeyGen list)");
+    for (const FoldedKey& f : folded_keys)
+        if (f.pt.get() == p.get() && f.key.get() == kit->second.get() && f.index == index && fabsl(f.scale / scale - 1.0L) < 1e-12L) return f;
+    FoldedKey f;
+    f.pt = p;
+    f.key = kit->second;
+    f.index = index;
+    f.scale = scale;
+    const int nl = c_.L + 1 + c_.K;
+    f.enc = p->at(nl, scale);
+    f.d = std::make_shared<DevBlock>();
+    f.d->ctx = &c_;
+    f.d->d = c_.dalloc<u64>(f.key->words());
+    launch_fold_key(c_.dt, f.d->d, f.key->d, c_.automorph_map(g), f.enc->d, f.key->digits * 2 * nl, c_.stream);
+    launch_ok("fold_key");
+    // built once, read from every stream afterwards: finish it before anyone else can see the pointer
+    hip_check(hipStreamSynchronize(c_.stream), "fold_key sync");
+    if (folded_keys.size() >= MAX_FOLDED) {
+        // the evicted copy may still be read by work in flight on any stream
+        hip_check(hipStreamSynchronize(c_.main_stream), "folded key eviction sync");
+        for (int k = 1; k <= c_.n_lanes; ++k) hip_check(hipStreamSynchronize(c_.lane_stream[k]), "folded key eviction sync (lane)");
+        folded_keys.erase(folded_keys.begin());
+    }
+    folded_keys.push_back(f);
+    return folded_keys.back();
+}
+
+std::vector<CtPtr> Evaluator::hoisted_dot_rows(const std::vector<CtPtr>& xin, const std::vector<PtPtr>& pts, const std::vector<int>& indices) {
+    if (xin.empty()) return {};
+    const int R = (int)indices.size();
+    if (R < 1 || R > KsShape::MAX_ROT || (int)pts.size() != R + 1)
+        throw Error(FHELIN_ERR_ARG, "hoisted_dot_rows: 1..7 rotations, one plaintext per rotation + the unrotated term's");
+    if (!have_rotation_keys(indices, xin[0]->slots)) throw Error(FHELIN_ERR_KEY, "hoisted_dot_rows: missing rotation key");
+    if (c_.K < 1) throw Error(FHELIN_ERR_STATE, "hybrid key switching needs at least one special prime");
+    const int ns = xin[0]->slots > 0 ? xin[0]->slots : (1 << c_.prm.log_slots);
+    for (int r : indices)
+        if (r % ns == 0) throw Error(FHELIN_ERR_ARG, "hoisted_dot_rows: a rotation by 0 is the unrotated term (pts[0])");
+    std::vector<CtPtr> x = xin;
+    {   // degree-2 operands are rescaled first (as before any product with a plaintext)
+        std::vector<CtPtr> need;
+        std::vector<size_t> pos;
+        for (size_t i = 0; i < x.size(); ++i)
+            if (x[i]->deg >= 2) {
+                need.push_back(x[i]);
+                pos.push_back(i);
+            }
+        if (!need.empty()) {
+            std::vector<CtPtr> r = rescale_batch(need);
+            for (size_t k = 0; k < pos.size(); ++k) x[pos[k]] = r[k];
+        }
+    }
+    std::vector<const u32*> maps;
+    for (int r : indices) maps.push_back(c_.automorph_map(c_.galois_element(r)));
+    const size_t N = c_.N;
+    const int K = c_.K, L1 = c_.L + 1;
+    hipStream_t s = c_.stream;
+    std::vector<CtPtr> out(x.size());
+    std::vector<char> done(x.size(), 0);
+    for (size_t first = 0; first < x.size(); ++first) {
+        if (done[first]) continue;
+        if (x[first]->npoly != 2) throw Error(FHELIN_ERR_STATE, "hoisted_dot_rows: ciphertext must have 2 components");
+        std::vector<size_t> idx;
+        for (size_t i = first; i < x.size() && (int)idx.size() < batch_limit; ++i) {
+            const CtPtr &a = x[first], &b = x[i];
+            if (!done[i] && b->npoly == 2 && b->ell == a->ell && b->deg == a->deg && fabsl(b->scale / a->scale - 1.0L) < 1e-9L) idx.push_back(i);
+        }
+        std::vector<CtPtr> chunk;
+        for (size_t i : idx) chunk.push_back(x[i]);
+        chunk = make_contiguous(chunk, 0);
+        const int B = (int)chunk.size(), ell = chunk[0]->ell;
+        const size_t pn = (size_t)ell * N, ctw = 2 * pn;
+        const LevelTables& lt = c_.lvl[ell];
+        const int nt = ell + K;
+        const long double sf = c_.sf_real[chunk[0]->level()];
+        std::vector<CtPtr> o = new_ct_batch(B, 2, ell, chunk[0]->deg + 1, chunk[0]->scale * sf, chunk[0]->slots);
+        const u64* base = chunk[0]->d;
+        KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, ctw, ctw, pn, ctw};
+        sh.n_rot = R;
+        sh.lds_digits = c_.lds_digits ? 1 : 0;
+        HoistAdd h;
+        h.n_rot = R;
+        std::vector<FoldedKey> hold;            // the folded keys and encodings of this launch set stay alive across a cache eviction
+        const std::shared_ptr<Encoding> e0 = pts[0]->at(ell, sf);
+        h.v[0] = e0->d;
+        for (int r = 0; r < R; ++r) {
+            hold.push_back(folded_key(pts[r + 1], indices[r], sf));
+            sh.evk_rot[r] = hold.back().d->d;
+            sh.map_rot[r] = maps[r];
+            h.v[r + 1] = hold.back().enc->d;
+            h.map[r] = maps[r];
+            if (c_.galois_element(indices[r]) % (u64)(c_.N / 256) != 1) sh.lds_digits = 0;
+        }
+        c_.stats.keyswitch += (u64)B * R;
+        c_.stats.keyswitch_limbs += (u64)B * R * ell;
+        c_.stats.ct_pt_mult += (u64)B * (R + 1);
+        c_.stats.ct_pt_limbs += (u64)B * (R + 1) * ell;
+        // ModUp of c1, once for all rotations
+        u64* cc = c_.dalloc<u64>((size_t)B * ell * N);
+        {
+            LimbBatch ib{cc, B * ell, nullptr, 0, ell, base + pn};
+            if (B > 1) {
+                ib.src_group = ell;
+                ib.src_group_stride = ctw;
+            }
+            c_.ntt(ib, true);
+        }
+        u64* ext = c_.dalloc<u64>((size_t)B * lt.beta * nt * N);
+        launch_modup_conv(c_.dt, sh, ext, cc, base + pn, lt.up_hatinv, lt.up_hatmod, s);
+        LimbBatch eb{ext, B * lt.beta * nt, lt.ext_limb_tab, 0, 1};
+        eb.tab_len = lt.beta * nt;
+        eb.lazy_out = true;
+        c_.ntt(eb, false, B * (lt.beta * nt - ell));
+        // sum_r V_r . sigma_r(d * evk_r) in the extended basis: the merged inner product with the folded keys
+        u64* accQ = c_.dalloc<u64>((size_t)B * 2 * ell * N);
+        u64* accP = c_.dalloc<u64>((size_t)B * 2 * K * N);
+        launch_ks_inner_multi(c_.dt, sh, accQ, accP, ext, base + pn, s);
+        // what does not pass through the key switch: V_0 (c0, c1) + sum_r V_r sigma_r(c0)
+        u64* pre = c_.dalloc<u64>((size_t)B * ctw);
+        launch_hoist_addends(c_.dt, sh, h, pre, base, s);
+        // one ModDown
+        c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
+        u64* conv = c_.dalloc<u64>((size_t)B * 2 * ell * N);
+        launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
+        c_.ntt(LimbBatch{conv, B * 2 * ell, nullptr, 0, ell}, false);
+        launch_moddown_finish(c_.dt, sh, o[0]->d, accQ, conv, c_.d_pinv, nullptr, nullptr, nullptr, pre, s);
+        launch_ok("hoisted_dot_rows");
+        c_.pool.free(cc);
+        c_.pool.free(ext);
+        c_.pool.free(accQ);
+        c_.pool.free(accP);
+        c_.pool.free(pre);
+        c_.pool.free(conv);
+        for (int b = 0; b < B; ++b) {
+            o[b]->scale = x[idx[b]]->scale * sf;
+            out[idx[b]] = o[b];
+            done[idx[b]] = 1;
+        }
+    }
+    return out;
+}
+
 CtPtr Evaluator::rotate_each_sum(const std::vector<CtPtr>& vin, const std::vector<int>& indices) {
     if (vin.empty() || vin.size() != indices.size()) throw Error(FHELIN_ERR_ARG, "rotate_each_sum: one index per ciphertext");
     const int ns = vin[0]->slots > 0 ? vin[0]->slots : (1 << c_.prm.log_slots);

@@ -127,6 +127,24 @@ public:
     // switches of a chunk of rows batched (one ModUp over rows x terms, one inner-product launch, one ModDown over rows).
     // Same residues as rotate_each_sum row by row (<= 7 rotated terms per row).
     std::vector<CtPtr> rotate_each_sum_rows(const std::vector<std::vector<CtPtr>>& rows, const std::vector<int>& indices);
+    // double hoisting: out[b] = xs[b] * pts[0] + sum_r rot(xs[b], indices[r]) * pts[r + 1]  (== sum_r rot(xs[b] * rot(pts[r + 1], -indices[r]),
+    // indices[r]) in slot values) with ONE ModUp and ONE ModDown per row: the rotations share the row's digits and the plaintext
+    // products are taken in the extended basis, through rotation keys with the plaintext folded in (folded_key; kernels_elem.h
+    // launch_fold_key).  Meant for FEW plaintexts shared by MANY rows (the re-arranged weights of matmulRElarge): a folded key is a
+    // full key copy.  Output: noise degree + 1, scale x the level's plaintext scale; 1 <= R <= 7 rotations.
+    std::vector<CtPtr> hoisted_dot_rows(const std::vector<CtPtr>& xs, const std::vector<PtPtr>& pts, const std::vector<int>& indices);
+    bool double_hoist = true;   // Composite::matmulRElarge takes its first step through hoisted_dot_rows; FHELIN_DOUBLE_HOIST=0: rotate_each_sum_rows
+    struct FoldedKey {
+        PtPtr pt;
+        KeyPtr key;
+        int index = 0;
+        long double scale = 0;
+        std::shared_ptr<Encoding> enc;   // the plaintext over the full key basis [L+1+k][N]
+        std::shared_ptr<DevBlock> d;     // [digits][2][L+1+k][N], layout of EvalKey::d_perm
+    };
+    std::vector<FoldedKey> folded_keys;  // bounded (MAX_FOLDED), oldest first
+    static constexpr size_t MAX_FOLDED = 12;
+    const FoldedKey& folded_key(const PtPtr& p, int index, long double scale);
     // hoisted rotations: rot(a, i) for every i in `indices` with ONE ModUp of a (results identical to rotate(a, i))
     std::vector<CtPtr> rotate_many(const CtPtr& a, const std::vector<int>& indices);
     // the same for several ciphertexts of one shape and ONE index list (the baby steps of a batch of bootstraps): one ModUp over

@@ -122,6 +122,21 @@ void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* a
 // accumulated in 128 bits and reduced once; ONE ModDown then serves the whole sum.
 void launch_ks_inner_multi(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* c_ntt,
                            hipStream_t s);
+// ---- double hoisting with plaintext-folded keys: sum_r rot(x, i_r) * V_r with ONE ModUp and ONE ModDown, the plaintext products taken
+// in the extended basis.  sigma_r(d * evk_r) * V_r = sigma_r(d) * (sigma_r(evk_r) * V_r): with the folded key
+//     fold_r[v][n] = pack30( V_r[limb(v)][n] * key_r[v][map_r[n]] mod m_limb(v) ),   limb(v) = v % (L1 + k),
+// (V_r encoded over the FULL key basis q_0..q_L, p_0..p_{k-1}: [L1 + k][N], NTT form) launch_ks_inner_multi computes the whole sum
+// as it stands (evk_rot[r] = fold_r).  The folded key is a canonical key in the layout of EvalKey::d_perm.
+void launch_fold_key(const DeviceTables& t, u64* out, const u64* key, const u32* map, const u64* V, int nvec, hipStream_t s);
+// what does not pass through the key switch: pre[b][0][t][n] = V_0[t][n] c0_b[t][n] + sum_r V_{r+1}[t][n] c0_b[t][map_r[n]],
+// pre[b][1][t][n] = V_0[t][n] c1_b[t][n]   (ct: batch row b at ct + b * sh.c_stride, [2][ell][N]; pre dense [batch][2][ell][N];
+// v[i]: [>= ell][N]).  128-bit sums, one reduction.
+struct HoistAdd {
+    int n_rot = 0;
+    const u64* v[KsShape::MAX_ROT + 1] = {};
+    const u32* map[KsShape::MAX_ROT] = {};
+};
+void launch_hoist_addends(const DeviceTables& t, const KsShape& sh, const HoistAdd& h, u64* pre, const u64* ct, hipStream_t s);
 // out[v][n] = sum_r in[v][map_rot[r][n]]  for v in [0, nvec) (the c0 parts of the rotated copies), per batch row
 // (FHELIN_FUSE_GATHER=0 only: by default the sum rides in launch_moddown_finish, KsShape::gsrc)
 void launch_gather_sum(const DeviceTables& t, const KsShape& sh, u64* out, const u64* in, size_t in_stride, hipStream_t s);

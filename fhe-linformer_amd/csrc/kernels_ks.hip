@@ -428,7 +428,57 @@ __global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsS
     reinterpret_cast<u64x2*>(out)[((size_t)v * N + j) >> 1] = r;
 }
 
+// Plaintext-folded rotation key (launch_fold_key): grid (N/512, digits * 2 * (L1 + k)); vector v belongs to limb v % (L1 + k)
+__global__ __launch_bounds__(256) void fold_key_kernel(DeviceTables t, u64* __restrict__ out, const u64* __restrict__ key, const u32* __restrict__ map,
+                                                       const u64* __restrict__ V) {
+    const size_t v = blockIdx.y;
+    const int limb = (int)(v % (size_t)t.n_limbs);
+    const Barrett br = load_barrett(t, limb);
+    const size_t N = (size_t)1 << t.log_n;
+    const size_t j = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const u32 m0 = map[j], m1 = map[j + 1];
+    const u64x2 pv = reinterpret_cast<const u64x2*>(V)[((size_t)limb * N + j) >> 1];
+    u64x2 r;
+    r.x = pack30(mul_mod(pv.x, key[v * N + m0], br));
+    r.y = pack30(mul_mod(pv.y, key[v * N + m1], br));
+    reinterpret_cast<u64x2*>(out)[(v * N + j) >> 1] = r;
+}
+
+// Addends of a hoisted plaintext-rotation sum (launch_hoist_addends): grid (N/512, batch * 2 * ell)
+__global__ __launch_bounds__(256) void hoist_addends_kernel(DeviceTables t, KsShape sh, HoistAdd h, u64* __restrict__ pre, const u64* __restrict__ ct) {
+    const int bi = blockIdx.y / (2 * sh.ell), v = blockIdx.y % (2 * sh.ell);
+    const int c = v / sh.ell, tt = v % sh.ell;
+    const Barrett br = load_barrett(t, tt);
+    const size_t N = (size_t)1 << t.log_n, row = N >> 1;
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u64x2* __restrict__ src = reinterpret_cast<const u64x2*>(ct + (size_t)bi * sh.c_stride + (size_t)v * N);
+    const u64x2 x = src[n2];
+    const u64x2 p0 = reinterpret_cast<const u64x2*>(h.v[0])[(size_t)tt * row + n2];
+    Acc128 a0 = {0, 0}, a1 = {0, 0};     // <= 8 products of canonical residues below 2^60: far below q * 2^64
+    acc_mac(a0, x.x, p0.x);
+    acc_mac(a1, x.y, p0.y);
+    if (c == 0)
+        for (int r = 0; r < h.n_rot; ++r) {
+            const u32 m0 = h.map[r][2 * n2];                           // map[2m + 1] = map[2m] ^ 1: one 16-byte gather per pair
+            const u64x2 g = src[m0 >> 1];
+            const u64x2 pr = reinterpret_cast<const u64x2*>(h.v[r + 1])[(size_t)tt * row + n2];
+            acc_mac(a0, (m0 & 1) ? g.y : g.x, pr.x);
+            acc_mac(a1, (m0 & 1) ? g.x : g.y, pr.y);
+        }
+    u64x2 o;
+    o.x = barrett_reduce128(a0.lo, a0.hi, br);
+    o.y = barrett_reduce128(a1.lo, a1.hi, br);
+    reinterpret_cast<u64x2*>(pre + (size_t)bi * 2 * sh.ell * N)[(size_t)v * row + n2] = o;
+}
+
 }  // namespace
+
+void launch_fold_key(const DeviceTables& t, u64* out, const u64* key, const u32* map, const u64* V, int nvec, hipStream_t s) {
+    hipLaunchKernelGGL(fold_key_kernel, dim3((1u << t.log_n) / 512, (unsigned)nvec), dim3(256), 0, s, t, out, key, map, V);
+}
+void launch_hoist_addends(const DeviceTables& t, const KsShape& sh, const HoistAdd& h, u64* pre, const u64* ct, hipStream_t s) {
+    hipLaunchKernelGGL(hoist_addends_kernel, dim3((1u << t.log_n) / 512, (unsigned)(sh.batch * 2 * sh.ell)), dim3(256), 0, s, t, sh, h, pre, ct);
+}
 
 void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const u64* cc, const u64* c_ntt, const u64* hatinv,
                        const u64* hatmod, hipStream_t s) {

@@ -147,7 +147,8 @@ void fhelin_pt_free(fhelin_pt* p);
 /* the residues [ell][N] (NTT form) this plaintext multiplies / adds with at `ell` live limbs and real scaling factor
  * scale_hi + scale_lo (the library keeps scales as 80-bit long double: two doubles carry one exactly; scale_hi <= 0:
  * the context's Delta of that level) — exactly the encoding EvalMult(ct,pt) / EvalAdd(ct,pt) use for a ciphertext of that
- * shape (parity tests hand them to the oracle's dyadic functions) */
+ * shape (parity tests hand them to the oracle's dyadic functions).  ell = L + 1 + k (all limbs of the chain and the special
+ * limbs; explicit scale required): the encoding over the full key basis, [L + 1 + k][N], as fhelin_hoisted_dot folds it into keys */
 int fhelin_pt_export(fhelin_ctx* c, const fhelin_pt* p, int32_t ell, double scale_hi, double scale_lo, uint64_t* out,
                      size_t cap_words);
 
@@ -207,6 +208,14 @@ int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* 
  * row: the rotated terms are accumulated in the extended basis QP.  Two steps of the reference's rotsum loop (:829-837),
  * x += rot(x, s); x += rot(x, 2s), are the call {s, 2s, 3s}.  Needs the rotation keys of all indices. */
 int fhelin_rotate_sum(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const int32_t* indices, int32_t n_rot, fhelin_ct** outs);
+/* outs[i] = v[i] * pts[0] + sum_r EvalRotate(v[i], indices[r]) * pts[r + 1] (1 <= n_rot <= 7; pts: n_rot + 1 plaintexts) with one
+ * decomposition and ONE ModDown per row ("double hoisting"): the plaintext products are taken in the extended basis QP, through
+ * rotation keys with the plaintext folded in (built once per (plaintext, index, scale) and cached: one full key copy each - meant
+ * for few plaintexts shared by many rows).  The first step of matmulRElarge (src/FHEController.cpp:915-944 re-associated, DESIGN.md
+ * §7) is the call {128, 256, 384} over all rows.  Result: noise degree + 1, scale x the level's plaintext scale.  The plaintext
+ * encodings over the full key basis are fhelin_pt_export(p, L + 1 + k, scale). */
+int fhelin_hoisted_dot(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const fhelin_pt* const* pts, const int32_t* indices,
+                       int32_t n_rot, fhelin_ct** outs);
 /* out = sum_i EvalRotate(v[i], indices[i]) (index 0 = plain addend): the giant steps of EvalBootstrap's linear
  * transforms (:445) — one ModUp per term, inner products accumulated in QP, ONE ModDown per group of <= 7 terms */
 int fhelin_rotate_each_sum(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* indices, int32_t n, fhelin_ct** out);

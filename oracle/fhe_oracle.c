@@ -677,6 +677,59 @@ void orc_rotate_each_sum(const u64* cts, const u64* evks, const u64* gs, int R, 
     free(c0s);
 }
 
+/* Double hoisting (csrc/kernels_elem.h launch_fold_key, Evaluator::hoisted_dot_rows): sum of rotations of ONE ciphertext times
+ * plaintexts, the plaintext products taken in the extended basis QP before the single ModDown:
+ *     ks    = ModDown( sum_r V_{r+1} . sigma_r( ModUp(c1) * evk_r ) )                      (V over the basis of the key switch)
+ *     out_0 = ks_0 + V_0 c0 + sum_r V_{r+1} sigma_r(c0),      out_1 = ks_1 + V_0 c1.
+ * ct, out: [2][ell][N]; evks: [R] keys, contiguous; pts: [R + 1][L1 + k][N] encodings over the FULL key basis (q_0..q_{L1-1},
+ * p_0..p_{k-1}), NTT form; entry 0 belongs to the unrotated term (only its first ell limbs are read). */
+void orc_hoisted_dot(const u64* ct, const u64* evks, const u64* gs, int R, const u64* pts, u64* out, int ell, int L1, int k, int alpha,
+                     int log_n, const u64* q, const u64* p, const u64* psi_q, const u64* psi_p) {
+    const ks_par P = {ell, L1, k, alpha, log_n, q, p, psi_q, psi_p};
+    size_t n = (size_t)1 << log_n, pn = n * ell;
+    int nt = ell + k, beta = ks_beta(&P);
+    size_t key_words = (size_t)((L1 + alpha - 1) / alpha) * 2 * (L1 + k) * n;
+    size_t pt_words = (size_t)(L1 + k) * n;
+    ks_tabs(&P);
+    u64* d = malloc(8 * n * nt * beta);
+    ks_modup(&P, ct + pn, d);
+    u64* acc = calloc((size_t)2 * nt * n, 8);
+    u64* tmp = malloc((size_t)2 * nt * n * 8);
+    u64* add = calloc(2 * pn, 8);
+    u32* map = malloc(4 * n);
+    /* the unrotated term: V_0 (c0, c1) */
+    for (int c = 0; c < 2; ++c) orc_mul(ct + (size_t)c * pn, pts, add + (size_t)c * pn, ell, log_n, q);
+    for (int r = 0; r < R; ++r) {
+        const u64* V = pts + (size_t)(r + 1) * pt_words;
+        automorph_map(map, log_n, gs[r]);
+        memset(tmp, 0, (size_t)2 * nt * n * 8);
+        ks_inner_acc(&P, d, evks + (size_t)r * key_words, tmp, map);
+        #pragma omp parallel for schedule(dynamic, 1)
+        for (int t = 0; t < nt; ++t) {
+            u64 mt = ks_mod(&P, t);
+            const modq mm = mq_make(mt);
+            const u64* v = V + (size_t)(t < ell ? t : L1 + (t - ell)) * n;
+            for (int c = 0; c < 2; ++c) {
+                u64* a = acc + ((size_t)c * nt + t) * n;
+                const u64* x = tmp + ((size_t)c * nt + t) * n;
+                for (size_t i = 0; i < n; ++i) a[i] = addmod(a[i], mq_mul(x[i], v[i], &mm), mt);
+            }
+        }
+        #pragma omp parallel for schedule(static)
+        for (int t = 0; t < ell; ++t) {
+            const modq mm = mq_make(q[t]);
+            for (size_t i = 0; i < n; ++i)
+                add[(size_t)t * n + i] = addmod(add[(size_t)t * n + i], mq_mul(ct[(size_t)t * n + map[i]], V[(size_t)t * n + i], &mm), q[t]);
+        }
+    }
+    free(d); free(map); free(tmp);
+    ks_moddown(&P, acc, out);
+    free(acc);
+    orc_add(out, add, out, ell, log_n, q);
+    orc_add(out + pn, add + pn, out + pn, ell, log_n, q);
+    free(add);
+}
+
 /* EvalMult(ct, ct) (reference :431) without the surrounding rescale: tensor + relinearise d2.
  * a, b, out: [2][ell][N];  out = (a0 b0 + ks0, a0 b1 + a1 b0 + ks1) with ks = KeySwitch(a1 b1, relin key). */
 void orc_mult_relin(const u64* a, const u64* b, const u64* evk, u64* out, int ell, int L1, int k, int alpha,

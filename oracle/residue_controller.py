@@ -3,7 +3,8 @@
 `ResidueController` runs the driver fhe-linformer_amd/linformer.py (the call sequence of reference src/main.cpp:145-475 /
 src/main_2.cpp) unchanged, every method composed from oracle/fhe_oracle.c through oracle/residue_eval.py and
 oracle/residue_boot.py in the order fhe-linformer_amd/csrc/composite.cpp runs it BY DEFAULT (products rescaled before their trees,
-tree steps merged in triples / pairs, log-depth shift trees, the re-associated matmulRElarge, the two-stage unwrapRepeatedLarge).
+tree steps merged in triples / pairs, log-depth shift trees, the re-associated matmulRElarge with its double-hoisted first step, the
+two-stage unwrapRepeatedLarge).
 The complete forward pass of the GPU library must end in the same residues, bit for bit (tests/test_forward_residue_gpu.py).
 
 What enters from the library, as for every other residue test: the switching keys (exported), the plaintext encodings
@@ -194,12 +195,15 @@ class ResidueController:
         return self._matmul_pt(rows, w, bias, 128, 1)
 
     def matmulRElarge(self, rows, weights, bias, mask_val=1.0):
-        w2 = []
-        for t in range(4):                                     # Composite::relarge_weights: block b of W''_t = block b of W_((b - t) mod 4)
-            v = np.zeros(SLOTS)
-            for b in range(128):
-                v[128 * b:128 * (b + 1)] = weights[(b - t) % 4].values[128 * b:128 * (b + 1)]
-            w2.append(RPt(self.eng, v, weights[0].level).enc)
+        if getattr(self, "_relarge_for", None) is not weights[0]:       # a call's four V_t, kept while the same weights come back (row subsets)
+            w2 = []
+            for t in range(4):                                 # Composite::relarge_weights: block b of W''_t = block b of W_((b - t) mod 4),
+                v = np.zeros(SLOTS)                            # V_t = rot(W''_t, 128 t)
+                for b in range(128):
+                    v[128 * b:128 * (b + 1)] = weights[(b - t) % 4].values[128 * b:128 * (b + 1)]
+                w2.append(RPt(self.eng, np.roll(v, -128 * t), weights[0].level).enc)
+            self._relarge_for, self._relarge_v = weights[0], w2
+        w2 = self._relarge_v
         m512 = self._block_mask(0, 512, mask_val).enc
         return self.rev.matmulRElarge(list(rows), w2, bias.enc if bias is not None else None, m512)
 

@@ -194,6 +194,23 @@ class ResidueEvaluator:
             acc = t if acc is None else self.add(acc, t)
         return acc
 
+    def hoisted_dot(self, a, encs, indices):
+        """a * V_0 + sum_r rot(a, indices[r]) * V_{r+1} (Evaluator::hoisted_dot_rows, one row): a degree-2 operand is rescaled
+        first, the plaintexts are encoded at the level's Delta over the FULL key basis (enc(n_q + n_p, scale)), one ModUp and
+        one ModDown, the plaintext products taken in QP (orc_hoisted_dot)"""
+        x = self.rescale(a) if a.deg >= 2 else a
+        sf = self.sf[self.level(x)]
+        nl = len(self.q) + len(self.p)
+        if not hasattr(self, "_full"):
+            self._full = {}
+        k = (tuple(id(e) for e in encs), float(sf), float(sf - LD(float(sf))))
+        if k not in self._full:           # the same few plaintexts serve every row of a call
+            self._full.clear()
+            self._full[k] = np.stack([e(nl, sf) for e in encs])
+        d = orc.hoisted_dot(x.d, self._stack(indices), [self._g(r) for r in indices], self._full[k], self.alpha, self.q, self.p,
+                            self.psi_q, self.psi_p)
+        return RCt(d, x.deg + 1, x.scale * sf)
+
     # ---- ct x ct, real constants, polynomial evaluation (reference :431, :1289-1336; order of csrc/polyeval.cpp)
     def mult(self, a, b):
         """EvalMult(ct, ct) (:431): degree-2 operands are rescaled first, the pair is level-adjusted, tensor + relinearisation
@@ -473,16 +490,14 @@ class ResidueEvaluator:
             out = [self.add_plain(o, bias_enc) for o in out]
         return out
 
-    def matmulRElarge(self, rows, w2_encs, bias_enc, mask512_enc):
-        """composite.cpp matmulRElarge, shared form: U = sum_{t<4} rot(x * W''_t, 128 t) (one shared-ModDown key switch of three
-        rotated terms + the unrotated one), Z = rotsum(U, 32, 512), out = Z * mask[0,512) + bias.  w2_encs[t] encodes W''_t
-        (block b of W''_t = block b of W_((b - t) mod 4)); a degree-2 input is rescaled once, the four products go through the
-        key switch unrescaled and U is rescaled once (by rotsum)"""
+    def matmulRElarge(self, rows, v_encs, bias_enc, mask512_enc):
+        """composite.cpp matmulRElarge, shared form: U = x * V_0 + sum_{t=1..3} rot(x, 128 t) * V_t (double hoisting: one ModUp, one
+        ModDown, the plaintext products in the extended basis), Z = rotsum(U, 32, 512), out = Z * mask[0,512) + bias.  v_encs[t]
+        encodes V_t = rot(W''_t, 128 t) (block b of W''_t = block b of W_((b - t) mod 4)); a degree-2 input is rescaled once and U is
+        rescaled once (by rotsum)"""
         out = []
         for r in rows:
-            x = self.rescale(r) if r.deg >= 2 else r
-            y = [self.mult_plain(x, w2_encs[t]) for t in range(4)]
-            u = self.rotate_each_sum(y, [0, 128, 256, 384])
+            u = self.hoisted_dot(r, v_encs, [128, 256, 384])
             z = self.rotsum(u, 32, 512)
             o = self.mult_plain(z, mask512_enc)
             out.append(self.add_plain(o, bias_enc) if bias_enc is not None else o)

@@ -2,7 +2,7 @@
 merged rotate-and-sum key switches (ks_inner_multi + gather_sum, one ModDown), the shared-ModDown giant steps,
 ct x pt / scalar / ct + pt element-wise kernels, the FLEXIBLEAUTO level adjustment, ModRaise, the decryption phase,
 and the composites with every default-on knob (FHELIN_MERGE_ROT, FHELIN_EARLY_RESCALE, log-depth shift trees, block
-masks in place of matmulRElarge's -128 shifts) left ON.  All comparisons are bit-exact (integer functions); plaintext operands enter the
+masks in place of matmulRElarge's -128 shifts, its double-hoisted first step) left ON.  All comparisons are bit-exact (integer functions); plaintext operands enter the
 oracle as the residues the library's encoder produced (fhelin_pt_export; the encoder is the client-side row a16)."""
 import numpy as np
 import pytest
@@ -78,6 +78,58 @@ def test_rotate_sum_bit_exact(engine_factory, orc, preset, over, ells, idx, rows
             want = orc.rotate_sum(x, evks, gs, eng.alpha, eng.q, eng.p, eng.psi_q, eng.psi_p)
             assert np.array_equal(g.export(), want), (preset, ell)
     del keys, evks
+
+
+@pytest.mark.parametrize("preset,over,ells,idx,rows,deg", [
+    ("toy", {}, [6, 5, 3, 2], [1, 2, 3], 2, 1),              # dnum=3, alpha=2: full, partial and single digit
+    ("toy13", {}, [7, 4], [64, 128, 192], 3, 1),             # three rotations, three rows
+    ("toy13", {}, [6], [1, 2, 3, 4, 5, 6, 7], 2, 2),         # the kernel's maximum of 7 rotations; degree-2 rows are rescaled first
+    ("toy13", {}, [5], [-2], 1, 1),                          # a single rotated term
+    ("reference", {}, [13, 9], [128, 256, 384], 2, 1),       # matmulRElarge's first step at the reference's ring (N=2^15, 28+7 limbs)
+    ("bench", FORWARD16, [13], [128, 256, 384], 3, 1),       # ... and at the headline ring: the LDS-staged digit tiles (rotations by 64 k slots)
+])
+def test_hoisted_dot_bit_exact(engine_factory, orc, preset, over, ells, idx, rows, deg):
+    """fhelin_hoisted_dot (Evaluator::hoisted_dot_rows: one ModUp, ks_inner_multi_kernel over rotation keys with the plaintexts folded
+    in by fold_key_kernel, hoist_addends_kernel, ONE ModDown) == orc_hoisted_dot on every residue, for a batch of rows.  The plaintext
+    encodings over the full key basis enter the oracle as exported (fhelin_pt_export at n_q + n_p limbs)."""
+    eng = engine_factory(preset, **over)
+    keys = _keys(orc, eng, idx, seed=6100)
+    rev = _rev(orc, eng, keys)
+    rng = np.random.default_rng(77)
+    ns = 1 << eng.params.log_slots
+    pts = [eng.encode(rng.uniform(-1, 1, ns)) for _ in range(len(idx) + 1)]
+    encs = [(lambda p: (lambda ell, sc: eng.pt_export(p, ell, sc)))(p) for p in pts]
+    for ell in ells:
+        pairs = [_imp(eng, rev, _ct(orc, eng, 500 + 7 * i + ell, ell), deg=deg) for i in range(rows)]
+        got = eng.hoisted_dot([p[0] for p in pairs], pts, idx)
+        for (c, r), g in zip(pairs, got):
+            want = rev.hoisted_dot(r, encs, idx)
+            _same(g, want, (preset, ell))
+            hi, lo = g.scale_parts()
+            assert LD(hi) + LD(lo) == want.scale
+    del keys
+
+
+def test_hoisted_dot_is_the_sum_of_rotated_products(fa):
+    """semantics with real keys: decrypt(hoisted_dot(x, V, idx)) = x * V_0 + sum_r rot(x, idx_r) * V_{r+1}, and it agrees with the
+    products-then-rotations form the library used before (mult_plain + rotate + add) to key-switching noise"""
+    eng = fa.Engine("toy13", seed=21)
+    try:
+        idx = [128, 256, 384]
+        eng.keygen()
+        eng.gen_rotation_keys(idx)
+        ns = 1 << eng.params.log_slots
+        rng = np.random.default_rng(5)
+        xs = [rng.uniform(-1, 1, ns) for _ in range(3)]
+        vs = [rng.uniform(-1, 1, ns) for _ in range(4)]
+        cts = [eng.encrypt(x) for x in xs]
+        outs = eng.hoisted_dot(cts, [eng.encode(v) for v in vs], idx)
+        for x, o in zip(xs, outs):
+            want = x * vs[0] + sum(np.roll(x, -r) * vs[k + 1] for k, r in enumerate(idx))
+            assert o.info()["deg"] == 2
+            assert np.max(np.abs(eng.decrypt(o)[:ns] - want)) < 1e-6
+    finally:
+        eng.close()
 
 
 @pytest.mark.parametrize("preset,over,ell,idx", [
@@ -294,7 +346,7 @@ def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
             v = np.zeros(ns)
             for b in range(128):
                 v[128 * b:128 * (b + 1)] = wv[(b - t) % 4][128 * b:128 * (b + 1)]
-            w2.append(enc_of(pt(v)))
+            w2.append(enc_of(pt(np.roll(v, -128 * t))))                 # V_t = rot(W''_t, 128 t): the first step is double-hoisted
         m512 = np.zeros(ns)
         m512[:512] = 0.5
         rows = cts[:2]

@@ -19,8 +19,8 @@ acc = collections.OrderedDict()
 
 
 def note(name, dt, d):
-    a = acc.setdefault(name, [0, 0.0, 0, 0])
-    a[0] += 1; a[1] += dt; a[2] += d["keyswitch"]; a[3] += d["limb_ntt"]
+    a = acc.setdefault(name, [0, 0.0, 0, 0, 0])
+    a[0] += 1; a[1] += dt; a[2] += d["keyswitch"]; a[3] += d["limb_ntt"]; a[4] += d["keyswitch_limbs"]
 
 
 class Timed(lf.GpuController):
@@ -68,6 +68,6 @@ for rep in range(2):
     out = lf.forward_encrypted(ctl, w, enc); e.sync()
     total = time.perf_counter() - t0
 print(f"forward (synchronised per call) {total*1e3:.0f} ms, N=2^{log_n}, S={S}, level plan {'on' if use_plan else 'off'}")
-print(f"{'method':58s} {'calls':>5s} {'keyswitch':>10s} {'limb-NTT':>10s} {'ms':>8s}")
-for k, (n, dt, ks, ntt) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
-    print(f"{k:58s} {n:5d} {ks:10d} {ntt:10d} {dt*1e3:8.1f}")
+print(f"{'method':58s} {'calls':>5s} {'keyswitch':>10s} {'limbs/ks':>8s} {'limb-NTT':>10s} {'ms':>8s}")
+for k, (n, dt, ks, ntt, ksl) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+    print(f"{k:58s} {n:5d} {ks:10d} {ksl / max(ks, 1):8.1f} {ntt:10d} {dt*1e3:8.1f}")
