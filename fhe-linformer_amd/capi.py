@@ -135,7 +135,7 @@ def load_library():
         "fhelin_rotate_many": (i32, [vp, vp, C.POINTER(i32), i32, C.POINTER(vp)]),
         "fhelin_rotate_each": (i32, [vp, C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(vp)]),
         "fhelin_rotate_sum": (i32, [vp, C.POINTER(vp), i32, C.POINTER(i32), i32, C.POINTER(vp)]),
-        "fhelin_hoisted_dot": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(vp)]),
+        "fhelin_hoisted_dot": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(i32), i32, i32, C.POINTER(vp)]),
         "fhelin_rescale": (i32, [vp, vp, C.POINTER(vp)]),
         "fhelin_rotate_batch": (i32, [vp, C.POINTER(vp), i32, i32, C.POINTER(vp)]),
         "fhelin_rescale_batch": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp)]),
@@ -499,14 +499,14 @@ class Engine:
         self._ck(self.lib.fhelin_rotate_sum(self.h, self._harr(v), len(v), idx, len(indices), outs))
         return self._cts(outs, len(v))
 
-    def hoisted_dot(self, v, pts, indices):
+    def hoisted_dot(self, v, pts, indices, rescale=False):
         """v[i] * pts[0] + sum_r rot(v[i], indices[r]) * pts[r + 1]: one ModUp and one ModDown per row, plaintext products in the
-        extended basis (plaintext-folded rotation keys)"""
+        extended basis (plaintext-folded rotation keys); rescale: ModDown and rescale as one basis conversion"""
         assert len(pts) == len(indices) + 1
         idx = (C.c_int32 * len(indices))(*indices)
         parr = (C.c_void_p * len(pts))(*[p.h for p in pts])
         outs = self._outs(len(v))
-        self._ck(self.lib.fhelin_hoisted_dot(self.h, self._harr(v), len(v), parr, idx, len(indices), outs))
+        self._ck(self.lib.fhelin_hoisted_dot(self.h, self._harr(v), len(v), parr, idx, len(indices), int(bool(rescale)), outs))
         return self._cts(outs, len(v))
 
     def rotate_each_sum(self, v, indices):

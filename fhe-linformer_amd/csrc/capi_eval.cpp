@@ -349,7 +349,7 @@ int fhelin_rotate_each(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* 
     FHELIN_CATCH
 }
 int fhelin_hoisted_dot(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const fhelin_pt* const* pts, const int32_t* indices, int32_t n_rot,
-                       fhelin_ct** outs) {
+                       int32_t rescale, fhelin_ct** outs) {
     NEED(c && v && pts && indices && outs && n >= 0 && n_rot >= 1);
     FHELIN_TRY
     std::vector<CtPtr> in;
@@ -362,7 +362,7 @@ int fhelin_hoisted_dot(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, cons
     }
     force_many(c, v, n);
     for (int i = 0; i < n; ++i) in.push_back(ct_in(c, v[i]));
-    std::vector<CtPtr> r = c->ev.hoisted_dot_rows(in, p, std::vector<int>(indices, indices + n_rot));
+    std::vector<CtPtr> r = c->ev.hoisted_dot_rows(in, p, std::vector<int>(indices, indices + n_rot), rescale != 0);
     for (int i = 0; i < n; ++i) outs[i] = wrap(c, r[i]);
     FHELIN_CATCH
 }

@@ -18,6 +18,7 @@ Composite::Composite(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {
     if (const char* e = std::getenv("FHELIN_CHEB_ROUNDS")) ev_.cheb_rounds = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_DOT_GROUPS")) ev_.dot_groups = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_DOUBLE_HOIST")) ev_.double_hoist = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FHELIN_MERGED_RESCALE")) ev_.merged_rescale = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_CHEB_LEAF_AT")) ev_.cheb_leaf_at_product = std::atoi(e) != 0;
     if (const char* b = std::getenv("FHELIN_BATCH")) {
         int v = std::atoi(b);
@@ -335,7 +336,8 @@ CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& we
             // U = x * V_0 + sum_{t=1..3} rot(x, 128 t) * V_t with V_t = rot(W''_t, 128 t): the three rotations share ONE ModUp of the row
             // and the plaintext products are taken in the extended basis (rotation keys with V_t folded in: Evaluator::hoisted_dot_rows),
             // so a row costs one ModUp and one ModDown where the products-then-rotations form costs three ModUps and one ModDown
-            u = ev_.hoisted_dot_rows(x, relarge_weights(weights, true), {128, 256, 384});
+            // U is wanted rescaled (the tree below runs on degree-1 rows): ModDown and rescale are one basis conversion
+            u = ev_.hoisted_dot_rows(x, relarge_weights(weights, true), {128, 256, 384}, ev_.merged_rescale);
         } else {
             const std::vector<PtPtr> w2 = relarge_weights(weights, false);
             std::vector<CtVec> y(4);

@@ -286,6 +286,12 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
         d_phatinv = upload_table(phatinv);
         d_phatmod = upload_table(phatmod);
         d_pinv = upload_table(pinv);
+        std::vector<u64> pmod(2 * (L + 1));
+        for (int t = 0; t <= L; ++t) {
+            pmod[2 * t] = prod_mod(chain.p, -1, chain.q[t]);
+            pmod[2 * t + 1] = h_shoup(pmod[2 * t], chain.q[t]);
+        }
+        d_pmod = upload_table(pmod);
         std::vector<u64> qlinv((size_t)(L + 1) * (L + 1) * 2, 0), qlmod((size_t)(L + 1) * (L + 1), 0);
         for (int l = 0; l <= L; ++l)
             for (int t = 0; t < l; ++t) {
@@ -329,6 +335,31 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
         lt.up_hatinv = upload_table(hatinv);
         lt.up_hatmod = upload_table(hatmod);
         lt.ext_limb_tab = upload_table(tab);
+        if (ell >= 2 && K >= 1) {   // ModDown + rescale in one conversion: drop B = (p_0..p_{k-1}, q_{ell-1})
+            const u64 ql = chain.q[ell - 1];
+            const int e1 = ell - 1;
+            std::vector<u64> mhi(2 * (K + 1)), mhm((size_t)(K + 1) * e1), minv(2 * e1);
+            for (int j = 0; j <= K; ++j) {
+                const u64 b = j < K ? chain.p[j] : ql;
+                const u64 hat_b = j < K ? h_mulmod(prod_mod(chain.p, j, b), ql % b, b) : prod_mod(chain.p, -1, b);
+                const u64 inv = h_invmod(hat_b, b);
+                mhi[2 * j] = inv;
+                mhi[2 * j + 1] = h_shoup(inv, b);
+                for (int t = 0; t < e1; ++t) {
+                    const u64 qt = chain.q[t];
+                    mhm[(size_t)j * e1 + t] = pack30(j < K ? h_mulmod(prod_mod(chain.p, j, qt), ql % qt, qt) : prod_mod(chain.p, -1, qt));
+                }
+            }
+            for (int t = 0; t < e1; ++t) {
+                const u64 qt = chain.q[t];
+                const u64 inv = h_invmod(h_mulmod(prod_mod(chain.p, -1, qt), ql % qt, qt), qt);
+                minv[2 * t] = inv;
+                minv[2 * t + 1] = h_shoup(inv, qt);
+            }
+            lt.md_hatinv = upload_table(mhi);
+            lt.md_hatmod = upload_table(mhm);
+            lt.md_minv = upload_table(minv);
+        }
     }
 }
 

@@ -79,6 +79,11 @@ struct LevelTables {
     const u64* up_hatinv = nullptr;   // [ell][2]
     const u64* up_hatmod = nullptr;   // [ell][ell+k]
     const int* ext_limb_tab = nullptr;  // [beta*(ell+k)] limb id for the NTT after ModUp, -1 on own-digit slots
+    // ModDown and rescale as ONE basis conversion (kernels_elem.h launch_moddown_rescale_conv; ell >= 2): the dropped basis is
+    // B = (p_0..p_{k-1}, q_{ell-1}) with product M = P q_{ell-1}
+    const u64* md_hatinv = nullptr;   // [k+1][2]      (M/b)^{-1} mod b, shoup
+    const u64* md_hatmod = nullptr;   // [k+1][ell-1]  (M/b) mod q_t, pre-split (pack30)
+    const u64* md_minv = nullptr;     // [ell-1][2]    M^{-1} mod q_t, shoup
 };
 
 // host-side operation counters (bench.py scales the CPU baseline sample with these)
@@ -158,6 +163,7 @@ struct Context {
     const u64* d_phatinv = nullptr;  // [k][2]   (P/p)^{-1} mod p, shoup
     const u64* d_phatmod = nullptr;  // [k][L+1] (P/p) mod q_t
     const u64* d_pinv = nullptr;     // [L+1][2] P^{-1} mod q_t, shoup
+    const u64* d_pmod = nullptr;     // [L+1][2] P mod q_t, shoup
     const u64* d_qlinv = nullptr;    // [L+1][L+1][2]  q_l^{-1} mod q_t, shoup   (row l, col t<l)
     const u64* d_qlmod = nullptr;    // [L+1][L+1]     q_l mod q_t
     std::vector<LevelTables> lvl;    // index by ell (1..L+1)

@@ -354,7 +354,8 @@ const Evaluator::FoldedKey& Evaluator::folded_key(const PtPtr& p, int index, lon
     return folded_keys.back();
 }
 
-std::vector<CtPtr> Evaluator::hoisted_dot_rows(const std::vector<CtPtr>& xin, const std::vector<PtPtr>& pts, const std::vector<int>& indices) {
+std::vector<CtPtr> Evaluator::hoisted_dot_rows(const std::vector<CtPtr>& xin, const std::vector<PtPtr>& pts, const std::vector<int>& indices,
+                                              bool rescale_out) {
     if (xin.empty()) return {};
     const int R = (int)indices.size();
     if (R < 1 || R > KsShape::MAX_ROT || (int)pts.size() != R + 1)
@@ -401,9 +402,12 @@ std::vector<CtPtr> Evaluator::hoisted_dot_rows(const std::vector<CtPtr>& xin, co
         const LevelTables& lt = c_.lvl[ell];
         const int nt = ell + K;
         const long double sf = c_.sf_real[chunk[0]->level()];
-        std::vector<CtPtr> o = new_ct_batch(B, 2, ell, chunk[0]->deg + 1, chunk[0]->scale * sf, chunk[0]->slots);
+        const bool merged = rescale_out && ell >= 2 && K + 1 <= 16;
+        if (rescale_out && !merged) throw Error(FHELIN_ERR_STATE, "hoisted_dot_rows: no limb left to drop");
+        const int oell = merged ? ell - 1 : ell;
+        std::vector<CtPtr> o = new_ct_batch(B, 2, oell, merged ? chunk[0]->deg : chunk[0]->deg + 1, chunk[0]->scale * sf, chunk[0]->slots);
         const u64* base = chunk[0]->d;
-        KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, ctw, ctw, pn, ctw};
+        KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, ctw, (size_t)2 * oell * N, pn, ctw};
         sh.n_rot = R;
         sh.lds_digits = c_.lds_digits ? 1 : 0;
         HoistAdd h;
@@ -423,6 +427,10 @@ std::vector<CtPtr> Evaluator::hoisted_dot_rows(const std::vector<CtPtr>& xin, co
         c_.stats.keyswitch_limbs += (u64)B * R * ell;
         c_.stats.ct_pt_mult += (u64)B * (R + 1);
         c_.stats.ct_pt_limbs += (u64)B * (R + 1) * ell;
+        if (merged) {
+            c_.stats.rescale += (u64)B;
+            c_.stats.rescale_limbs += (u64)B * ell;
+        }
         // ModUp of c1, once for all rotations
         u64* cc = c_.dalloc<u64>((size_t)B * ell * N);
         {
@@ -443,24 +451,48 @@ std::vector<CtPtr> Evaluator::hoisted_dot_rows(const std::vector<CtPtr>& xin, co
         u64* accQ = c_.dalloc<u64>((size_t)B * 2 * ell * N);
         u64* accP = c_.dalloc<u64>((size_t)B * 2 * K * N);
         launch_ks_inner_multi(c_.dt, sh, accQ, accP, ext, base + pn, s);
-        // what does not pass through the key switch: V_0 (c0, c1) + sum_r V_r sigma_r(c0)
-        u64* pre = c_.dalloc<u64>((size_t)B * ctw);
-        launch_hoist_addends(c_.dt, sh, h, pre, base, s);
-        // one ModDown
-        c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
-        u64* conv = c_.dalloc<u64>((size_t)B * 2 * ell * N);
-        launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
-        c_.ntt(LimbBatch{conv, B * 2 * ell, nullptr, 0, ell}, false);
-        launch_moddown_finish(c_.dt, sh, o[0]->d, accQ, conv, c_.d_pinv, nullptr, nullptr, nullptr, pre, s);
+        u64* pre = nullptr;
+        u64* conv = nullptr;
+        u64* top = nullptr;
+        if (!merged) {
+            // what does not pass through the key switch: V_0 (c0, c1) + sum_r V_r sigma_r(c0)
+            pre = c_.dalloc<u64>((size_t)B * ctw);
+            launch_hoist_addends(c_.dt, sh, h, pre, base, s);
+            // one ModDown
+            c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
+            conv = c_.dalloc<u64>((size_t)B * 2 * ell * N);
+            launch_moddown_conv(c_.dt, sh, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
+            c_.ntt(LimbBatch{conv, B * 2 * ell, nullptr, 0, ell}, false);
+            launch_moddown_finish(c_.dt, sh, o[0]->d, accQ, conv, c_.d_pinv, nullptr, nullptr, nullptr, pre, s);
+        } else {
+            // the same addends times P into the accumulator's Q part, then P and the top limb are dropped together
+            h.acc = accQ;
+            h.pmod = c_.d_pmod;
+            launch_hoist_addends(c_.dt, sh, h, nullptr, base, s);
+            c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
+            top = c_.dalloc<u64>((size_t)B * 2 * N);
+            {
+                LimbBatch tb{top, B * 2, nullptr, ell - 1, 1, accQ + (size_t)(ell - 1) * N};
+                tb.src_group = 1;
+                tb.src_group_stride = pn;
+                c_.ntt(tb, true);
+            }
+            conv = c_.dalloc<u64>((size_t)B * 2 * (ell - 1) * N);
+            launch_moddown_rescale_conv(c_.dt, sh, conv, accP, top, lt.md_hatinv, lt.md_hatmod, s);
+            c_.ntt(LimbBatch{conv, B * 2 * (ell - 1), nullptr, 0, ell - 1}, false);
+            launch_moddown_rescale_finish(c_.dt, sh, o[0]->d, accQ, conv, lt.md_minv, s);
+        }
         launch_ok("hoisted_dot_rows");
         c_.pool.free(cc);
         c_.pool.free(ext);
         c_.pool.free(accQ);
         c_.pool.free(accP);
-        c_.pool.free(pre);
+        if (pre) c_.pool.free(pre);
+        if (top) c_.pool.free(top);
         c_.pool.free(conv);
         for (int b = 0; b < B; ++b) {
             o[b]->scale = x[idx[b]]->scale * sf;
+            if (merged) o[b]->scale = o[b]->scale / (long double)c_.chain.q[ell - 1];
             out[idx[b]] = o[b];
             done[idx[b]] = 1;
         }

@@ -132,7 +132,12 @@ public:
     // products are taken in the extended basis, through rotation keys with the plaintext folded in (folded_key; kernels_elem.h
     // launch_fold_key).  Meant for FEW plaintexts shared by MANY rows (the re-arranged weights of matmulRElarge): a folded key is a
     // full key copy.  Output: noise degree + 1, scale x the level's plaintext scale; 1 <= R <= 7 rotations.
-    std::vector<CtPtr> hoisted_dot_rows(const std::vector<CtPtr>& xs, const std::vector<PtPtr>& pts, const std::vector<int>& indices);
+    // rescale_out: the result is wanted rescaled - ModDown and rescale run as ONE basis conversion (drop P and the top limb together:
+    // kernels_elem.h launch_moddown_rescale_conv); output one limb and one noise degree lower, scale / q_top.  A different integer
+    // function from hoisted_dot_rows + rescale (one rounding instead of two), same value up to rounding noise.
+    std::vector<CtPtr> hoisted_dot_rows(const std::vector<CtPtr>& xs, const std::vector<PtPtr>& pts, const std::vector<int>& indices,
+                                        bool rescale_out = false);
+    bool merged_rescale = true; // results that are rescaled right after their key switch drop P and the top limb in one conversion; FHELIN_MERGED_RESCALE=0: ModDown, then rescale
     bool double_hoist = true;   // Composite::matmulRElarge takes its first step through hoisted_dot_rows; FHELIN_DOUBLE_HOIST=0: rotate_each_sum_rows
     struct FoldedKey {
         PtPtr pt;

@@ -131,10 +131,15 @@ void launch_fold_key(const DeviceTables& t, u64* out, const u64* key, const u32*
 // what does not pass through the key switch: pre[b][0][t][n] = V_0[t][n] c0_b[t][n] + sum_r V_{r+1}[t][n] c0_b[t][map_r[n]],
 // pre[b][1][t][n] = V_0[t][n] c1_b[t][n]   (ct: batch row b at ct + b * sh.c_stride, [2][ell][N]; pre dense [batch][2][ell][N];
 // v[i]: [>= ell][N]).  128-bit sums, one reduction.
+// acc != nullptr: instead of storing pre, the kernel adds P * pre to the Q part of the key switch's accumulator (acc [batch][2][ell][N]
+// += pre * pmod[t]; pmod [L+1][2] = P mod q_t, shoup): the sum then passes through the ModDown with everything else, which is what a
+// ModDown merged with the rescale needs (launch_moddown_rescale_conv) - pre itself is not written.
 struct HoistAdd {
     int n_rot = 0;
     const u64* v[KsShape::MAX_ROT + 1] = {};
     const u32* map[KsShape::MAX_ROT] = {};
+    u64* acc = nullptr;
+    const u64* pmod = nullptr;
 };
 void launch_hoist_addends(const DeviceTables& t, const KsShape& sh, const HoistAdd& h, u64* pre, const u64* ct, hipStream_t s);
 // out[v][n] = sum_r in[v][map_rot[r][n]]  for v in [0, nvec) (the c0 parts of the rotated copies), per batch row
@@ -143,6 +148,17 @@ void launch_gather_sum(const DeviceTables& t, const KsShape& sh, u64* out, const
 // K8a: accP coefficient form [2][k][N] -> conv [2][ell][N] (coefficient form)
 void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
                          hipStream_t s);
+// ModDown and rescale as ONE basis conversion: with B = (p_0..p_{k-1}, q_{ell-1}), M = P q_{ell-1} and X the accumulator over
+// (q_0..q_{ell-1}, p_0..p_{k-1}):      out_t = (X_t - sum_{b in B} [X_b (M/b)^{-1}]_b [(M/b)]_t) M^{-1}  mod q_t,   t < ell - 1
+// (no centring, like K8).  A key switch whose result is rescaled right away then costs 2(k+1) inverse and 2(ell-1) forward transforms
+// where ModDown + rescale cost 2k + 2 inverse and 2 ell + 2(ell-1) forward ones.  Addends that do not pass through the key switch must
+// be in X already (multiplied by P: HoistAdd::acc).
+//   conv:   accP [batch][2][k][N] and top [batch][2][N] (= X mod q_{ell-1}) in coefficient form -> conv [batch][2][ell-1][N] (coefficient form)
+//   finish: out [batch][2][ell-1][N] = (accQ[.][.][t] - NTT(conv)) * minv_t      (accQ [batch][2][ell][N]; sh.out_stride per batch row)
+void launch_moddown_rescale_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* top, const u64* hatinv,
+                                 const u64* hatmod, hipStream_t s);
+void launch_moddown_rescale_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* minv,
+                                   hipStream_t s);
 // K8b: out[c][t][j] = (accQ[c][t][m] - conv[c][t][m]) * P^{-1} + add_c[t][m] (+ post[c][t][j]),  m = map ? map[j] : j
 void launch_moddown_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* pinv,
                            const u64* add0, const u64* add1, const u32* map, const u64* post, hipStream_t s);

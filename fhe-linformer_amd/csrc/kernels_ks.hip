@@ -468,7 +468,75 @@ __global__ __launch_bounds__(256) void hoist_addends_kernel(DeviceTables t, KsSh
     u64x2 o;
     o.x = barrett_reduce128(a0.lo, a0.hi, br);
     o.y = barrett_reduce128(a1.lo, a1.hi, br);
+    if (h.acc) {   // into the key switch's accumulator, multiplied by P
+        u64x2* A = reinterpret_cast<u64x2*>(h.acc + (size_t)bi * 2 * sh.ell * N) + (size_t)v * row + n2;
+        const u64 w = h.pmod[2 * tt], ws = h.pmod[2 * tt + 1];
+        u64x2 a = *A;
+        a.x = add_mod(a.x, mul_shoup(o.x, w, ws, br.q), br.q);
+        a.y = add_mod(a.y, mul_shoup(o.y, w, ws, br.q), br.q);
+        *A = a;
+        return;
+    }
     reinterpret_cast<u64x2*>(pre + (size_t)bi * 2 * sh.ell * N)[(size_t)v * row + n2] = o;
+}
+
+// ModDown + rescale, conversion (launch_moddown_rescale_conv): grid (N/256, batch * 2, ceil((ell-1)/TCH)); sources = the k special
+// limbs of accP and the top Q limb (coefficient form), targets t < ell - 1
+__global__ __launch_bounds__(256) void moddown_rescale_conv_kernel(DeviceTables t, KsShape sh, u64* __restrict__ conv, const u64* __restrict__ accP,
+                                                                   const u64* __restrict__ top, const u64* __restrict__ hatinv,
+                                                                   const u64* __restrict__ hatmod) {
+    constexpr int MAXS = 16;
+    const int bi = blockIdx.y >> 1, c = blockIdx.y & 1;
+    const size_t N = (size_t)1 << t.log_n;
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int e1 = sh.ell - 1, ns = sh.k + 1;
+    u32 z0[MAXS], z1[MAXS];
+#pragma unroll
+    for (int p = 0; p < MAXS; ++p) {
+        if (p < ns) {
+            const u64 x = p < sh.k ? accP[(((size_t)bi * 2 + c) * sh.k + p) * N + n] : top[((size_t)bi * 2 + c) * N + n];
+            const u64 m = t.moduli[p < sh.k ? sh.L1 + p : sh.ell - 1];
+            split30(mul_shoup(x, hatinv[2 * p], hatinv[2 * p + 1], m), z0[p], z1[p]);
+        } else {
+            z0[p] = z1[p] = 0;
+        }
+    }
+    u64* dst = conv + ((size_t)bi * 2 + c) * e1 * N + n;
+    const int t0 = blockIdx.z * TCH, t1 = min(e1, t0 + TCH);
+    for (int tt = t0; tt < t1; ++tt) {
+        const Barrett br = load_barrett(t, tt);
+        u64 slo = 0, shi = 0;
+#pragma unroll
+        for (int p0 = 0; p0 < MAXS; p0 += 8) {
+            Acc30 acc = {0, 0, 0};
+#pragma unroll
+            for (int p = p0; p < p0 + 8; ++p)
+                if (p < ns) {
+                    const u64 hm = hatmod[(size_t)p * e1 + tt];  // pre-split on the host (pack30)
+                    mac30(acc, z0[p], z1[p], (u32)hm, (u32)(hm >> 32));
+                }
+            acc30_flush(acc, slo, shi);
+        }
+        dst[(size_t)tt * N] = barrett_reduce128(slo, shi, br);
+    }
+}
+
+// grid (N/512, batch * 2 * (ell-1))
+__global__ __launch_bounds__(256) void moddown_rescale_finish_kernel(DeviceTables t, KsShape sh, u64* __restrict__ out, const u64* __restrict__ accQ,
+                                                                     const u64* __restrict__ conv, const u64* __restrict__ minv) {
+    const int e1 = sh.ell - 1;
+    const int bi = blockIdx.y / (2 * e1), v = blockIdx.y % (2 * e1);
+    const int c = v / e1, tt = v % e1;
+    const u64 q = t.moduli[tt];
+    const u64 w = minv[2 * tt], ws = minv[2 * tt + 1];
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u64x2 a = reinterpret_cast<const u64x2*>(accQ)[(((size_t)bi * 2 + c) * sh.ell + tt) * row + n2];
+    const u64x2 b = reinterpret_cast<const u64x2*>(conv)[(((size_t)bi * 2 + c) * e1 + tt) * row + n2];
+    u64x2 r;
+    r.x = mul_shoup(sub_mod(a.x, b.x, q), w, ws, q);
+    r.y = mul_shoup(sub_mod(a.y, b.y, q), w, ws, q);
+    reinterpret_cast<u64x2*>(out + (size_t)bi * sh.out_stride)[(size_t)v * row + n2] = r;
 }
 
 }  // namespace
@@ -478,6 +546,17 @@ void launch_fold_key(const DeviceTables& t, u64* out, const u64* key, const u32*
 }
 void launch_hoist_addends(const DeviceTables& t, const KsShape& sh, const HoistAdd& h, u64* pre, const u64* ct, hipStream_t s) {
     hipLaunchKernelGGL(hoist_addends_kernel, dim3((1u << t.log_n) / 512, (unsigned)(sh.batch * 2 * sh.ell)), dim3(256), 0, s, t, sh, h, pre, ct);
+}
+
+void launch_moddown_rescale_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* top, const u64* hatinv,
+                                 const u64* hatmod, hipStream_t s) {
+    dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * 2), (unsigned)((sh.ell - 1 + TCH - 1) / TCH));
+    hipLaunchKernelGGL(moddown_rescale_conv_kernel, g, dim3(256), 0, s, t, sh, conv, accP, top, hatinv, hatmod);
+}
+void launch_moddown_rescale_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* minv,
+                                   hipStream_t s) {
+    dim3 g((1u << t.log_n) / 512, (unsigned)(sh.batch * 2 * (sh.ell - 1)));
+    hipLaunchKernelGGL(moddown_rescale_finish_kernel, g, dim3(256), 0, s, t, sh, out, accQ, conv, minv);
 }
 
 void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const u64* cc, const u64* c_ntt, const u64* hatinv,

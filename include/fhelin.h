@@ -213,9 +213,11 @@ int fhelin_rotate_sum(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const
  * rotation keys with the plaintext folded in (built once per (plaintext, index, scale) and cached: one full key copy each - meant
  * for few plaintexts shared by many rows).  The first step of matmulRElarge (src/FHEController.cpp:915-944 re-associated, DESIGN.md
  * §7) is the call {128, 256, 384} over all rows.  Result: noise degree + 1, scale x the level's plaintext scale.  The plaintext
- * encodings over the full key basis are fhelin_pt_export(p, L + 1 + k, scale). */
+ * encodings over the full key basis are fhelin_pt_export(p, L + 1 + k, scale).
+ * rescale != 0: the result rescaled, with ModDown and rescale as ONE basis conversion (P and the top limb dropped together: one rounding
+ * instead of two, 2 ell fewer transforms per row): one limb fewer, the input's noise degree, scale / q_top. */
 int fhelin_hoisted_dot(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const fhelin_pt* const* pts, const int32_t* indices,
-                       int32_t n_rot, fhelin_ct** outs);
+                       int32_t n_rot, int32_t rescale, fhelin_ct** outs);
 /* out = sum_i EvalRotate(v[i], indices[i]) (index 0 = plain addend): the giant steps of EvalBootstrap's linear
  * transforms (:445) — one ModUp per term, inner products accumulated in QP, ONE ModDown per group of <= 7 terms */
 int fhelin_rotate_each_sum(fhelin_ctx* c, const fhelin_ct* const* v, const int32_t* indices, int32_t n, fhelin_ct** out);

@@ -64,7 +64,7 @@ def _load(name):
             "orc_modraise": (None, [vp, vp, i32, i32, i32, vp, vp]),
             "orc_rotate_sum": (None, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
             "orc_rotate_each_sum": (None, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
-            "orc_hoisted_dot": (None, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+            "orc_hoisted_dot": (None, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
             "orc_is_fast_build": (i32, []),
             "orc_automorph_coeff": (None, [vp, vp, i32, u64, u64]),
             "orc_automorph_ntt": (None, [vp, vp, i32, u64]),
@@ -264,16 +264,17 @@ def rotate_each_sum(cts, evks, gs, alpha, q, p, psi_q, psi_p):
     return out
 
 
-def hoisted_dot(ct, evks, gs, pts, alpha, q, p, psi_q, psi_p):
+def hoisted_dot(ct, evks, gs, pts, alpha, q, p, psi_q, psi_p, drop=False):
     """double hoisting: ct * V_0 + sum_r rot(ct, r) * V_{r+1} with ONE ModUp and ONE ModDown, the plaintext products taken in QP;
-    pts [R+1][L1+k][N] = the plaintext encodings over the full key basis"""
+    pts [R+1][L1+k][N] = the plaintext encodings over the full key basis.  drop: the result rescaled, ModDown and rescale as one
+    basis conversion -> [2][ell-1][N]"""
     ct, evks, pts, q, p, psi_q, psi_p = _u(ct), _u(evks), _u(pts), _u(q), _u(p), _u(psi_q), _u(psi_p)
     gs = _u(gs)
     _, ell, n = ct.shape
     R = len(gs)
     assert evks.shape == (R, -(-len(q) // alpha), 2, len(q) + len(p), n) and pts.shape == (R + 1, len(q) + len(p), n)
-    out = np.empty((2, ell, n), dtype=np.uint64)
-    lib().orc_hoisted_dot(_p(ct), _p(evks), _p(gs), R, _p(pts), _p(out), ell, len(q), len(p), alpha, int(np.log2(n)),
+    out = np.empty((2, ell - 1 if drop else ell, n), dtype=np.uint64)
+    lib().orc_hoisted_dot(_p(ct), _p(evks), _p(gs), R, _p(pts), _p(out), int(bool(drop)), ell, len(q), len(p), alpha, int(np.log2(n)),
                           _p(q), _p(p), _p(psi_q), _p(psi_p))
     return out
 

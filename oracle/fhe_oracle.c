@@ -573,6 +573,48 @@ static void ks_moddown(const ks_par* P, u64* acc, u64* out) {
     }
 }
 
+/* ModDown and rescale as ONE basis conversion (csrc/kernels_elem.h launch_moddown_rescale_conv).  acc [2][ell+k][N] NTT form
+ * (destroyed) -> out [2][ell-1][N].  The dropped basis is B = (p_0..p_{k-1}, q_{ell-1}), M = P q_{ell-1}:
+ *     out_t = (acc_t - sum_{b in B} [acc_b * (M/b)^{-1}]_b * [(M/b)]_t) * M^{-1}  mod q_t,   t < ell-1     (no centring) */
+static void ks_moddown_rescale(const ks_par* P, u64* acc, u64* out) {
+    size_t n = (size_t)1 << P->log_n;
+    int ell = P->ell, k = P->k, nt = ell + k, e1 = ell - 1, nb = k + 1;
+    u64 bm[65], bpsi[65];
+    for (int j = 0; j < k; ++j) { bm[j] = P->p[j]; bpsi[j] = P->psi_p[j]; }
+    bm[k] = P->q[e1]; bpsi[k] = P->psi_q[e1];
+    for (int comp = 0; comp < 2; ++comp) {
+        u64* a = acc + (size_t)comp * nt * n;
+        /* source limb j of B: acc limb ell + j (special limbs), acc limb ell - 1 (the top Q limb) for j = k */
+        #pragma omp parallel for schedule(dynamic, 1)
+        for (int j = 0; j < nb; ++j) {
+            const modq mb = mq_make(bm[j]);
+            u64* ab = a + (size_t)(j < k ? ell + j : e1) * n;
+            orc_ntt_inverse(ab, P->log_n, bm[j], bpsi[j]);
+            u64 hinv = invmod(prodmod_skip(bm, 0, nb, j, bm[j]), bm[j]);
+            for (size_t x = 0; x < n; ++x) ab[x] = mq_mul(ab[x], hinv, &mb);
+        }
+        #pragma omp parallel for schedule(dynamic, 1)
+        for (int t = 0; t < e1; ++t) {
+            u64 qt = P->q[t];
+            const modq mt = mq_make(qt);
+            u64 hmod[65];
+            for (int j = 0; j < nb; ++j) hmod[j] = prodmod_skip(bm, 0, nb, j, qt);
+            u64* conv = malloc(8 * n);
+            for (size_t x = 0; x < n; ++x) {
+                u128 s = 0;
+                for (int j = 0; j < nb; ++j) s += (u128)mq_red((u128)a[(size_t)(j < k ? ell + j : e1) * n + x], &mt) * hmod[j];
+                conv[x] = mq_red(s, &mt);
+            }
+            orc_ntt_forward(conv, P->log_n, qt, P->psi_q[t]);
+            u64 minv = invmod(prodmod_skip(bm, 0, nb, -1, qt), qt);
+            u64* o = out + ((size_t)comp * e1 + t) * n;
+            const u64* at = a + (size_t)t * n;
+            for (size_t x = 0; x < n; ++x) o[x] = mq_mul(submod(at[x], conv[x], qt), minv, &mt);
+            free(conv);
+        }
+    }
+}
+
 /* c: [ell][N] NTT form over q_0..q_{ell-1}.
  * evk: [dnum_digits][2][L1+k][N] NTT form over (q_0..q_{L1-1}, p_0..p_{k-1}); digit j, component 0 = "b", 1 = "a".
  * out: [2][ell][N] NTT form:  out_c = ModDown( sum_j ModUp_j(c) * evk[j][c] ). */
@@ -682,8 +724,10 @@ void orc_rotate_each_sum(const u64* cts, const u64* evks, const u64* gs, int R, 
  *     ks    = ModDown( sum_r V_{r+1} . sigma_r( ModUp(c1) * evk_r ) )                      (V over the basis of the key switch)
  *     out_0 = ks_0 + V_0 c0 + sum_r V_{r+1} sigma_r(c0),      out_1 = ks_1 + V_0 c1.
  * ct, out: [2][ell][N]; evks: [R] keys, contiguous; pts: [R + 1][L1 + k][N] encodings over the FULL key basis (q_0..q_{L1-1},
- * p_0..p_{k-1}), NTT form; entry 0 belongs to the unrotated term (only its first ell limbs are read). */
-void orc_hoisted_dot(const u64* ct, const u64* evks, const u64* gs, int R, const u64* pts, u64* out, int ell, int L1, int k, int alpha,
+ * p_0..p_{k-1}), NTT form; entry 0 belongs to the unrotated term (only its first ell limbs are read).
+ * drop != 0: the result rescaled, ModDown and rescale as ONE conversion (ks_moddown_rescale): the addends enter the accumulator's Q
+ * part multiplied by P first,  out = ModDownRescale( acc + P * (V_0 c + sum_r V_{r+1} sigma_r(c0)) ),  out: [2][ell-1][N]. */
+void orc_hoisted_dot(const u64* ct, const u64* evks, const u64* gs, int R, const u64* pts, u64* out, int drop, int ell, int L1, int k, int alpha,
                      int log_n, const u64* q, const u64* p, const u64* psi_q, const u64* psi_p) {
     const ks_par P = {ell, L1, k, alpha, log_n, q, p, psi_q, psi_p};
     size_t n = (size_t)1 << log_n, pn = n * ell;
@@ -723,6 +767,20 @@ void orc_hoisted_dot(const u64* ct, const u64* evks, const u64* gs, int R, const
         }
     }
     free(d); free(map); free(tmp);
+    if (drop) {
+        for (int c = 0; c < 2; ++c)
+            #pragma omp parallel for schedule(static)
+            for (int t = 0; t < ell; ++t) {
+                const modq mm = mq_make(q[t]);
+                u64 pm = prodmod_skip(p, 0, k, -1, q[t]);
+                u64* a = acc + ((size_t)c * nt + t) * n;
+                const u64* ad = add + ((size_t)c * ell + t) * n;
+                for (size_t i = 0; i < n; ++i) a[i] = addmod(a[i], mq_mul(ad[i], pm, &mm), q[t]);
+            }
+        ks_moddown_rescale(&P, acc, out);
+        free(acc); free(add);
+        return;
+    }
     ks_moddown(&P, acc, out);
     free(acc);
     orc_add(out, add, out, ell, log_n, q);

@@ -194,10 +194,11 @@ class ResidueEvaluator:
             acc = t if acc is None else self.add(acc, t)
         return acc
 
-    def hoisted_dot(self, a, encs, indices):
+    def hoisted_dot(self, a, encs, indices, rescale=False):
         """a * V_0 + sum_r rot(a, indices[r]) * V_{r+1} (Evaluator::hoisted_dot_rows, one row): a degree-2 operand is rescaled
         first, the plaintexts are encoded at the level's Delta over the FULL key basis (enc(n_q + n_p, scale)), one ModUp and
-        one ModDown, the plaintext products taken in QP (orc_hoisted_dot)"""
+        one ModDown, the plaintext products taken in QP (orc_hoisted_dot).  rescale: the result rescaled, ModDown and rescale as
+        ONE basis conversion (P and the top limb dropped together)"""
         x = self.rescale(a) if a.deg >= 2 else a
         sf = self.sf[self.level(x)]
         nl = len(self.q) + len(self.p)
@@ -208,7 +209,9 @@ class ResidueEvaluator:
             self._full.clear()
             self._full[k] = np.stack([e(nl, sf) for e in encs])
         d = orc.hoisted_dot(x.d, self._stack(indices), [self._g(r) for r in indices], self._full[k], self.alpha, self.q, self.p,
-                            self.psi_q, self.psi_p)
+                            self.psi_q, self.psi_p, drop=rescale)
+        if rescale:
+            return RCt(d, x.deg, x.scale * sf / LD(int(self.q[x.ell - 1])))
         return RCt(d, x.deg + 1, x.scale * sf)
 
     # ---- ct x ct, real constants, polynomial evaluation (reference :431, :1289-1336; order of csrc/polyeval.cpp)
@@ -493,11 +496,11 @@ class ResidueEvaluator:
     def matmulRElarge(self, rows, v_encs, bias_enc, mask512_enc):
         """composite.cpp matmulRElarge, shared form: U = x * V_0 + sum_{t=1..3} rot(x, 128 t) * V_t (double hoisting: one ModUp, one
         ModDown, the plaintext products in the extended basis), Z = rotsum(U, 32, 512), out = Z * mask[0,512) + bias.  v_encs[t]
-        encodes V_t = rot(W''_t, 128 t) (block b of W''_t = block b of W_((b - t) mod 4)); a degree-2 input is rescaled once and U is
-        rescaled once (by rotsum)"""
+        encodes V_t = rot(W''_t, 128 t) (block b of W''_t = block b of W_((b - t) mod 4)); a degree-2 input is rescaled once and U comes
+        out rescaled (ModDown and rescale in one conversion)"""
         out = []
         for r in rows:
-            u = self.hoisted_dot(r, v_encs, [128, 256, 384])
+            u = self.hoisted_dot(r, v_encs, [128, 256, 384], rescale=True)
             z = self.rotsum(u, 32, 512)
             o = self.mult_plain(z, mask512_enc)
             out.append(self.add_plain(o, bias_enc) if bias_enc is not None else o)

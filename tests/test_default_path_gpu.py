@@ -101,12 +101,15 @@ def test_hoisted_dot_bit_exact(engine_factory, orc, preset, over, ells, idx, row
     encs = [(lambda p: (lambda ell, sc: eng.pt_export(p, ell, sc)))(p) for p in pts]
     for ell in ells:
         pairs = [_imp(eng, rev, _ct(orc, eng, 500 + 7 * i + ell, ell), deg=deg) for i in range(rows)]
-        got = eng.hoisted_dot([p[0] for p in pairs], pts, idx)
-        for (c, r), g in zip(pairs, got):
-            want = rev.hoisted_dot(r, encs, idx)
-            _same(g, want, (preset, ell))
-            hi, lo = g.scale_parts()
-            assert LD(hi) + LD(lo) == want.scale
+        for rescale in (False, True):            # True: ModDown and rescale as one basis conversion (moddown_rescale_*_kernel)
+            if rescale and (ell if deg == 1 else ell - 1) < 2:
+                continue
+            got = eng.hoisted_dot([p[0] for p in pairs], pts, idx, rescale=rescale)
+            for (c, r), g in zip(pairs, got):
+                want = rev.hoisted_dot(r, encs, idx, rescale=rescale)
+                _same(g, want, (preset, ell, rescale))
+                hi, lo = g.scale_parts()
+                assert LD(hi) + LD(lo) == want.scale
     del keys
 
 
@@ -127,6 +130,10 @@ def test_hoisted_dot_is_the_sum_of_rotated_products(fa):
         for x, o in zip(xs, outs):
             want = x * vs[0] + sum(np.roll(x, -r) * vs[k + 1] for k, r in enumerate(idx))
             assert o.info()["deg"] == 2
+            assert np.max(np.abs(eng.decrypt(o)[:ns] - want)) < 1e-6
+        for x, o in zip(xs, eng.hoisted_dot(cts, [eng.encode(v) for v in vs], idx, rescale=True)):     # ModDown + rescale in one conversion
+            want = x * vs[0] + sum(np.roll(x, -r) * vs[k + 1] for k, r in enumerate(idx))
+            assert o.info()["deg"] == 1 and o.info()["ell"] == cts[0].info()["ell"] - 1
             assert np.max(np.abs(eng.decrypt(o)[:ns] - want)) < 1e-6
     finally:
         eng.close()

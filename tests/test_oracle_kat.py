@@ -319,6 +319,43 @@ def test_rotate_each_sum_by_decryption(orc):
     assert max(abs(e) for e in _crt2(d1[0], d1[1], int(q[0]), int(q[1]))) < 2 ** 40
 
 
+@pytest.mark.parametrize("ell", [4, 3])
+def test_hoisted_dot_by_decryption(orc, ell):
+    """double hoisting (plaintext products in the extended basis, one ModUp, one ModDown): decrypts to V_0 m + sum_r V_{r+1} sigma_r(m)
+    up to key-switching noise times the plaintext size; and the variant that drops P and the top limb in ONE conversion equals
+    rescale(that) up to the roundings of the two conversions"""
+    log_n, L1, k, alpha = 12, 4, 2, 2
+    q, p, psi_q, psi_p = _chain(orc, log_n, L1, k)
+    rng = np.random.default_rng(13)
+    n = 1 << log_n
+    rots = [1, 128, -64]
+    s = [int(v) for v in rng.integers(-1, 2, size=n)]
+    evks, gs = _rot_keys(orc, log_n, q, p, psi_q, psi_p, alpha, s, rots, rng)
+    mods, psis = list(q) + list(p), list(psi_q) + list(psi_p)
+    # plaintext polynomials with small integer coefficients, over the full key basis, NTT form
+    vco = [[int(v) for v in rng.integers(-2 ** 10, 2 ** 10, size=n)] for _ in range(len(rots) + 1)]
+    pts = np.stack([orc.ntt_batch(np.array([[c % int(m) for c in v] for m in mods], dtype=np.uint64), mods, psis) for v in vco])
+    ql, pl = q[:ell], psi_q[:ell]
+    ct = np.array([[rng.integers(0, int(m), size=n, dtype=np.uint64) for m in ql] for _ in range(2)])
+    out = orc.hoisted_dot(ct, evks, gs, pts, alpha, q, p, psi_q, psi_p)
+    s_ntt = orc.ntt_batch(np.array([[v % int(m) for v in s] for m in ql], dtype=np.uint64), ql, pl)
+    din = _phase(orc, ct, s_ntt, ql)
+    expect = orc.mul(din, pts[0][:ell], ql)
+    for r, g in enumerate(gs):
+        expect = orc.add(expect, orc.mul(np.array([orc.automorph_ntt(x, g) for x in din]), pts[r + 1][:ell], ql), ql)
+    diff = orc.ntt_batch(orc.sub(_phase(orc, out, s_ntt, ql), expect, ql), ql, pl, inverse=True)
+    assert max(abs(e) for e in _crt2(diff[0], diff[1], int(ql[0]), int(ql[1]))) < 2 ** 62      # noise 2^40 x plaintext 2^10 x sqrt(n) with room
+    # ModDown and rescale as one conversion vs ModDown, then rescale
+    one = orc.hoisted_dot(ct, evks, gs, pts, alpha, q, p, psi_q, psi_p, drop=True)
+    two = orc.rescale(out, ql, pl)
+    assert one.shape == two.shape == (2, ell - 1, n)
+    q1, p1 = ql[:ell - 1], pl[:ell - 1]
+    s1 = s_ntt[:ell - 1]
+    d = orc.ntt_batch(orc.sub(_phase(orc, one, s1, q1), _phase(orc, two, s1, q1), q1), q1, p1, inverse=True)
+    assert max(abs(e) for e in _crt2(d[0], d[1], int(q1[0]), int(q1[1]))) < 2 ** 20           # a few units per coefficient x |s|_1
+    assert not np.array_equal(one, two)                                                      # a different integer function
+
+
 def test_modraise_is_the_centred_lift(orc):
     """ModRaise: every coefficient's centred representative modulo q0, read modulo each q_t (python big ints)"""
     log_n, nl = 12, 4
