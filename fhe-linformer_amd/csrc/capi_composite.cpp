@@ -43,6 +43,10 @@ void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx) {
         CtVec sub;
         for (int i : todo) sub.push_back(g.rows[i]);
         r = c->comp.matmul_pt(sub, g.w, g.bias, g.slots, g.padding);
+    } else if (g.kind == LazyRows::RElarge) {
+        CtVec sub;
+        for (int i : todo) sub.push_back(g.rows[i]);
+        r = c->comp.matmulRElarge(sub, g.weights, g.bias, g.mask_val);
     } else {
         r = c->comp.unwrapExpanded_rows(g.src, g.n, todo);
     }
@@ -334,7 +338,17 @@ int fhelin_fc_matmulRElarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t
         if (!weights[i]) throw Error(FHELIN_ERR_ARG, "null weight");
         w.push_back(weights[i]->p);
     }
-    emit(c, c->comp.matmulRElarge(vec_of(c, rows, n), w, opt(bias), mask_val), outs);
+    if (c->lazy_rows && n >= 1) {      // rows that generate_containers reads next are never evaluated on their own (capi_internal.h)
+        auto g = std::make_shared<LazyRows>();
+        g->kind = LazyRows::RElarge;
+        g->rows = vec_of(c, rows, n);
+        g->weights = w;
+        g->bias = opt(bias);
+        g->mask_val = mask_val;
+        emit_lazy(c, g, n, outs);
+    } else {
+        emit(c, c->comp.matmulRElarge(vec_of(c, rows, n), w, opt(bias), mask_val), outs);
+    }
     FHELIN_CATCH
 }
 int fhelin_fc_matmulCRlarge(fhelin_ctx* c, const fhelin_ct* const* rows, int32_t n, const fhelin_pt* const* weights,
@@ -415,7 +429,32 @@ int fhelin_fc_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs,
                                   fhelin_ct** outs, int32_t* n_out) {
     NEED(c && inputs && outs);
     FHELIN_TRY
-    auto r = c->comp.generate_containers(vec_of(c, inputs, n), opt(bias));
+    // every input an unread row of matmulRElarge with one set of weights: the two calls as one (Composite::relarge_containers)
+    bool fused = n > 0 && c->comp.fuse_relarge;
+    const LazyRows* g0 = nullptr;
+    for (int i = 0; fused && i < n; ++i) {
+        const fhelin_ct* h = inputs[i];
+        if (!h) throw Error(FHELIN_ERR_ARG, "null ciphertext handle in array");
+        const LazyRows* g = (!h->p && !h->heavy && h->lazy) ? h->lazy.get() : nullptr;
+        fused = g && g->kind == LazyRows::RElarge && !g->done[h->lazy_idx] && g->rows.size() == g->done.size();
+        if (!fused) break;
+        if (!g0) g0 = g;
+        fused = g->weights == g0->weights && g->bias == g0->bias && g->mask_val == g0->mask_val;
+    }
+    CtVec r;
+    if (fused) {
+        CtVec x;
+        for (int i = 0; i < n; ++i) {
+            const fhelin_ct* h = inputs[i];
+            x.push_back(h->lazy->rows[h->lazy_idx]);
+            // level plan: the containers consume what the rows of matmulRElarge would have consumed
+            if (c->plan.live(h->node, h->node_epoch))
+                for (int in : c->plan.nodes[h->node].in) plan_inputs().push_back(in);
+        }
+        r = c->comp.relarge_containers(x, g0->weights, g0->bias, g0->mask_val, opt(bias));
+    } else {
+        r = c->comp.generate_containers(vec_of(c, inputs, n), opt(bias));
+    }
     emit(c, r, outs);
     if (n_out) *n_out = (int)r.size();
     FHELIN_CATCH

@@ -106,11 +106,19 @@ struct fhelin_ctx {
 // deferred row of the same call that the consuming operation also takes — and never if nobody reads it.  Rows are
 // independent, so a forced row holds exactly the residues eager evaluation gives (bit-exact tests run with deferral
 // on).  FHELIN_LAZY_ROWS=0 evaluates eagerly.
+// fhelin_fc_matmulRElarge defers its rows too, for another reason: the drivers hand ALL of them to generate_containers next
+// (src/main.cpp:341-352), and the two calls together are one shift sum per 32 rows (Composite::relarge_containers) where each alone
+// is a tree per row and then the container sum.  generate_containers takes the fused form when every input is a row of
+// matmulRElarge that nobody has read (same weights, bias and mask); a row somebody reads first is evaluated as matmulRElarge
+// itself would.  The fused form is a different integer function with the same slot values: it is part of the default path the
+// residue-level oracle restates (oracle/residue_controller.py).
 namespace fhelin {
 struct LazyRows {
-    enum Kind { MatmulPt, UnwrapExpanded } kind = MatmulPt;
-    CtVec rows;                 // MatmulPt: the input rows (kept alive)
+    enum Kind { MatmulPt, UnwrapExpanded, RElarge } kind = MatmulPt;
+    CtVec rows;                 // MatmulPt, RElarge: the input rows (kept alive)
     PtPtr w, bias;
+    std::vector<PtPtr> weights; // RElarge: the four weight blocks; mask value
+    double mask_val = 1.0;
     int slots = 0, padding = 0;
     CtPtr src;                  // UnwrapExpanded: the wrapped ciphertext
     int n = 0;

@@ -18,6 +18,7 @@ Composite::Composite(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {
     if (const char* e = std::getenv("FHELIN_CHEB_ROUNDS")) ev_.cheb_rounds = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_DOT_GROUPS")) ev_.dot_groups = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_DOUBLE_HOIST")) ev_.double_hoist = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FHELIN_FUSE_RELARGE")) fuse_relarge = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_MERGED_RESCALE")) ev_.merged_rescale = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_CHEB_LEAF_AT")) ev_.cheb_leaf_at_product = std::atoi(e) != 0;
     if (const char* b = std::getenv("FHELIN_BATCH")) {
@@ -302,6 +303,141 @@ std::vector<PtPtr> Composite::relarge_weights(const std::vector<PtPtr>& weights,
     return out;
 }
 
+bool Composite::relarge_shared(const CtVec& inputs, const std::vector<PtPtr>& weights) {
+    return merge_rot_ && weights.size() == 4 && num_slots() == 16384 && !inputs.empty() &&
+           ev_.have_rotation_keys({128, 256, 384, 512, 1024, 2048, 4096, 8192}, inputs[0]->slots);
+}
+
+CtVec Composite::relarge_u(const CtVec& inputs, const std::vector<PtPtr>& weights) {
+    // rescale degree-2 inputs once (each product below would otherwise do it again)
+    CtVec x = inputs;
+    {
+        CtVec need;
+        std::vector<size_t> pos;
+        for (size_t i = 0; i < x.size(); ++i)
+            if (x[i]->deg >= 2) {
+                need.push_back(x[i]);
+                pos.push_back(i);
+            }
+        if (!need.empty()) {
+            CtVec r = ev_.rescale_batch(need);
+            for (size_t k = 0; k < pos.size(); ++k) x[pos[k]] = r[k];
+        }
+    }
+    if (ev_.double_hoist) {
+        // U = x * V_0 + sum_{t=1..3} rot(x, 128 t) * V_t with V_t = rot(W''_t, 128 t): the three rotations share ONE ModUp of the row
+        // and the plaintext products are taken in the extended basis (rotation keys with V_t folded in: Evaluator::hoisted_dot_rows),
+        // so a row costs one ModUp and one ModDown where the products-then-rotations form costs three ModUps and one ModDown.
+        // U is wanted rescaled (the tree below runs on degree-1 rows): ModDown and rescale are one basis conversion
+        return ev_.hoisted_dot_rows(x, relarge_weights(weights, true), {128, 256, 384}, ev_.merged_rescale);
+    }
+    const std::vector<PtPtr> w2 = relarge_weights(weights, false);
+    // the four products stay unrescaled through the key switch that sums them: ONE rescale of U (inside rotsum_batch) instead
+    // of four, at the price of running that one key switch a limb higher
+    // the three products of a row that get rotated are produced next to one another (one block, [row][t]): the key switch
+    // takes them where they are
+    CtVec xflat;
+    std::vector<PtPtr> wflat;
+    for (size_t i = 0; i < x.size(); ++i)
+        for (int t = 1; t < 4; ++t) {
+            xflat.push_back(x[i]);
+            wflat.push_back(w2[t]);
+        }
+    const CtVec rotated = ev_.mult_plain_each(xflat, wflat);
+    const CtVec y0 = ev_.mult_plain_batch(x, w2[0]);
+    std::vector<CtVec> rows(x.size(), CtVec(4));
+    for (size_t i = 0; i < x.size(); ++i) {
+        rows[i][0] = y0[i];
+        for (int t = 1; t < 4; ++t) rows[i][t] = rotated[3 * i + (t - 1)];
+    }
+    return ev_.rotate_each_sum_rows(rows, {0, 128, 256, 384});
+}
+
+CtVec Composite::relarge_tail(const CtVec& u, const PtPtr& bias, double mask_val) {
+    CtVec z = rotsum_batch(u, 32, 512);
+    CtVec res = ev_.mult_plain_batch(z, block_mask(0, 512, mask_val));
+    if (bias) res = ev_.add_plain_batch(res, bias);
+    return res;
+}
+
+// One container of generate_containers(matmulRElarge(.)) from the U rows of its q <= 32 tokens:
+//   C = sum_{i<q} rot(Z_i * mask_[0,512) + bias, -512 i),   Z_i = sum_{k<32} rot(U_i, 512 k).
+// Z_i has period 512, so rot(Z_i * mask_[0,512), -512 i) = Z_i * mask_i with mask_i = mask_val on [512 i, 512 i + 512), and
+// mask_i * rot(U_i, 512 k) = rot(mask_{(i + k) mod 32} * U_i, 512 k):
+//   C = sum_{k<32} rot(W_k, 512 k) + sum_{i<q} rot(bias, -512 i),      W_k = sum_{i<q} mask_{(i + k) mod 32} * U_i.
+// 32 plaintext-weighted sums over the q rows (the mask product the tree form has too: same depth) and ONE shift sum of 32 terms -
+// 31 ModUps and 5 ModDowns for the group, where the tree form runs 2 key switches per row and then the container's own shift sum.
+CtPtr Composite::relarge_container(const CtVec& uin, const PtPtr& bias, double mask_val) {
+    const int q = (int)uin.size(), ns = num_slots();
+    CtVec u = uin;
+    {
+        bool any2 = false;
+        for (const CtPtr& c : u) any2 = any2 || c->deg >= 2;
+        if (any2) u = ev_.rescale_batch(u);
+    }
+    std::vector<PtPtr> mask(32);
+    for (int j = 0; j < 32; ++j) mask[j] = block_mask(512 * j, 512 * (j + 1), mask_val);
+    const CtPtr& f = u[0];
+    CtVec w = ev_.new_ct_batch(32, 2, f->ell, f->deg + 1, f->scale, f->slots);
+    const int MG = EwDotGroups::MAX_G;
+    static_assert(EwDotGroups::MAX_A >= 32 && 32 % EwDotGroups::MAX_G == 0, "relarge_container: a group of 32 rows in one pass");
+    // 8 sums per pass over the q rows (every row is read once per pass, every mask q times in all): all 32 land in one block, in order
+    for (int g0 = 0; g0 < 32; g0 += MG) {
+        std::vector<std::vector<PtPtr>> pts(MG, std::vector<PtPtr>(q));
+        for (int g = 0; g < MG; ++g)
+            for (int b = 0; b < q; ++b) pts[g][b] = mask[(b + g0 + g) % 32];
+        CtVec dest(w.begin() + g0, w.begin() + g0 + MG);
+        if (!ev_.dot_plain_groups(u, pts, 0, dest))
+            for (int g = 0; g < MG; ++g) w[g0 + g] = ev_.dot_plain(u, pts[g]);
+    }
+    CtPtr c = shift_sum(w, 512);
+    if (bias) {
+        char key[96];
+        snprintf(key, sizeof key, "relarge_bias:%p:%d", (void*)bias.get(), q);
+        auto it = relarge_cache_.find(key);
+        PtPtr tiled;
+        if (it != relarge_cache_.end()) {
+            tiled = it->second[0];
+        } else {
+            std::vector<double> v(ns, 0.0);
+            for (int i = 0; i < q; ++i)
+                for (int s = 0; s < ns; ++s) {
+                    const double b = s < (int)bias->values.size() ? bias->values[s] : 0.0;
+                    if (b != 0.0) v[(s + 512 * i) % ns] += b;       // rot(bias, -512 i): slot s lands at s + 512 i
+                }
+            tiled = encode_vec(v, bias->level);
+            if (relarge_cache_.size() > 16) relarge_cache_.clear();
+            relarge_cache_[key] = {tiled, bias};      // holds the bias: its address stays its own
+        }
+        c = ev_.add_plain(c, tiled);
+    }
+    return c;
+}
+
+CtVec Composite::relarge_containers(const CtVec& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias, double mask_val, const PtPtr& cbias) {
+    if (!fuse_relarge || !relarge_shared(inputs, weights)) return generate_containers(matmulRElarge(inputs, weights, bias, mask_val), cbias);
+    const CtVec u = relarge_u(inputs, weights);
+    const int total = (int)u.size();
+    CtVec containers;
+    // the groups of generate_containers (:1164-1191): 32 rows each, a shorter last one
+    for (int lo = 0; lo < total; lo += 32) {
+        const int q = std::min(32, total - lo);
+        CtVec ug(u.begin() + lo, u.begin() + lo + q);
+        bool uniform = q >= RELARGE_FUSE_MIN;
+        for (const CtPtr& c : ug)
+            uniform = uniform && c->npoly == 2 && c->ell == ug[0]->ell && c->deg == ug[0]->deg && fabsl(c->scale / ug[0]->scale - 1.0L) < 1e-9L;
+        if (uniform) {
+            containers.push_back(relarge_container(ug, bias, mask_val));
+        } else {
+            CtVec rows = relarge_tail(ug, bias, mask_val);
+            std::reverse(rows.begin(), rows.end());
+            containers.push_back(wrap_containers(rows, q));
+        }
+    }
+    if (cbias) containers = ev_.add_plain_batch(containers, cbias);
+    return containers;
+}
+
 CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias, double mask_val) {
     // per input the reference computes (:915-944) res = sum_j shift_j(mask_first_128(rotsum(x * W_j, 128, 128))) + bias: four
     // 7-step rotate-and-sum trees per input.  What it needs of tree j is ONE block: block j of out = the sum of all 128 blocks
@@ -311,61 +447,8 @@ CtVec Composite::matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& we
     //       "keep blocks = j mod 4" masks folded into the plaintext weights: no extra level);
     //   Z = U + its rotations by 512, 1024, ..., 8192 (5 doubling steps): block j of Z = sum of all blocks of P_j;
     //   out = Z * (mask_val on slots [0, 512)) + bias.
-    // One shared-ModDown key switch of three terms and a 5-step tree instead of four 7-step trees per input.
-    const int ns = num_slots();
-    const bool shared = merge_rot_ && weights.size() == 4 && ns == 16384 && !inputs.empty() &&
-                        ev_.have_rotation_keys({128, 256, 384, 512, 1024, 2048, 4096, 8192}, inputs[0]->slots);
-    if (shared) {
-        // rescale degree-2 inputs once (each product below would otherwise do it again)
-        CtVec x = inputs;
-        {
-            CtVec need;
-            std::vector<size_t> pos;
-            for (size_t i = 0; i < x.size(); ++i)
-                if (x[i]->deg >= 2) {
-                    need.push_back(x[i]);
-                    pos.push_back(i);
-                }
-            if (!need.empty()) {
-                CtVec r = ev_.rescale_batch(need);
-                for (size_t k = 0; k < pos.size(); ++k) x[pos[k]] = r[k];
-            }
-        }
-        CtVec u;
-        if (ev_.double_hoist) {
-            // U = x * V_0 + sum_{t=1..3} rot(x, 128 t) * V_t with V_t = rot(W''_t, 128 t): the three rotations share ONE ModUp of the row
-            // and the plaintext products are taken in the extended basis (rotation keys with V_t folded in: Evaluator::hoisted_dot_rows),
-            // so a row costs one ModUp and one ModDown where the products-then-rotations form costs three ModUps and one ModDown
-            // U is wanted rescaled (the tree below runs on degree-1 rows): ModDown and rescale are one basis conversion
-            u = ev_.hoisted_dot_rows(x, relarge_weights(weights, true), {128, 256, 384}, ev_.merged_rescale);
-        } else {
-            const std::vector<PtPtr> w2 = relarge_weights(weights, false);
-            std::vector<CtVec> y(4);
-            // the four products stay unrescaled through the key switch that sums them: ONE rescale of U (inside rotsum_batch) instead
-            // of four, at the price of running that one key switch a limb higher
-            // the three products of a row that get rotated are produced next to one another (one block, [row][t]): the key switch
-            // takes them where they are
-            CtVec xflat;
-            std::vector<PtPtr> wflat;
-            for (size_t i = 0; i < x.size(); ++i)
-                for (int t = 1; t < 4; ++t) {
-                    xflat.push_back(x[i]);
-                    wflat.push_back(w2[t]);
-                }
-            const CtVec rotated = ev_.mult_plain_each(xflat, wflat);
-            y[0] = ev_.mult_plain_batch(x, w2[0]);
-            std::vector<CtVec> rows(x.size(), CtVec(4));
-            for (size_t i = 0; i < x.size(); ++i) {
-                rows[i][0] = y[0][i];
-                for (int t = 1; t < 4; ++t) rows[i][t] = rotated[3 * i + (t - 1)];
-            }
-            u = ev_.rotate_each_sum_rows(rows, {0, 128, 256, 384});
-        }
-        CtVec z = rotsum_batch(u, 32, 512);
-        CtVec res = ev_.mult_plain_batch(z, block_mask(0, 512, mask_val));
-        if (bias) res = ev_.add_plain_batch(res, bias);
-        return res;
-    }
+    // One key switch over three rotations (relarge_u) and a 5-step tree instead of four 7-step trees per input.
+    if (relarge_shared(inputs, weights)) return relarge_tail(relarge_u(inputs, weights), bias, mask_val);
     // the reference's formulation: one tree per weight block; a rotsum(., 128, 128) output repeats with period 128, so masking
     // block j directly selects what "mask the first block, then shift it" does (FHELIN_MERGE_ROT=0: the reference's shifts)
     CtVec res(inputs.size());

@@ -70,6 +70,13 @@ public:
     // tokens [first, first + count) only (count < 0: all)
     std::vector<CtVec> unwrapRepeatedLarge(const CtVec& containers, int input_number, int first = 0, int count = -1);
     CtVec generate_containers(const CtVec& inputs, const PtPtr& bias);
+    // generate_containers(matmulRElarge(inputs, weights, bias, mask_val), cbias) in one go, for rows of matmulRElarge nobody has read
+    // yet (the C ABI defers them: capi_composite.cpp): the 5-step tree of every row and the container sum collapse into ONE shift sum
+    // per group of 32 rows (relarge_container).  Same slot values, a different integer function (oracle/residue_controller.py
+    // restates it); groups of fewer than RELARGE_FUSE_MIN rows and contexts without the shared form take the two calls as they stand.
+    CtVec relarge_containers(const CtVec& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias, double mask_val, const PtPtr& cbias);
+    static constexpr int RELARGE_FUSE_MIN = 8;
+    bool fuse_relarge = true;   // FHELIN_FUSE_RELARGE=0: never
     CtPtr wrap_containers(const CtVec& c, int inputs_number);
 
 private:
@@ -79,6 +86,10 @@ private:
     // matmulRElarge: the four 128x128 weight blocks re-arranged block-wise (W''_t, t = 0..3), cached per weight set
     std::map<std::string, std::vector<PtPtr>> relarge_cache_;
     std::vector<PtPtr> relarge_weights(const std::vector<PtPtr>& weights, bool rotated);
+    bool relarge_shared(const CtVec& inputs, const std::vector<PtPtr>& weights);
+    CtVec relarge_u(const CtVec& inputs, const std::vector<PtPtr>& weights);        // the shared form's first step: U per row
+    CtVec relarge_tail(const CtVec& u, const PtPtr& bias, double mask_val);          // its 5-step tree, mask and bias
+    CtPtr relarge_container(const CtVec& u, const PtPtr& bias, double mask_val);     // tree + container sum of one group of rows
     bool early_rescale_ = true;   // FHELIN_EARLY_RESCALE: rescale a fresh product before its rotation tree
     bool merge_rot_ = true;       // FHELIN_MERGE_ROT: two tree steps as one merged key switch when the 3s key exists
     bool row_lanes_ = false;      // FHELIN_ROW_LANES: row chunks of a tree on separate streams (off: measured slower)

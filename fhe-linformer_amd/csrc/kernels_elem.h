@@ -66,7 +66,7 @@ void launch_ew_dot(const DeviceTables& t, u64* out, const EwItems& it, int limb_
 // giant step).  a_b: [2][ell][N]; p_{g,b}: [ell][N] or nullptr (term absent); out_g: [2][ell][N].  Same 128-bit accumulation and
 // single reduction per output as launch_ew_dot: identical residues.
 struct EwDotGroups {
-    static constexpr int MAX_A = 16, MAX_G = 8;
+    static constexpr int MAX_A = 32, MAX_G = 8;
     int na = 0, ng = 0, ell = 0;
     const u64* a[MAX_A];
     const u64* p[MAX_G][MAX_A];

@@ -393,8 +393,10 @@ void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& d, hipStream
     if (d.na <= 0 || d.ng <= 0 || d.ell <= 0) return;
     if (d.na <= 8)
         hipLaunchKernelGGL((ew_dot_groups_kernel<8>), grid2(t.log_n, 2 * d.ell), dim3(256), 0, s, t, d);
-    else
+    else if (d.na <= 16)
         hipLaunchKernelGGL((ew_dot_groups_kernel<16>), grid2(t.log_n, 2 * d.ell), dim3(256), 0, s, t, d);
+    else
+        hipLaunchKernelGGL((ew_dot_groups_kernel<32>), grid2(t.log_n, 2 * d.ell), dim3(256), 0, s, t, d);
 }
 void launch_ew_mul(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s) {
     if (nvec <= 0) return;

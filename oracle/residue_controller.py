@@ -84,10 +84,38 @@ class _LazyRows(list):
         return (self._get(i) for i in range(len(self)))
 
     def __add__(self, other):
+        if getattr(self, "relarge", None) is not None and getattr(other, "relarge", None) is not None:
+            return _RelargeConcat([self, other])        # output_0 + output_1 of the driver: still nobody has read a row
         return list(self) + list(other)
 
     def __radd__(self, other):
         return list(other) + list(self)
+
+
+class _RelargeConcat(list):
+    """rows of several matmulRElarge calls in a row, unread (linformer.py: outputs_raw = output_0 + output_1)"""
+
+    def __init__(self, lists):
+        super().__init__()
+        self.relarge_lists = lists
+        self.relarge_parts = [lz.relarge for lz in lists]
+        for lz in lists:
+            list.extend(self, [None] * len(lz))
+
+    def _get(self, i):
+        for lz in self.relarge_lists:
+            if i < len(lz):
+                return lz[i]
+            i -= len(lz)
+        raise IndexError(i)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._get(k) for k in range(*i.indices(len(self)))]
+        return self._get(i if i >= 0 else i + len(self))
+
+    def __iter__(self):
+        return (self._get(i) for i in range(len(self)))
 
 
 class ResidueController:
@@ -194,18 +222,27 @@ class ResidueController:
     def matmulCR(self, rows, w, bias=None):
         return self._matmul_pt(rows, w, bias, 128, 1)
 
-    def matmulRElarge(self, rows, weights, bias, mask_val=1.0):
-        if getattr(self, "_relarge_for", None) is not weights[0]:       # a call's four V_t, kept while the same weights come back (row subsets)
+    def _relarge_v(self, weights):
+        if getattr(self, "_relarge_for", None) is not weights[0]:       # a call's four V_t, kept while the same weights come back
             w2 = []
             for t in range(4):                                 # Composite::relarge_weights: block b of W''_t = block b of W_((b - t) mod 4),
                 v = np.zeros(SLOTS)                            # V_t = rot(W''_t, 128 t)
                 for b in range(128):
                     v[128 * b:128 * (b + 1)] = weights[(b - t) % 4].values[128 * b:128 * (b + 1)]
                 w2.append(RPt(self.eng, np.roll(v, -128 * t), weights[0].level).enc)
-            self._relarge_for, self._relarge_v = weights[0], w2
-        w2 = self._relarge_v
+            self._relarge_for, self._relarge_vt = weights[0], w2
+        return self._relarge_vt
+
+    def matmulRElarge(self, rows, weights, bias, mask_val=1.0):
+        """rows that nobody has read when generate_containers takes them are never evaluated on their own (the C ABI defers them the
+        same way: csrc/capi_internal.h); a row that is read is Composite::matmulRElarge"""
+        v = self._relarge_v(weights)
         m512 = self._block_mask(0, 512, mask_val).enc
-        return self.rev.matmulRElarge(list(rows), w2, bias.enc if bias is not None else None, m512)
+        rows = list(rows)
+        rev, benc = self.rev, (bias.enc if bias is not None else None)
+        out = _LazyRows(len(rows), lambda i: rev.matmulRElarge([rows[i]], v, benc, m512)[0])
+        out.relarge = (rows, weights, bias, mask_val)
+        return out
 
     def matmulCRlarge(self, rows, weights, bias):
         """:998-1026: per row sum_j r[j] * W_j as (p0 + p1) + (p2 + p3), one rotsum(128, 1), + bias"""
@@ -245,7 +282,41 @@ class ResidueController:
         return self.rev.unwrapRepeatedLarge(list(cs), n, lambda v: self._mask(v).enc)
 
     def generate_containers(self, inputs, bias=None):
-        """:1164-1191: groups of 32 inputs, sum_i rot(group[i], -512 i) each"""
+        """:1164-1191: groups of 32 inputs, sum_i rot(group[i], -512 i) each.  Inputs that are unread rows of matmulRElarge (one set of
+        weights) take Composite::relarge_containers: per group of >= 8 rows the trees of the rows and the container sum are one
+        shift sum (ResidueEvaluator.relarge_container)"""
+        lists = getattr(inputs, "relarge_lists", None)
+        if lists is None and getattr(inputs, "relarge", None) is not None:
+            lists = [inputs]
+        parts = [lz.relarge for lz in lists] if lists else None
+        same = parts is not None and all(p[1] is parts[0][1] and p[2] is parts[0][2] and p[3] == parts[0][3] for p in parts)
+        if same and all(list.__getitem__(lz, i) is None for lz in lists for i in range(len(lz))) and sum(len(lz) for lz in lists) > 0:
+            rows = [r for p in parts for r in p[0]]
+            _, weights, rbias, mask_val = parts[0]
+            v = self._relarge_v(weights)
+            us = [self.rev.relarge_u(r, v) for r in rows]
+            masks = [self._block_mask(512 * j, 512 * (j + 1), mask_val).enc for j in range(32)]
+            m512 = self._block_mask(0, 512, mask_val).enc
+            out = []
+            for lo in range(0, len(us), 32):
+                ug = us[lo:lo + 32]
+                q = len(ug)
+                if q >= 8:
+                    tiled = None
+                    if rbias is not None:
+                        tv = np.zeros(SLOTS)
+                        for i in range(q):
+                            tv += np.roll(rbias.values, 512 * i)
+                        tiled = RPt(self.eng, tv, rbias.level).enc
+                    part = self.rev.relarge_container(ug, masks, tiled)
+                else:
+                    tail = []
+                    for u in ug:
+                        o = self.rev.mult_plain(self.rev.rotsum(u, 32, 512), m512)
+                        tail.append(self.rev.add_plain(o, rbias.enc) if rbias is not None else o)
+                    part = self.rev.wrap_containers(list(reversed(tail)), q)
+                out.append(self.rev.add_plain(part, bias.enc) if bias is not None else part)
+            return out
         inputs = list(inputs)
         total, out = len(inputs), []
         i = 0

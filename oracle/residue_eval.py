@@ -493,18 +493,42 @@ class ResidueEvaluator:
             out = [self.add_plain(o, bias_enc) for o in out]
         return out
 
+    def relarge_u(self, row, v_encs):
+        """composite.cpp relarge_u: U = x * V_0 + sum_{t=1..3} rot(x, 128 t) * V_t (double hoisting: one ModUp, the plaintext products in
+        the extended basis, ModDown and rescale as one conversion); v_encs[t] encodes V_t = rot(W''_t, 128 t) (block b of W''_t =
+        block b of W_((b - t) mod 4)); a degree-2 input is rescaled first"""
+        return self.hoisted_dot(row, v_encs, [128, 256, 384], rescale=True)
+
     def matmulRElarge(self, rows, v_encs, bias_enc, mask512_enc):
-        """composite.cpp matmulRElarge, shared form: U = x * V_0 + sum_{t=1..3} rot(x, 128 t) * V_t (double hoisting: one ModUp, one
-        ModDown, the plaintext products in the extended basis), Z = rotsum(U, 32, 512), out = Z * mask[0,512) + bias.  v_encs[t]
-        encodes V_t = rot(W''_t, 128 t) (block b of W''_t = block b of W_((b - t) mod 4)); a degree-2 input is rescaled once and U comes
-        out rescaled (ModDown and rescale in one conversion)"""
+        """composite.cpp matmulRElarge, shared form: U (relarge_u), Z = rotsum(U, 32, 512), out = Z * mask[0,512) + bias"""
         out = []
         for r in rows:
-            u = self.hoisted_dot(r, v_encs, [128, 256, 384], rescale=True)
-            z = self.rotsum(u, 32, 512)
+            z = self.rotsum(self.relarge_u(r, v_encs), 32, 512)
             o = self.mult_plain(z, mask512_enc)
             out.append(self.add_plain(o, bias_enc) if bias_enc is not None else o)
         return out
+
+    def relarge_container(self, us, mask_encs, bias_tiled_enc):
+        """composite.cpp relarge_container: one container of generate_containers(matmulRElarge(.)) from the U rows of its q <= 32
+        tokens: W_k = sum_i mask_((i + k) mod 32) * U_i for k < 32 (exact sums of dyadic products, noise degree 2), C = sum_k
+        rot(W_k, 512 k) (shift_sum), + the bias of the q tokens tiled at their 512-slot blocks.  mask_encs[j] encodes the mask
+        value on slots [512 j, 512 j + 512)."""
+        x0 = us[0]
+        sf = self.sf[self.level(x0)]
+        ql = self.q[:x0.ell]
+        encs = [m(x0.ell, sf) for m in mask_encs]
+        w = []
+        for k in range(32):
+            acc = None
+            for i, u in enumerate(us):
+                e = encs[(i + k) % 32]
+                if acc is None:
+                    acc = np.stack([orc.mul(u.d[c], e, ql) for c in range(2)])
+                else:
+                    acc = np.stack([orc.muladd(acc[c], u.d[c], e, ql) for c in range(2)])
+            w.append(RCt(acc, x0.deg + 1, x0.scale * sf))
+        c = self.shift_sum(w, 512)
+        return self.add_plain(c, bias_tiled_enc) if bias_tiled_enc is not None else c
 
     def unwrapRepeatedLarge(self, containers, n_tokens, enc_of_values):
         """composite.cpp unwrapRepeatedLarge (two-stage shared form): per container, block k and range a (8 tokens = 4096
