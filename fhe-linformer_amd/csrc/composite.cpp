@@ -379,16 +379,13 @@ CtPtr Composite::relarge_container(const CtVec& uin, const PtPtr& bias, double m
     for (int j = 0; j < 32; ++j) mask[j] = block_mask(512 * j, 512 * (j + 1), mask_val);
     const CtPtr& f = u[0];
     CtVec w = ev_.new_ct_batch(32, 2, f->ell, f->deg + 1, f->scale, f->slots);
-    const int MG = EwDotGroups::MAX_G;
-    static_assert(EwDotGroups::MAX_A >= 32 && 32 % EwDotGroups::MAX_G == 0, "relarge_container: a group of 32 rows in one pass");
-    // 8 sums per pass over the q rows (every row is read once per pass, every mask q times in all): all 32 land in one block, in order
-    for (int g0 = 0; g0 < 32; g0 += MG) {
-        std::vector<std::vector<PtPtr>> pts(MG, std::vector<PtPtr>(q));
-        for (int g = 0; g < MG; ++g)
-            for (int b = 0; b < q; ++b) pts[g][b] = mask[(b + g0 + g) % 32];
-        CtVec dest(w.begin() + g0, w.begin() + g0 + MG);
-        if (!ev_.dot_plain_groups(u, pts, 0, dest))
-            for (int g = 0; g < MG; ++g) w[g0 + g] = ev_.dot_plain(u, pts[g]);
+    // all 32 sums in one pass over the rows (every operand read once), landing in one block in order
+    if (!ev_.dot_plain_cyclic(u, mask, w)) {
+        for (int k = 0; k < 32; ++k) {
+            std::vector<PtPtr> pk(q);
+            for (int b = 0; b < q; ++b) pk[b] = mask[(b + k) % 32];
+            w[k] = ev_.dot_plain(u, pk);
+        }
     }
     CtPtr c = shift_sum(w, 512);
     if (bias) {

@@ -1239,6 +1239,35 @@ bool Evaluator::dot_plain_groups(const std::vector<CtPtr>& cts, const std::vecto
     return true;
 }
 
+bool Evaluator::dot_plain_cyclic(const std::vector<CtPtr>& cts, const std::vector<PtPtr>& pts, const std::vector<CtPtr>& dest) {
+    constexpr int P = EwCyclic::PERIOD;
+    if (cts.empty() || (int)cts.size() > P || (int)pts.size() != P || (int)dest.size() != P) return false;
+    const CtPtr& f = cts[0];
+    for (const CtPtr& c : cts)
+        if (c->npoly != 2 || c->deg != 1 || c->ell != f->ell || fabsl(c->scale / f->scale - 1.0L) > 1e-9L) return false;
+    for (const CtPtr& o : dest)
+        if (!o || o->npoly != 2 || o->ell != f->ell) return false;
+    const long double sf = c_.sf_real[f->level()];
+    EwCyclic d;
+    d.n = (int)cts.size();
+    d.ell = f->ell;
+    std::vector<std::shared_ptr<Encoding>> hold;
+    for (int j = 0; j < P; ++j) {
+        hold.push_back(pts[j]->at(f->ell, sf));
+        d.m[j] = hold.back()->d;
+        d.a[j] = j < d.n ? cts[j]->d : nullptr;
+        d.out[j] = dest[j]->d;
+        dest[j]->deg = f->deg + 1;
+        dest[j]->scale = f->scale * sf;
+        dest[j]->slots = f->slots;
+    }
+    launch_ew_cyclic_dot(c_.dt, d, c_.stream);
+    launch_ok("dot_plain_cyclic");
+    c_.stats.ct_pt_mult += (u64)P * d.n;
+    c_.stats.ct_pt_limbs += (u64)P * d.n * (u64)f->ell;
+    return true;
+}
+
 std::vector<CtPtr> Evaluator::add_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 1); }
 std::vector<CtPtr> Evaluator::sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 2); }
 

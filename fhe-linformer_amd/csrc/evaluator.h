@@ -177,6 +177,9 @@ public:
     // (deg+1, scale x plaintext scale); false if the operands do not fit the kernel (caller falls back to dot_plain per g)
     bool dot_plain_groups(const std::vector<CtPtr>& cts, const std::vector<std::vector<PtPtr>>& pts, long double pt_scale,
                           const std::vector<CtPtr>& dest);
+    // the 32 cyclic sums out_k = sum_i cts[i] * pts[(i + k) mod 32] over <= 32 ciphertexts of one shape (degree 1) in one pass
+    // (kernels_elem.h launch_ew_cyclic_dot), written to dest[k]; the residues of dot_plain per k.  false: operands do not fit
+    bool dot_plain_cyclic(const std::vector<CtPtr>& cts, const std::vector<PtPtr>& pts, const std::vector<CtPtr>& dest);
     CtPtr dot_plain(const std::vector<CtPtr>& v, const std::vector<PtPtr>& p, long double pt_scale = 0,
                     const CtPtr& dest = CtPtr());   // pt_scale > 0: encode the plaintexts at this scale instead of the level's own;
                                                     // dest: write the sum there (a slice of a caller's batch block)

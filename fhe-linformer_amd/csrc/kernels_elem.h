@@ -66,13 +66,26 @@ void launch_ew_dot(const DeviceTables& t, u64* out, const EwItems& it, int limb_
 // giant step).  a_b: [2][ell][N]; p_{g,b}: [ell][N] or nullptr (term absent); out_g: [2][ell][N].  Same 128-bit accumulation and
 // single reduction per output as launch_ew_dot: identical residues.
 struct EwDotGroups {
-    static constexpr int MAX_A = 32, MAX_G = 8;
+    static constexpr int MAX_A = 16, MAX_G = 8;
     int na = 0, ng = 0, ell = 0;
     const u64* a[MAX_A];
     const u64* p[MAX_G][MAX_A];
     u64* out[MAX_G];
 };
 void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& d, hipStream_t s);
+// The 32 CYCLIC plaintext-weighted sums over n <= 32 ciphertexts of one shape (Composite::relarge_container):
+//     out_k = sum_{i<n} a_i * m_{(i + k) mod 32},   k < 32        a_i, out_k: [2][ell][N];  m_j: [ell][N]
+// in ONE pass: a workgroup keeps the 32 plaintext values of its 256 coefficients in LDS (a dynamically indexed register file: every
+// thread reads its own column) and the n ciphertext values of both components in registers, pre-split in 30-bit halves; every
+// operand is read from memory once.  Exact sums (128-bit accumulation, folded every 16 products): the canonical residues of the sum.
+struct EwCyclic {
+    static constexpr int PERIOD = 32;
+    int n = 0, ell = 0;
+    const u64* a[PERIOD];
+    const u64* m[PERIOD];
+    u64* out[PERIOD];
+};
+void launch_ew_cyclic_dot(const DeviceTables& t, const EwCyclic& d, hipStream_t s);
 
 struct KsShape {
     int ell;     // live Q limbs

@@ -132,6 +132,44 @@ __global__ __launch_bounds__(256) void ew_dot_groups_kernel(DeviceTables t, EwDo
     }
 }
 
+// grid (N/256, ell, 2 components): one coefficient per thread
+__global__ __launch_bounds__(256) void ew_cyclic_dot_kernel(DeviceTables t, EwCyclic d) {
+    constexpr int P = EwCyclic::PERIOD;
+    __shared__ u64 ml[P][256];                       // pack30(m_j[n]): low 30 bits | next 30 bits << 32
+    const int tt = blockIdx.y;
+    const Barrett br = load_barrett(t, tt);
+    const size_t N = (size_t)1 << t.log_n;
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t om = (size_t)tt * N + n, oc = (size_t)(blockIdx.z * d.ell + tt) * N + n;
+#pragma unroll
+    for (int j = 0; j < P; ++j) ml[j][threadIdx.x] = pack30(d.m[j][om]);
+    u64 a[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) a[i] = i < d.n ? pack30(d.a[i][oc]) : 0;
+    // every thread reads only its own column of ml: no barrier needed (a thread sees its own LDS writes in program order)
+#pragma unroll 1
+    for (int k = 0; k < P; ++k) {
+        u64 lo = 0, hi = 0;
+#pragma unroll
+        for (int i0 = 0; i0 < P; i0 += 8) {
+            if (i0 < d.n) {
+                Acc30 x = {0, 0, 0};
+#pragma unroll
+                for (int i = i0; i < i0 + 8; ++i) {
+                    const u64 w = ml[(i + k) & (P - 1)][threadIdx.x];
+                    mac30(x, (u32)a[i], (u32)(a[i] >> 32), (u32)w, (u32)(w >> 32));
+                }
+                acc30_flush(x, lo, hi);
+                if (i0 == 8) {   // 16 products so far: fold, so that the final 128-bit value stays below q * 2^64 for 60-bit limbs too
+                    lo = barrett_reduce128(lo, hi, br);
+                    hi = 0;
+                }
+            }
+        }
+        d.out[k][oc] = barrett_reduce128(lo, hi, br);
+    }
+}
+
 // out[v] = acc[v] + a[v] * b[v % b_mod]
 __global__ __launch_bounds__(256) void ew_muladd_kernel(DeviceTables t, u64* out, const u64* acc, const u64* a, const u64* b,
                                                         int b_mod, int limb_first, int limb_count) {
@@ -393,10 +431,12 @@ void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& d, hipStream
     if (d.na <= 0 || d.ng <= 0 || d.ell <= 0) return;
     if (d.na <= 8)
         hipLaunchKernelGGL((ew_dot_groups_kernel<8>), grid2(t.log_n, 2 * d.ell), dim3(256), 0, s, t, d);
-    else if (d.na <= 16)
-        hipLaunchKernelGGL((ew_dot_groups_kernel<16>), grid2(t.log_n, 2 * d.ell), dim3(256), 0, s, t, d);
     else
-        hipLaunchKernelGGL((ew_dot_groups_kernel<32>), grid2(t.log_n, 2 * d.ell), dim3(256), 0, s, t, d);
+        hipLaunchKernelGGL((ew_dot_groups_kernel<16>), grid2(t.log_n, 2 * d.ell), dim3(256), 0, s, t, d);
+}
+void launch_ew_cyclic_dot(const DeviceTables& t, const EwCyclic& d, hipStream_t s) {
+    if (d.n <= 0 || d.ell <= 0) return;
+    hipLaunchKernelGGL(ew_cyclic_dot_kernel, dim3((1u << t.log_n) / 256, (unsigned)d.ell, 2), dim3(256), 0, s, t, d);
 }
 void launch_ew_mul(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s) {
     if (nvec <= 0) return;

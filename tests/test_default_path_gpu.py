@@ -323,11 +323,13 @@ def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
         for u in (128, 512, 2048):
             need.update((u, 2 * u, 3 * u))
         need.update((8192, 1024, 4096, 12288))                      # rotsum(128,128); matmulRElarge's 5-step tree by 512 (pairs: no 5s/7s keys here)
-        need.update((1536, 3072, 6144))
+        need.update((1536, 3072, 6144, 2560, 3584))                 # ... and the radix-8 shift sum by 512 of the fused containers
         for u in (-1, -4, -16):
             need.update((u, 2 * u, 3 * u))
         need.update((-64, 1, 2, -512, -1024, -2048))                # repeat(128,1), fans, wrap_containers
+        need.update((-1536, -2560, -3072, -3584))                   # ... of 9 degree-2 rows: the radix-8 shift sum by -512, as in the forward pass
         keys = _keys(orc, eng, sorted(need), seed=100)
+        keys[-4096] = keys[12288]                                   # one Galois element (16384 slots): the engine holds one key for both
         rev = _rev(orc, eng, keys)
         ns, rng = 16384, np.random.default_rng(9)
         pt = lambda v: eng.encode(v)
@@ -347,7 +349,8 @@ def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
         # matmulRElarge (four weight blocks, shared form): W''_t block-wise re-arranged weights, mask value 0.5 on [0, 512), bias
         wv = [rng.uniform(-1, 1, ns) / 8 for _ in range(4)]
         ws = [pt(v) for v in wv]
-        bias = pt(rng.uniform(-1, 1, ns))
+        bias_values = rng.uniform(-1, 1, ns)
+        bias = pt(bias_values)
         w2 = []
         for t in range(4):
             v = np.zeros(ns)
@@ -361,6 +364,29 @@ def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
         want = rev.matmulRElarge([c[1] for c in rows], w2, enc_of(bias), enc_of(pt(m512)))
         for o, r in zip(outs, want):
             _same(o, r, "matmulRElarge")
+        # generate_containers over UNREAD rows of matmulRElarge: the trees of the rows and the container sum as one shift sum of 32
+        # cyclic plaintext-weighted sums (Composite::relarge_container, ew_cyclic_dot_kernel); 9 rows = one fused group
+        rows9 = [_imp(eng, rev, _ct(orc, eng, 900 + i, ell)) for i in range(9)]
+        lazy = eng.matmulRElarge([c[0] for c in rows9], ws, bias, 0.5)
+        got = eng.generate_containers(lazy)
+        assert len(got) == 1
+        masks = []
+        for j in range(32):
+            m = np.zeros(ns)
+            m[512 * j:512 * (j + 1)] = 0.5
+            masks.append(enc_of(pt(m)))
+        tiled = np.zeros(ns)
+        for i in range(9):
+            tiled += np.roll(bias_values, 512 * i)
+        us = [rev.relarge_u(c[1], w2) for c in rows9]
+        _same(got[0], rev.relarge_container(us, masks, enc_of(pt(tiled))), "fused containers")
+        # a row that IS read first is matmulRElarge's own (and the container then takes the evaluated rows the old way)
+        lazy2 = eng.matmulRElarge([c[0] for c in rows9], ws, bias, 0.5)
+        _same(lazy2[3], rev.matmulRElarge([rows9[3][1]], w2, enc_of(bias), enc_of(pt(m512)))[0], "a read row")
+        full = rev.matmulRElarge([c[1] for c in rows9], w2, enc_of(bias), enc_of(pt(m512)))
+        for i in (0, 8):
+            _same(lazy2[i], full[i], ("row read after another", i))
+        _same(eng.generate_containers(lazy2)[0], rev.wrap_containers(list(reversed(full)), 9), "containers of evaluated rows")
     finally:
         eng.close()
 
