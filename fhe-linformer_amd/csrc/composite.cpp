@@ -19,6 +19,7 @@ Composite::Composite(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {
     if (const char* e = std::getenv("FHELIN_DOT_GROUPS")) ev_.dot_groups = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_DOUBLE_HOIST")) ev_.double_hoist = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_FUSE_RELARGE")) fuse_relarge = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FHELIN_BULK_UNWRAP")) bulk_unwrap = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_MERGED_RESCALE")) ev_.merged_rescale = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_CHEB_LEAF_AT")) ev_.cheb_leaf_at_product = std::atoi(e) != 0;
     if (const char* b = std::getenv("FHELIN_BATCH")) {
@@ -662,12 +663,60 @@ CtPtr Composite::wrapUpExpanded(const CtVec& v) {
 CtVec Composite::unwrapExpanded(CtPtr c, int n) {
     // :1089-1097 masks rot(c, i) for i = 0..n-1 (there: n-1 dependent rotations by 1); the `repeat` of every extracted
     // token is independent
-    return repeat_batch(ev_.mult_plain_batch(shift_fan(c, n, 1), mod_n_mask(128, 0)), 128, 1);
+    std::vector<int> all(std::max(n, 0));
+    for (int i = 0; i < n; ++i) all[i] = i;
+    return unwrapExpanded_rows(c, n, all);
 }
 
 CtVec Composite::unwrapExpanded_rows(CtPtr c, int n, const std::vector<int>& idx) {
+    if (bulk_unwrap && merge_rot_ && (int)idx.size() >= UNWRAP_BULK_MIN && n <= 128 && num_slots() % 128 == 0) {
+        std::vector<int> need;
+        for (int k = 1; k < 8; ++k) need.push_back(-k), need.push_back(-8 * k);
+        need.push_back(-64);
+        if (ev_.have_rotation_keys(need, c->slots)) return unwrapExpanded_bulk(c, n, idx);
+    }
     // row i of the fan is the same composition whichever rows are asked for (shift_fan_rows)
     return repeat_batch(ev_.mult_plain_batch(shift_fan_rows(c, n, 1, idx), mod_n_mask(128, 0)), 128, 1);
+}
+
+CtVec Composite::unwrapExpanded_bulk(CtPtr c, int n, const std::vector<int>& idx) {
+    for (int i : idx)
+        if (i < 0 || i >= n) throw Error(FHELIN_ERR_ARG, "unwrapExpanded: row out of range");
+    if (c->deg >= 2) c = ev_.rescale(c);
+    const int imin = *std::min_element(idx.begin(), idx.end()), imax = *std::max_element(idx.begin(), idx.end());
+    // D_j = rot(c, j) for j in [imin - 127, imax]: the fan of the call for j >= 0, the fan by -1 (128 rows) for j < 0
+    std::vector<int> pj, nj;
+    for (int j = 0; j <= imax; ++j) pj.push_back(j);
+    for (int j = 1; j <= 127 - imin; ++j) nj.push_back(j);
+    const CtVec pos = shift_fan_rows(c, n, 1, pj);
+    const CtVec neg = nj.empty() ? CtVec() : shift_fan_rows(c, 128, -1, nj);
+    auto D = [&](int d) -> CtPtr {
+        if (d >= 0) return d <= imax ? pos[d] : CtPtr();
+        return -d <= 127 - imin ? neg[-d - 1] : CtPtr();
+    };
+    std::vector<PtPtr> mask(128);
+    for (int k = 0; k < 128; ++k) mask[k] = mod_n_mask(128, k);
+    CtVec out(idx.size());
+    std::vector<char> block_wanted(4, 0);
+    for (int i : idx) block_wanted[i / 32] = 1;
+    for (int g = 0; g < 4; ++g) {
+        if (!block_wanted[g]) continue;
+        // x_i = sum_{k<128} mask_k * D_{i-k} for the 32 rows i = 32 g + t: four tap chunks of 32, accumulated in place
+        CtVec dest = ev_.new_ct_batch(32, 2, c->ell, c->deg + 1, c->scale, c->slots);
+        for (int ch = 0; ch < 4; ++ch) {
+            const int p = 32 * g - 32 * ch;
+            CtVec cur(32), prev(32);
+            for (int j = 0; j < 32; ++j) {
+                cur[j] = D(p + j);
+                prev[j] = p - 32 + j >= -127 ? D(p - 32 + j) : CtPtr();
+            }
+            const std::vector<PtPtr> m(mask.begin() + 32 * ch, mask.begin() + 32 * ch + 32);
+            if (!ev_.dot_plain_window(cur, prev, m, dest, ch > 0)) throw Error(FHELIN_ERR_INTERNAL, "unwrapExpanded_bulk: window operands");
+        }
+        for (size_t r = 0; r < idx.size(); ++r)
+            if (idx[r] / 32 == g) out[r] = dest[idx[r] % 32];
+    }
+    return out;
 }
 
 CtVec Composite::unwrapScoresExpanded(CtPtr c, int n) {

@@ -77,6 +77,13 @@ public:
     CtVec relarge_containers(const CtVec& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias, double mask_val, const PtPtr& cbias);
     static constexpr int RELARGE_FUSE_MIN = 8;
     bool fuse_relarge = true;   // FHELIN_FUSE_RELARGE=0: never
+    // unwrapExpanded for MANY rows of one call at once (>= UNWRAP_BULK_MIN rows read together): row i = repeat(mask_0 * rot(c, i), 128, 1)
+    // = sum_{k<128} mask_k * rot(c, i - k)  (mask_k: slots = k mod 128): the rotations rot(c, j), -127 <= j < n, are hoisted fans shared
+    // by all rows, and every row is a plaintext-weighted sliding-window sum of them (Evaluator::dot_plain_window) - no key switch per row
+    // where the tree form runs three.  Same slot values, a different integer function (oracle/residue_eval.py unwrapExpanded_bulk).
+    CtVec unwrapExpanded_bulk(CtPtr c, int n, const std::vector<int>& idx);
+    static constexpr int UNWRAP_BULK_MIN = 64;
+    bool bulk_unwrap = true;    // FHELIN_BULK_UNWRAP=0: the tree form for every read
     CtPtr wrap_containers(const CtVec& c, int inputs_number);
 
 private:

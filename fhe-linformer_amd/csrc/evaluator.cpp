@@ -1268,6 +1268,46 @@ bool Evaluator::dot_plain_cyclic(const std::vector<CtPtr>& cts, const std::vecto
     return true;
 }
 
+bool Evaluator::dot_plain_window(const std::vector<CtPtr>& cur, const std::vector<CtPtr>& prev, const std::vector<PtPtr>& pts,
+                                 const std::vector<CtPtr>& dest, bool accumulate) {
+    constexpr int W = EwWindow::W;
+    if ((int)cur.size() != W || (int)prev.size() != W || (int)pts.size() != W || (int)dest.size() != W) return false;
+    CtPtr f;
+    for (const auto* v : {&cur, &prev})
+        for (const CtPtr& c : *v)
+            if (c && !f) f = c;
+    if (!f) return false;
+    u64 terms = 0;
+    for (const auto* v : {&cur, &prev})
+        for (const CtPtr& c : *v)
+            if (c) {
+                if (c->npoly != 2 || c->deg != 1 || c->ell != f->ell || fabsl(c->scale / f->scale - 1.0L) > 1e-9L) return false;
+                ++terms;
+            }
+    for (const CtPtr& o : dest)
+        if (!o || o->npoly != 2 || o->ell != f->ell) return false;
+    const long double sf = c_.sf_real[f->level()];
+    EwWindow d;
+    d.ell = f->ell;
+    d.accumulate = accumulate ? 1 : 0;
+    std::vector<std::shared_ptr<Encoding>> hold;
+    for (int j = 0; j < W; ++j) {
+        hold.push_back(pts[j]->at(f->ell, sf));
+        d.m[j] = hold.back()->d;
+        d.cur[j] = cur[j] ? cur[j]->d : nullptr;
+        d.prev[j] = prev[j] ? prev[j]->d : nullptr;
+        d.out[j] = dest[j]->d;
+        dest[j]->deg = f->deg + 1;
+        dest[j]->scale = f->scale * sf;
+        dest[j]->slots = f->slots;
+    }
+    launch_ew_window_dot(c_.dt, d, c_.stream);
+    launch_ok("dot_plain_window");
+    c_.stats.ct_pt_mult += terms * (u64)W / 2;          // every operand meets half of the block's plaintexts on average
+    c_.stats.ct_pt_limbs += terms * (u64)W / 2 * (u64)f->ell;
+    return true;
+}
+
 std::vector<CtPtr> Evaluator::add_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 1); }
 std::vector<CtPtr> Evaluator::sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 2); }
 

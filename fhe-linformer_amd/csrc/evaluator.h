@@ -180,6 +180,11 @@ public:
     // the 32 cyclic sums out_k = sum_i cts[i] * pts[(i + k) mod 32] over <= 32 ciphertexts of one shape (degree 1) in one pass
     // (kernels_elem.h launch_ew_cyclic_dot), written to dest[k]; the residues of dot_plain per k.  false: operands do not fit
     bool dot_plain_cyclic(const std::vector<CtPtr>& cts, const std::vector<PtPtr>& pts, const std::vector<CtPtr>& dest);
+    // one 32 x 32 block of a sliding-window sum (kernels_elem.h launch_ew_window_dot):
+    //     dest[t] (+)= sum_{j<32} (j <= t ? cur[j] : prev[j]) * pts[(t - j) mod 32]
+    // cur / prev: 32 entries each, null = zero; all present ciphertexts of one shape, degree 1; accumulate: dest holds earlier blocks' sums
+    bool dot_plain_window(const std::vector<CtPtr>& cur, const std::vector<CtPtr>& prev, const std::vector<PtPtr>& pts,
+                          const std::vector<CtPtr>& dest, bool accumulate);
     CtPtr dot_plain(const std::vector<CtPtr>& v, const std::vector<PtPtr>& p, long double pt_scale = 0,
                     const CtPtr& dest = CtPtr());   // pt_scale > 0: encode the plaintexts at this scale instead of the level's own;
                                                     // dest: write the sum there (a slice of a caller's batch block)

@@ -86,6 +86,20 @@ struct EwCyclic {
     u64* out[PERIOD];
 };
 void launch_ew_cyclic_dot(const DeviceTables& t, const EwCyclic& d, hipStream_t s);
+// One 32 x 32 block of a plaintext-weighted SLIDING-WINDOW sum  x_i = sum_k m_k * D_{i-k}  (Composite::unwrapExpanded_bulk):
+//     out_t (+)= sum_{j<32} (j <= t ? cur_j : prev_j) * m_{(t - j) mod 32},   t < 32
+// cur_j = D_{p+j}, prev_j = D_{p-32+j} for the block's window position p: the pairs (i, k) = (32 g + t, 32 c + k') of one output
+// block g and one tap chunk c.  Same structure as launch_ew_cyclic_dot (plaintext values in LDS, ciphertext values in registers,
+// both pre-split); a null cur / prev entry counts as zero; accumulate: out_t already holds the sum of earlier tap chunks.
+struct EwWindow {
+    static constexpr int W = 32;
+    int ell = 0, accumulate = 0;
+    const u64* cur[W];
+    const u64* prev[W];
+    const u64* m[W];
+    u64* out[W];
+};
+void launch_ew_window_dot(const DeviceTables& t, const EwWindow& d, hipStream_t s);
 
 struct KsShape {
     int ell;     // live Q limbs

@@ -170,6 +170,46 @@ __global__ __launch_bounds__(256) void ew_cyclic_dot_kernel(DeviceTables t, EwCy
     }
 }
 
+// grid (N/256, ell, 2 components): one coefficient per thread
+__global__ __launch_bounds__(256) void ew_window_dot_kernel(DeviceTables t, EwWindow d) {
+    constexpr int P = EwWindow::W;
+    __shared__ u64 ml[P][256];                       // pack30(m_k[n])
+    const int tt = blockIdx.y;
+    const Barrett br = load_barrett(t, tt);
+    const size_t N = (size_t)1 << t.log_n;
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t om = (size_t)tt * N + n, oc = (size_t)(blockIdx.z * d.ell + tt) * N + n;
+#pragma unroll
+    for (int k = 0; k < P; ++k) ml[k][threadIdx.x] = pack30(d.m[k][om]);
+    u64 cur[P], prv[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        cur[j] = d.cur[j] ? pack30(d.cur[j][oc]) : 0;
+        prv[j] = d.prev[j] ? pack30(d.prev[j][oc]) : 0;
+    }
+    // every thread reads only its own column of ml: no barrier needed (a thread sees its own LDS writes in program order)
+#pragma unroll 1
+    for (int o = 0; o < P; ++o) {
+        u64 lo = d.accumulate ? d.out[o][oc] : 0, hi = 0;
+#pragma unroll
+        for (int j0 = 0; j0 < P; j0 += 8) {
+            Acc30 x = {0, 0, 0};
+#pragma unroll
+            for (int j = j0; j < j0 + 8; ++j) {
+                const u64 a = j <= o ? cur[j] : prv[j];          // o is wave-uniform: a scalar-conditioned select
+                const u64 w = ml[(o - j) & (P - 1)][threadIdx.x];
+                mac30(x, (u32)a, (u32)(a >> 32), (u32)w, (u32)(w >> 32));
+            }
+            acc30_flush(x, lo, hi);
+            if (j0 == 8 || j0 == 24) {   // <= 16 products (+ one carried residue) per fold: below q * 2^64 for the 60-bit limbs too
+                lo = barrett_reduce128(lo, hi, br);
+                hi = 0;
+            }
+        }
+        d.out[o][oc] = lo;
+    }
+}
+
 // out[v] = acc[v] + a[v] * b[v % b_mod]
 __global__ __launch_bounds__(256) void ew_muladd_kernel(DeviceTables t, u64* out, const u64* acc, const u64* a, const u64* b,
                                                         int b_mod, int limb_first, int limb_count) {
@@ -437,6 +477,10 @@ void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& d, hipStream
 void launch_ew_cyclic_dot(const DeviceTables& t, const EwCyclic& d, hipStream_t s) {
     if (d.n <= 0 || d.ell <= 0) return;
     hipLaunchKernelGGL(ew_cyclic_dot_kernel, dim3((1u << t.log_n) / 256, (unsigned)d.ell, 2), dim3(256), 0, s, t, d);
+}
+void launch_ew_window_dot(const DeviceTables& t, const EwWindow& d, hipStream_t s) {
+    if (d.ell <= 0) return;
+    hipLaunchKernelGGL(ew_window_dot_kernel, dim3((1u << t.log_n) / 256, (unsigned)d.ell, 2), dim3(256), 0, s, t, d);
 }
 void launch_ew_mul(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s) {
     if (nvec <= 0) return;

@@ -64,6 +64,7 @@ def _load(name):
             "orc_modraise": (None, [vp, vp, i32, i32, i32, vp, vp]),
             "orc_rotate_sum": (None, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
             "orc_rotate_each_sum": (None, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+            "orc_dot": (None, [vp, vp, i32, vp, i32, i32, vp]),
             "orc_hoisted_dot": (None, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
             "orc_is_fast_build": (i32, []),
             "orc_automorph_coeff": (None, [vp, vp, i32, u64, u64]),
@@ -177,6 +178,21 @@ def add_scalar(a, s, q):
     c = np.empty_like(a)
     lib().orc_add_scalar(_p(a), _p(s), _p(c), a.shape[0], int(np.log2(a.shape[1])), _p(q))
     return c
+
+
+def dot(a_list, b_list, q):
+    """sum_i a_list[i] (.) b_list[i] over [nlimbs][N] arrays (exact sums of dyadic products)"""
+    import ctypes as C
+    a_list = [_u(a) for a in a_list]
+    b_list = [_u(b) for b in b_list]
+    q = _u(q)
+    nl, n = a_list[0].shape
+    assert len(a_list) == len(b_list) and all(a.shape == (nl, n) for a in a_list) and all(b.shape == (nl, n) for b in b_list)
+    pa = (C.c_void_p * len(a_list))(*[a.ctypes.data for a in a_list])
+    pb = (C.c_void_p * len(b_list))(*[b.ctypes.data for b in b_list])
+    out = np.empty((nl, n), dtype=np.uint64)
+    lib().orc_dot(pa, pb, len(a_list), _p(out), nl, int(np.log2(n)), _p(q))
+    return out
 
 
 def muladd(acc, a, b, q):

@@ -352,6 +352,22 @@ void orc_add_scalar(const u64* a, const u64* s, u64* c, int nlimbs, int log_n, c
         for (size_t i = 0; i < n; ++i) c[l * n + i] = addmod(a[l * n + i], s[l] % q[l], q[l]);
 }
 /* acc + a * b: the decryption phase c0 + c1 * s (reference Decrypt call sites :389,:399) */
+/* out = sum_i a[i] (.) b[i] over n pairs of [nlimbs][N] arrays (exact: the canonical residues of the sum) */
+void orc_dot(const u64* const* a, const u64* const* b, int n, u64* out, int nlimbs, int log_n, const u64* q) {
+    size_t N = (size_t)1 << log_n;
+    #pragma omp parallel for schedule(static)
+    for (int t = 0; t < nlimbs; ++t) {
+        const modq m = mq_make(q[t]);
+        u64* o = out + (size_t)t * N;
+        for (size_t x = 0; x < N; ++x) o[x] = 0;
+        for (int i = 0; i < n; ++i) {
+            const u64* ai = a[i] + (size_t)t * N;
+            const u64* bi = b[i] + (size_t)t * N;
+            for (size_t x = 0; x < N; ++x) o[x] = addmod(o[x], mq_mul(ai[x], bi[x], &m), q[t]);
+        }
+    }
+}
+
 void orc_muladd(const u64* acc, const u64* a, const u64* b, u64* c, int nlimbs, int log_n, const u64* q) {
     size_t n = (size_t)1 << log_n;
     #pragma omp parallel for schedule(static)

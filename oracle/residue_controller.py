@@ -62,11 +62,13 @@ class RPt:
 
 
 class _LazyRows(list):
-    """rows evaluated when read (the library defers the same calls: rows nobody reads cost nothing on either side)"""
+    """rows evaluated when read (the library defers the same calls: rows nobody reads cost nothing on either side).  bulk: how MANY
+    rows read together are evaluated (the library takes another form of the same rows when >= bulk_min of them are forced at once:
+    Composite::unwrapExpanded_bulk)"""
 
-    def __init__(self, n, fn):
+    def __init__(self, n, fn, bulk=None, bulk_min=64):
         super().__init__([None] * n)
-        self._fn = fn
+        self._fn, self._bulk, self._bulk_min = fn, bulk, bulk_min
 
     def _get(self, i):
         v = list.__getitem__(self, i)
@@ -75,47 +77,75 @@ class _LazyRows(list):
             list.__setitem__(self, i, v)
         return v
 
+    def _get_many(self, ids):
+        todo = [i for i in ids if list.__getitem__(self, i) is None]
+        if self._bulk is not None and len(todo) >= self._bulk_min:
+            for i, v in zip(todo, self._bulk(todo)):
+                list.__setitem__(self, i, v)
+        return [self._get(i) for i in ids]
+
     def __getitem__(self, i):
         if isinstance(i, slice):
-            return [self._get(k) for k in range(*i.indices(len(self)))]
+            return self._get_many(list(range(*i.indices(len(self)))))
         return self._get(i if i >= 0 else i + len(self))
 
     def __iter__(self):
-        return (self._get(i) for i in range(len(self)))
+        return iter(self._get_many(list(range(len(self)))))
 
     def __add__(self, other):
-        if getattr(self, "relarge", None) is not None and getattr(other, "relarge", None) is not None:
-            return _RelargeConcat([self, other])        # output_0 + output_1 of the driver: still nobody has read a row
+        if isinstance(other, (_LazyRows, _LazyConcat)):
+            return _LazyConcat([self] + (other.parts if isinstance(other, _LazyConcat) else [other]))   # still nobody has read a row
         return list(self) + list(other)
 
     def __radd__(self, other):
         return list(other) + list(self)
 
 
-class _RelargeConcat(list):
-    """rows of several matmulRElarge calls in a row, unread (linformer.py: outputs_raw = output_0 + output_1)"""
+class _LazyConcat(list):
+    """rows of several deferred calls in a row, unread (linformer.py: outputs_raw = output_0 + output_1)"""
 
-    def __init__(self, lists):
+    def __init__(self, parts):
         super().__init__()
-        self.relarge_lists = lists
-        self.relarge_parts = [lz.relarge for lz in lists]
-        for lz in lists:
-            list.extend(self, [None] * len(lz))
+        self.parts = parts
+        if all(getattr(p, "relarge", None) is not None for p in parts):
+            self.relarge_lists = parts
+        for p in parts:
+            list.extend(self, [None] * len(p))
 
-    def _get(self, i):
-        for lz in self.relarge_lists:
-            if i < len(lz):
-                return lz[i]
-            i -= len(lz)
+    def _locate(self, i):
+        for p in self.parts:
+            if i < len(p):
+                return p, i
+            i -= len(p)
         raise IndexError(i)
+
+    def _get_many(self, ids):
+        by_part = {}
+        for i in ids:
+            p, k = self._locate(i)
+            by_part.setdefault(id(p), (p, []))[1].append(k)
+        for p, ks in by_part.values():        # rows of one call that are read together are evaluated together
+            p._get_many(ks)
+        out = []
+        for i in ids:
+            p, k = self._locate(i)
+            out.append(p._get(k))
+        return out
 
     def __getitem__(self, i):
         if isinstance(i, slice):
-            return [self._get(k) for k in range(*i.indices(len(self)))]
-        return self._get(i if i >= 0 else i + len(self))
+            return self._get_many(list(range(*i.indices(len(self)))))
+        return self._get_many([i if i >= 0 else i + len(self)])[0]
 
     def __iter__(self):
-        return (self._get(i) for i in range(len(self)))
+        return iter(self._get_many(list(range(len(self)))))
+
+    def __add__(self, other):
+        if isinstance(other, _LazyRows):
+            return _LazyConcat(self.parts + [other])
+        if isinstance(other, _LazyConcat):
+            return _LazyConcat(self.parts + other.parts)
+        return list(self) + list(other)
 
 
 class ResidueController:
@@ -211,6 +241,7 @@ class ResidueController:
 
     def _matmul_pt(self, rows, w, bias, slots, padding):
         rev = self.rev
+        rows = list(rows)          # the library reads its input rows at the call (deferred input rows are evaluated together there)
         return _LazyRows(len(rows), lambda i: rev.matmul_pt([rows[i]], w.enc, bias.enc if bias is not None else None, slots, padding)[0])
 
     def matmulRE(self, rows, w, bias=None, row_size=128, padding=128):
@@ -274,9 +305,11 @@ class ResidueController:
         return self.rev.wrapUpExpanded(list(v), self._mod_mask(128, 0).enc)
 
     def unwrapExpanded(self, c, n):
-        """:1086-1100 with the three-level fan of Composite::shift_fan_rows (ResidueEvaluator.fan_row); rows evaluated when read"""
+        """:1086-1100 with the three-level fan of Composite::shift_fan_rows (ResidueEvaluator.fan_row); rows evaluated when read -
+        64 or more of them read together as sliding-window sums of the two fans (ResidueEvaluator.unwrapExpanded_bulk)"""
         rev, mask, memo = self.rev, self._mod_mask(128, 0).enc, {}
-        return _LazyRows(n, lambda i: rev.repeat(rev.mult_plain(rev.fan_row(c, i, 1, memo, n - 1), mask), 128, 1))
+        bulk = lambda ids: rev.unwrapExpanded_bulk(c, n, ids, [self._mod_mask(128, k).enc for k in range(128)])
+        return _LazyRows(n, lambda i: rev.repeat(rev.mult_plain(rev.fan_row(c, i, 1, memo, n - 1), mask), 128, 1), bulk if n <= 128 else None)
 
     def unwrapRepeatedLarge(self, cs, n):
         return self.rev.unwrapRepeatedLarge(list(cs), n, lambda v: self._mask(v).enc)

@@ -578,3 +578,20 @@ class ResidueEvaluator:
 
     def unwrapExpanded(self, c, n, mask_enc):
         return [self.repeat(self.mult_plain(x, mask_enc), 128, 1) for x in self.shift_fan(c, n, 1)]
+
+    def unwrapExpanded_bulk(self, c, n, idx, mask_encs):
+        """Composite::unwrapExpanded_bulk (many rows of one call read together): row i = sum_{k<128} mask_k * rot(c, i - k), mask_k =
+        slots = k mod 128 - exact sums of dyadic products (noise degree 2); the rotations rot(c, j) are the hoisted fans of
+        shift_fan_rows: the call's own fan for j >= 0, the fan by -1 over 128 rows for j < 0; a degree-2 input is rescaled first.
+        mask_encs[k] encodes mask_k."""
+        x = self.rescale(c) if c.deg >= 2 else c
+        mp, mn = {}, {}
+        sf = self.sf[self.level(x)]
+        ql = self.q[:x.ell]
+        encs = [m(x.ell, sf) for m in mask_encs]
+        out = []
+        for i in idx:
+            ds = [self.fan_row(x, i - k, 1, mp, n - 1) if i - k >= 0 else self.fan_row(x, k - i, -1, mn, 127) for k in range(128)]
+            d = np.stack([orc.dot([t.d[cmp] for t in ds], encs, ql) for cmp in range(2)])
+            out.append(RCt(d, x.deg + 1, x.scale * sf))
+        return out

@@ -391,6 +391,39 @@ def test_layout_shuffles_and_large_matmul_default_path_bit_exact(fa, orc):
         eng.close()
 
 
+def test_unwrap_expanded_bulk_bit_exact(fa, orc):
+    """unwrapExpanded with 64 or more rows read together (Composite::unwrapExpanded_bulk: the fans rot(c, j), -127 <= j < n, and every
+    row as a plaintext-weighted sliding-window sum over them, ew_window_dot_kernel) == ResidueEvaluator.unwrapExpanded_bulk; a single
+    row read on its own keeps the tree form (mask, repeat)"""
+    eng = fa.Engine("reference", seed=5, n_q=4, n_p=2, dnum=2)
+    try:
+        need = set()
+        for s in (1, -1):
+            need.update(s * k for k in range(1, 8))
+            need.update(8 * s * k for k in range(1, 8))
+            need.add(64 * s)
+        keys = _keys(orc, eng, sorted(need), seed=300)
+        rev = _rev(orc, eng, keys)
+        ns, n, ell = 16384, 70, 4
+        enc_of = lambda p: (lambda l, sc: eng.pt_export(p, l, sc))
+        masks = []
+        for k in range(128):
+            m = np.zeros(ns)
+            m[k::128] = 1.0
+            masks.append(enc_of(eng.encode(m)))
+        c, r = _imp(eng, rev, _ct(orc, eng, 77, ell))
+        rows = eng.unwrapExpanded(c, n)
+        idx = list(range(n))
+        eng.force(rows)                                            # all 70 rows read together: the bulk form
+        want = rev.unwrapExpanded_bulk(r, n, idx, masks)
+        for i in (0, 1, 31, 32, 63, 64, 69):
+            _same(rows[i], want[i], ("bulk row", i))
+        one = eng.unwrapExpanded(c, n)[5]                          # one row read on its own: the tree form
+        _same(one, rev.unwrapExpanded(r, n, masks[0])[5], "single row")
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("preset,ell", [("toy13", 6), ("bench", 24)])
 def test_batched_leaf_ops_bit_exact(engine_factory, orc, preset, ell):
     """the batched leaf entry points (fhelin_rotate_batch / rescale_batch / mult_plain_batch / mult_batch / add_batch:
