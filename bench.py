@@ -651,8 +651,10 @@ def main():
                                            if row_mode else f"independent samples x{world}, keys replicated (one key seed)"),
                            "logit_err_vs_circuit_oracle": round(fwd["logit_err_vs_circuit_oracle"], 5),
                            "samples_checked_vs_circuit_oracle": fwd["samples_checked"],
-                           "deferred_rows": "on: rows of matmulRE / unwrapExpanded that no later call reads are not evaluated "
-                                            "(results unchanged); ops_per_sample counts what was executed",
+                           "deferred_rows": "on: rows of matmulRE / unwrapExpanded / matmulRElarge are evaluated when read - rows no later call "
+                                            "reads never; rows of matmulRElarge that generate_containers takes unread go through the fused "
+                                            "container sum (DESIGN.md 7g: same slot values, checked bit for bit against the oracle's restatement); "
+                                            "ops_per_sample counts what was executed",
                            "ms_per_sample_with_every_row_evaluated": round(fwd["eager_ms"], 2),
                            "level_plan": ("off" if not fwd["plan"] else
                                           "on: one untimed pass of the same driver was recorded; fresh encryptions and bootstrap outputs start with "
@@ -668,7 +670,7 @@ def main():
                                "deferred_rows=on,level_plan=on": round(value, 2) if fwd["plan"] else None,
                                "deferred_rows=off,level_plan=on": round(fwd["eager_ms"], 2) if fwd["plan"] else None,
                                "deferred_rows=on,level_plan=off": round(fwd["unplanned_ms"], 2),
-                               "deferred_rows=off,level_plan=off (the reference's literal op sequence at its own levels)": round(fwd["literal_ms"], 2),
+                               "deferred_rows=off,level_plan=off (every call of the reference's driver evaluated in full where it is made, at the driver's own levels)": round(fwd["literal_ms"], 2),
                                "how": "value: the timed region (steps x passes, max over ranks); the other cells: 2 passes each after one untimed "
                                       "pass, same build, same process, after the timed region"},
                            "throughput_with_samples_in_flight": fwd["inflight"],

@@ -480,7 +480,9 @@ class ResidueEvaluator:
             memo[("a", a)] = self.rotate(c, 64 * step * a) if a else c
         if ("b", a, b) not in memo:
             memo[("b", a, b)] = self.rotate(memo[("a", a)], 8 * step * b) if b else memo[("a", a)]
-        return self.rotate(memo[("b", a, b)], step * k) if k else memo[("b", a, b)]
+        if ("k", i) not in memo:       # a row is asked for many times when the rows are window sums over the fan (unwrapExpanded_bulk)
+            memo[("k", i)] = self.rotate(memo[("b", a, b)], step * k) if k else memo[("b", a, b)]
+        return memo[("k", i)]
 
     def shift_fan(self, c, n, step):
         """rot(c, step * i), i < n (Composite::shift_fan)"""
@@ -519,13 +521,8 @@ class ResidueEvaluator:
         encs = [m(x0.ell, sf) for m in mask_encs]
         w = []
         for k in range(32):
-            acc = None
-            for i, u in enumerate(us):
-                e = encs[(i + k) % 32]
-                if acc is None:
-                    acc = np.stack([orc.mul(u.d[c], e, ql) for c in range(2)])
-                else:
-                    acc = np.stack([orc.muladd(acc[c], u.d[c], e, ql) for c in range(2)])
+            ms = [encs[(i + k) % 32] for i in range(len(us))]
+            acc = np.stack([orc.dot([u.d[c] for u in us], ms, ql) for c in range(2)])
             w.append(RCt(acc, x0.deg + 1, x0.scale * sf))
         c = self.shift_sum(w, 512)
         return self.add_plain(c, bias_tiled_enc) if bias_tiled_enc is not None else c
