@@ -279,12 +279,24 @@ CtVec Composite::matmul_ct(const CtVec& rows, const CtPtr& w, int slots, int pad
     return rotsum_batch(prod, slots, padding);
 }
 
+static uint64_t hash_plain(const PtPtr& w, uint64_t h) {   // FNV-1a over the slot values and the level
+    for (double v : w->values) {
+        uint64_t bits;
+        std::memcpy(&bits, &v, sizeof bits);
+        h = (h ^ bits) * 1099511628211ull;
+    }
+    return (h ^ (uint64_t)w->values.size() ^ ((uint64_t)w->level << 32)) * 1099511628211ull;
+}
+
 // W''_t (t = 0..3): block b (128 slots) of W''_t is block b of W_j with j = (b - t) mod 4 — see matmulRElarge.
 // rotated: V_t = rot(W''_t, 128 t) instead (slot s of V_t = slot s + 128 t of W''_t): rot(x * W''_t, 128 t) = rot(x, 128 t) * V_t
 std::vector<PtPtr> Composite::relarge_weights(const std::vector<PtPtr>& weights, bool rotated) {
-    char key[160];
-    snprintf(key, sizeof key, "%p:%p:%p:%p:%d", (void*)weights[0].get(), (void*)weights[1].get(), (void*)weights[2].get(), (void*)weights[3].get(),
-             rotated ? 1 : 0);
+    // keyed by CONTENT: a driver that reads its weights again for every sample (src/main.cpp does, per run) gets the same re-arranged
+    // plaintexts back, and with them the rotation keys they are folded into (Evaluator::folded_key is keyed by plaintext handle)
+    uint64_t h = 1469598103934665603ull;
+    for (const PtPtr& w : weights) h = hash_plain(w, h);
+    char key[96];
+    snprintf(key, sizeof key, "relarge:%016llx:%d", (unsigned long long)h, rotated ? 1 : 0);
     auto it = relarge_cache_.find(key);
     if (it != relarge_cache_.end()) return it->second;
     const int ns = num_slots();
@@ -391,7 +403,7 @@ CtPtr Composite::relarge_container(const CtVec& uin, const PtPtr& bias, double m
     CtPtr c = shift_sum(w, 512);
     if (bias) {
         char key[96];
-        snprintf(key, sizeof key, "relarge_bias:%p:%d", (void*)bias.get(), q);
+        snprintf(key, sizeof key, "relarge_bias:%016llx:%d", (unsigned long long)hash_plain(bias, 1469598103934665603ull), q);
         auto it = relarge_cache_.find(key);
         PtPtr tiled;
         if (it != relarge_cache_.end()) {
@@ -405,7 +417,7 @@ CtPtr Composite::relarge_container(const CtVec& uin, const PtPtr& bias, double m
                 }
             tiled = encode_vec(v, bias->level);
             if (relarge_cache_.size() > 16) relarge_cache_.clear();
-            relarge_cache_[key] = {tiled, bias};      // holds the bias: its address stays its own
+            relarge_cache_[key] = {tiled};
         }
         c = ev_.add_plain(c, tiled);
     }
