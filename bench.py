@@ -716,12 +716,12 @@ def main():
                               "in the reference's units); plaintext encodes, additions and host orchestration not counted (lower bound)",
                     "ops": detail, "ops_single_thread": detail_one, "timed_composite_stage": res.get("composite")}
                 # the WHOLE pass timed on the CPU port (tools/cpu_forward_pass.py, ~2 minutes: too long for this run) - a static record
-                rec = os.path.join(ROOT, "profiles", "r03_r_cpu_forward_pass.json")
+                rec = os.path.join(ROOT, "profiles", "r03_be_cpu_forward_pass.json")
                 if os.path.exists(rec):
                     try:
                         full = json.load(open(rec))
                         line["cpu_baseline"]["timed_full_pass_record"] = {
-                            "source": "profiles/r03_r_cpu_forward_pass.json (tools/cpu_forward_pass.py on a GPU box's host cores, round 3; not re-run here)",
+                            "source": "profiles/r03_be_cpu_forward_pass.json (tools/cpu_forward_pass.py on a GPU box's host cores, round 3; not re-run here)",
                             "cpu_port_s": full.get("cpu_port_s"), "cpu_threads": full.get("cpu_threads"), "gpu_s_same_run": full.get("gpu_s"),
                             "ring": full.get("ring"), "same_residues_as_the_gpu_pass": full.get("same_residues_as_the_gpu_pass")}
                     except Exception:

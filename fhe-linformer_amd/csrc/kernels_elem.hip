@@ -132,42 +132,66 @@ __global__ __launch_bounds__(256) void ew_dot_groups_kernel(DeviceTables t, EwDo
     }
 }
 
-// grid (N/256, ell, 2 components): one coefficient per thread
-__global__ __launch_bounds__(256) void ew_cyclic_dot_kernel(DeviceTables t, EwCyclic d) {
+// grid (N/256, ell, 2 components): one coefficient per thread.  SH: see pack_sh below (limbs under 2^53 take one flush per output)
+template <int SH>
+__device__ __forceinline__ u64 cyc_pack(u64 x) { return (x & ((1ull << SH) - 1)) | ((x >> SH) << 32); }
+template <int SH>
+__device__ __forceinline__ void cyclic_body(const DeviceTables& t, const EwCyclic& d, const Barrett& br, u64 (*ml)[256]) {
     constexpr int P = EwCyclic::PERIOD;
-    __shared__ u64 ml[P][256];                       // pack30(m_j[n]): low 30 bits | next 30 bits << 32
     const int tt = blockIdx.y;
-    const Barrett br = load_barrett(t, tt);
     const size_t N = (size_t)1 << t.log_n;
     const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t om = (size_t)tt * N + n, oc = (size_t)(blockIdx.z * d.ell + tt) * N + n;
 #pragma unroll
-    for (int j = 0; j < P; ++j) ml[j][threadIdx.x] = pack30(d.m[j][om]);
+    for (int j = 0; j < P; ++j) ml[j][threadIdx.x] = cyc_pack<SH>(d.m[j][om]);
     u64 a[P];
 #pragma unroll
-    for (int i = 0; i < P; ++i) a[i] = i < d.n ? pack30(d.a[i][oc]) : 0;
+    for (int i = 0; i < P; ++i) a[i] = i < d.n ? cyc_pack<SH>(d.a[i][oc]) : 0;
     // every thread reads only its own column of ml: no barrier needed (a thread sees its own LDS writes in program order)
 #pragma unroll 1
     for (int k = 0; k < P; ++k) {
         u64 lo = 0, hi = 0;
+        Acc30 x = {0, 0, 0};
 #pragma unroll
         for (int i0 = 0; i0 < P; i0 += 8) {
             if (i0 < d.n) {
-                Acc30 x = {0, 0, 0};
 #pragma unroll
                 for (int i = i0; i < i0 + 8; ++i) {
                     const u64 w = ml[(i + k) & (P - 1)][threadIdx.x];
                     mac30(x, (u32)a[i], (u32)(a[i] >> 32), (u32)w, (u32)(w >> 32));
                 }
-                acc30_flush(x, lo, hi);
-                if (i0 == 8) {   // 16 products so far: fold, so that the final 128-bit value stays below q * 2^64 for 60-bit limbs too
-                    lo = barrett_reduce128(lo, hi, br);
-                    hi = 0;
+                if (SH == 30) {
+                    acc30_flush(x, lo, hi);
+                    x = Acc30{0, 0, 0};
+                    if (i0 == 8) {   // 16 products so far: fold, so that the final 128-bit value stays below q * 2^64 for 60-bit limbs too
+                        lo = barrett_reduce128(lo, hi, br);
+                        hi = 0;
+                    }
                 }
             }
         }
+        if (SH != 30) {              // all products below 2^54: one accumulator, one flush
+            u64 tq = lo + x.s0;
+            hi += (tq < lo);
+            lo = tq;
+            tq = lo + (x.s1 << SH);
+            hi += (x.s1 >> (64 - SH)) + (tq < lo);
+            lo = tq;
+            tq = lo + (x.s2 << (2 * SH));
+            hi += (x.s2 >> (64 - 2 * SH)) + (tq < lo);
+            lo = tq;
+        }
         d.out[k][oc] = barrett_reduce128(lo, hi, br);
     }
+}
+
+__global__ __launch_bounds__(256) void ew_cyclic_dot_kernel(DeviceTables t, EwCyclic d) {
+    __shared__ u64 ml[EwCyclic::PERIOD][256];        // the plaintext values of this workgroup's 256 coefficients, pre-split
+    const Barrett br = load_barrett(t, blockIdx.y);
+    if ((br.q >> 53) == 0)                           // wave-uniform: the limb of the block
+        cyclic_body<27>(t, d, br, ml);
+    else
+        cyclic_body<30>(t, d, br, ml);
 }
 
 // grid (N/256, ell, 2 components): one coefficient per thread.  The plaintext values sit in LDS (a dynamically indexed register file:
@@ -176,7 +200,24 @@ __global__ __launch_bounds__(256) void ew_cyclic_dot_kernel(DeviceTables t, EwCy
 // for j >= O0 + 8 whatever the output, and the LDS row is a fixed distance from the output's own - only the eight columns of the
 // segment itself need the per-output select and the wrapped index.  (A fully unrolled register-only form - 1024 static
 // multiply-accumulates - measured slower: 48 KB of straight-line code per kernel.)
-template <int O0>
+// SH = bits of the low half of the pre-split operands: 30 for the 60-bit limbs (eight products per column before a flush, a fold
+// every 16), 27 for limbs below 2^53 (every product below 2^54: all 32 of an output in one accumulator, one flush, one reduction)
+template <int SH>
+__device__ __forceinline__ u64 pack_sh(u64 x) { return (x & ((1ull << SH) - 1)) | ((x >> SH) << 32); }
+template <int SH>
+__device__ __forceinline__ void acc_flush_sh(const Acc30& a, u64& lo, u64& hi) {
+    u64 t = lo + a.s0;
+    hi += (t < lo);
+    lo = t;
+    t = lo + (a.s1 << SH);
+    hi += (a.s1 >> (64 - SH)) + (t < lo);
+    lo = t;
+    t = lo + (a.s2 << (2 * SH));
+    hi += (a.s2 >> (64 - 2 * SH)) + (t < lo);
+    lo = t;
+}
+
+template <int O0, int SH>
 __device__ __forceinline__ void window_segment(const EwWindow& d, const Barrett& br, const u64 (&cur)[EwWindow::W], const u64 (&prv)[EwWindow::W],
                                                const u64 (*ml)[256], size_t oc) {
     constexpr int P = EwWindow::W;
@@ -184,9 +225,9 @@ __device__ __forceinline__ void window_segment(const EwWindow& d, const Barrett&
     for (int oo = 0; oo < 8; ++oo) {
         const int o = O0 + oo;
         u64 lo = d.accumulate ? d.out[o][oc] : 0, hi = 0;
+        Acc30 x = {0, 0, 0};
 #pragma unroll
         for (int j0 = 0; j0 < P; j0 += 8) {
-            Acc30 x = {0, 0, 0};
 #pragma unroll
             for (int j = j0; j < j0 + 8; ++j) {
                 u64 a, w;
@@ -202,37 +243,52 @@ __device__ __forceinline__ void window_segment(const EwWindow& d, const Barrett&
                 }
                 mac30(x, (u32)a, (u32)(a >> 32), (u32)w, (u32)(w >> 32));
             }
-            acc30_flush(x, lo, hi);
-            if (j0 == 8 || j0 == 24) {   // <= 16 products (+ one carried residue) per fold: below q * 2^64 for the 60-bit limbs too
-                lo = barrett_reduce128(lo, hi, br);
-                hi = 0;
+            if (SH == 30) {
+                acc_flush_sh<30>(x, lo, hi);
+                x = Acc30{0, 0, 0};
+                if (j0 == 8 || j0 == 24) {   // <= 16 products (+ one carried residue) per fold: below q * 2^64 for the 60-bit limbs too
+                    lo = barrett_reduce128(lo, hi, br);
+                    hi = 0;
+                }
             }
+        }
+        if (SH != 30) {
+            acc_flush_sh<SH>(x, lo, hi);
+            lo = barrett_reduce128(lo, hi, br);
         }
         d.out[o][oc] = lo;
     }
 }
 
-__global__ __launch_bounds__(256) void ew_window_dot_kernel(DeviceTables t, EwWindow d) {
+template <int SH>
+__device__ __forceinline__ void window_body(const DeviceTables& t, const EwWindow& d, const Barrett& br, u64 (*ml)[256]) {
     constexpr int P = EwWindow::W;
-    __shared__ u64 ml[P][256];                       // pack30(m_k[n])
     const int tt = blockIdx.y;
-    const Barrett br = load_barrett(t, tt);
     const size_t N = (size_t)1 << t.log_n;
     const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t om = (size_t)tt * N + n, oc = (size_t)(blockIdx.z * d.ell + tt) * N + n;
 #pragma unroll
-    for (int k = 0; k < P; ++k) ml[k][threadIdx.x] = pack30(d.m[k][om]);
+    for (int k = 0; k < P; ++k) ml[k][threadIdx.x] = pack_sh<SH>(d.m[k][om]);
     u64 cur[P], prv[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-        cur[j] = d.cur[j] ? pack30(d.cur[j][oc]) : 0;
-        prv[j] = d.prev[j] ? pack30(d.prev[j][oc]) : 0;
+        cur[j] = d.cur[j] ? pack_sh<SH>(d.cur[j][oc]) : 0;
+        prv[j] = d.prev[j] ? pack_sh<SH>(d.prev[j][oc]) : 0;
     }
     // every thread reads only its own column of ml: no barrier needed (a thread sees its own LDS writes in program order)
-    window_segment<0>(d, br, cur, prv, ml, oc);
-    window_segment<8>(d, br, cur, prv, ml, oc);
-    window_segment<16>(d, br, cur, prv, ml, oc);
-    window_segment<24>(d, br, cur, prv, ml, oc);
+    window_segment<0, SH>(d, br, cur, prv, ml, oc);
+    window_segment<8, SH>(d, br, cur, prv, ml, oc);
+    window_segment<16, SH>(d, br, cur, prv, ml, oc);
+    window_segment<24, SH>(d, br, cur, prv, ml, oc);
+}
+
+__global__ __launch_bounds__(256) void ew_window_dot_kernel(DeviceTables t, EwWindow d) {
+    __shared__ u64 ml[EwWindow::W][256];             // the plaintext values of this workgroup's 256 coefficients, pre-split
+    const Barrett br = load_barrett(t, blockIdx.y);
+    if ((br.q >> 53) == 0)                           // wave-uniform: the limb of the block
+        window_body<27>(t, d, br, ml);
+    else
+        window_body<30>(t, d, br, ml);
 }
 
 // out[v] = acc[v] + a[v] * b[v % b_mod]
