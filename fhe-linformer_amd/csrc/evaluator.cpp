@@ -982,23 +982,37 @@ std::vector<std::vector<CtPtr>> Evaluator::rotate_many_batch(const std::vector<C
         // inner products: per input, rows of <= MAX_ROWS indices with their own keys, all reading that input's digits
         u64* accQ = c_.dalloc<u64>((size_t)rows * 2 * ell * N);
         u64* accP = c_.dalloc<u64>((size_t)rows * 2 * K * N);
+        // ONE launch per chunk of <= MAX_ROWS indices over ALL inputs (KsShape::row_mod): row (i, r) = rotation r of input i; in the
+        // XCD-aware block order a key tile is fetched once for all inputs and a digit tile once for all indices
         auto row_shape = [&](int first, int cnt) {
-            KsShape sh{ell, K, c_.alpha, lt.beta, L1, cnt, 0, ctw, 0, 0};
+            KsShape sh{ell, K, c_.alpha, lt.beta, L1, B * cnt, ctw, ctw, ctw, 0};
             sh.per_row = 1;
             sh.shared_input = 1;
+            sh.row_mod = cnt;
+            sh.ext_batch_stride = (size_t)lt.beta * nt * N;
             for (int b = 0; b < cnt; ++b) {
                 sh.evk_row[b] = keys[first + b]->d;
                 sh.map_row[b] = maps[first + b];
             }
             return sh;
         };
-        for (int i = 0; i < B; ++i)
-            for (int first = 0; first < R; first += KsShape::MAX_ROWS) {
-                const int cnt = std::min(R - first, (int)KsShape::MAX_ROWS);
-                const size_t row0 = (size_t)i * R + first;
-                launch_ks_inner(c_.dt, row_shape(first, cnt), accQ + row0 * 2 * ell * N, accP + row0 * 2 * K * N,
-                                ext + (size_t)i * lt.beta * nt * N, nullptr, base + pn + (size_t)i * ctw, s);
-            }
+        const bool one_chunk = R <= (int)KsShape::MAX_ROWS;     // rows then lie [input][index] as the outputs do
+        if (one_chunk) launch_ks_inner(c_.dt, row_shape(0, R), accQ, accP, ext, nullptr, base + pn, s);
+        else
+            for (int i = 0; i < B; ++i)
+                for (int first = 0; first < R; first += KsShape::MAX_ROWS) {
+                    const int cnt = std::min(R - first, (int)KsShape::MAX_ROWS);
+                    const size_t row0 = (size_t)i * R + first;
+                    KsShape sh1{ell, K, c_.alpha, lt.beta, L1, cnt, 0, ctw, 0, 0};
+                    sh1.per_row = 1;
+                    sh1.shared_input = 1;
+                    for (int b = 0; b < cnt; ++b) {
+                        sh1.evk_row[b] = keys[first + b]->d;
+                        sh1.map_row[b] = maps[first + b];
+                    }
+                    launch_ks_inner(c_.dt, sh1, accQ + row0 * 2 * ell * N, accP + row0 * 2 * K * N, ext + (size_t)i * lt.beta * nt * N, nullptr,
+                                    base + pn + (size_t)i * ctw, s);
+                }
         // ONE ModDown over all rows
         KsShape dn{ell, K, c_.alpha, lt.beta, L1, rows, 0, ctw, 0, 0};
         c_.ntt(LimbBatch{accP, rows * 2 * K, nullptr, L1, K}, true);
@@ -1006,14 +1020,26 @@ std::vector<std::vector<CtPtr>> Evaluator::rotate_many_batch(const std::vector<C
         launch_moddown_conv(c_.dt, dn, conv, accP, c_.d_phatinv, c_.d_phatmod, s);
         c_.ntt(LimbBatch{conv, rows * 2 * ell, nullptr, 0, ell}, false);
         std::vector<CtPtr> o = new_ct_batch(rows, 2, ell, xs[lo]->deg, xs[lo]->scale, xs[lo]->slots);
-        for (int i = 0; i < B; ++i)
-            for (int first = 0; first < R; first += KsShape::MAX_ROWS) {
-                const int cnt = std::min(R - first, (int)KsShape::MAX_ROWS);
-                const size_t row0 = (size_t)i * R + first;
-                // the epilogue adds the input's c0 (gathered through each row's map): add_stride 0 = the same c0 for every row
-                launch_moddown_finish(c_.dt, row_shape(first, cnt), o[row0]->d, accQ + row0 * 2 * ell * N, conv + row0 * 2 * ell * N, c_.d_pinv,
-                                      base + (size_t)i * ctw, nullptr, nullptr, nullptr, s);
-            }
+        // the epilogue adds the input's c0 (gathered through each row's map)
+        if (one_chunk) {
+            launch_moddown_finish(c_.dt, row_shape(0, R), o[0]->d, accQ, conv, c_.d_pinv, base, nullptr, nullptr, nullptr, s);
+        } else {
+            for (int i = 0; i < B; ++i)
+                for (int first = 0; first < R; first += KsShape::MAX_ROWS) {
+                    const int cnt = std::min(R - first, (int)KsShape::MAX_ROWS);
+                    const size_t row0 = (size_t)i * R + first;
+                    KsShape sh1{ell, K, c_.alpha, lt.beta, L1, cnt, 0, ctw, 0, 0};
+                    sh1.per_row = 1;
+                    sh1.shared_input = 1;
+                    for (int b = 0; b < cnt; ++b) {
+                        sh1.evk_row[b] = keys[first + b]->d;
+                        sh1.map_row[b] = maps[first + b];
+                    }
+                    // add_stride 0 = the same c0 for every row
+                    launch_moddown_finish(c_.dt, sh1, o[row0]->d, accQ + row0 * 2 * ell * N, conv + row0 * 2 * ell * N, c_.d_pinv,
+                                          base + (size_t)i * ctw, nullptr, nullptr, nullptr, s);
+                }
+        }
         launch_ok("rotate_many_batch");
         c_.pool.free(cc);
         c_.pool.free(ext);

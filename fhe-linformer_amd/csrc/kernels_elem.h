@@ -119,6 +119,12 @@ struct KsShape {
     static constexpr int MAX_ROWS = 16;
     int per_row = 0;
     int shared_input = 0;
+    // row_mod = R > 0 (with per_row): batch row bi is rotation bi % R (key evk_row[bi % R], map map_row[bi % R]) of INPUT bi / R - the
+    // digits at ext + (bi / R) * ext_batch_stride, the polynomial at c + (bi / R) * c_stride, the K8b addend at add + (bi / R) *
+    // add_stride: the hoisted rotations of MANY inputs in one launch (Evaluator::rotate_many_batch).  In the XCD-aware block order
+    // the rows of one (tile, limb) run back to back on one XCD: every key tile is fetched once for all inputs, every digit tile
+    // once for all rotations.
+    int row_mod = 0;
     const u64* evk_row[MAX_ROWS] = {};
     const u32* map_row[MAX_ROWS] = {};
     // merged rotations (launch_ks_inner_multi): n_rot <= MAX_ROT rotations of every row are accumulated before ONE ModDown

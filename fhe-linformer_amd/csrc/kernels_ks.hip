@@ -112,11 +112,18 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
     const KsBlock kb_ = ks_block(sh);
     const int bi = kb_.bi, tt = kb_.tt;
     const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
-    if (!sh.shared_input) {
-        ext += (size_t)bi * sh.beta * nt * ((size_t)1 << t.log_n);
-        c_ntt += (size_t)bi * sh.c_stride;
+    if (sh.row_mod) {
+        const int in = bi / sh.row_mod;
+        ext += (size_t)in * sh.ext_batch_stride;
+        c_ntt += (size_t)in * sh.c_stride;
+        evk = sh.evk_row[bi % sh.row_mod];
+    } else {
+        if (!sh.shared_input) {
+            ext += (size_t)bi * sh.beta * nt * ((size_t)1 << t.log_n);
+            c_ntt += (size_t)bi * sh.c_stride;
+        }
+        if (sh.per_row) evk = sh.evk_row[bi];
     }
-    if (sh.per_row) evk = sh.evk_row[bi];
     const int own = tt < sh.ell ? tt / sh.alpha : -1;  // the digit that contains target limb tt (its slot in ext is unused)
     accQ += (size_t)bi * 2 * sh.ell * ((size_t)1 << t.log_n);
     accP += (size_t)bi * 2 * sh.k * ((size_t)1 << t.log_n);
@@ -386,9 +393,9 @@ __global__ __launch_bounds__(256) void moddown_finish_kernel(DeviceTables t, KsS
     conv += (size_t)bi * 2 * sh.ell * N;
     out += (size_t)bi * sh.out_stride;
     const u64* add = c == 0 ? add0 : add1;
-    if (add) add += (size_t)bi * sh.add_stride;
+    if (add) add += (size_t)(sh.row_mod ? bi / sh.row_mod : bi) * sh.add_stride;
     if (post) post += (size_t)bi * sh.post_stride;
-    if (sh.per_row) map = sh.map_row[bi];
+    if (sh.per_row) map = sh.map_row[sh.row_mod ? bi % sh.row_mod : bi];
     u64x2 r;
     if (map) {
         const u32 m0 = map[j], m1 = map[j + 1];
