@@ -348,6 +348,10 @@ CtPtr Bootstrapper::mod_raise(const CtPtr& ct, long double& rho, int top_ell) {
 std::vector<CtPtr> Bootstrapper::eval_mod(const std::vector<CtPtr>& xs) {
     std::vector<CtPtr> u = ev_.eval_chebyshev_many(xs, cheb_, -1.0, 1.0);
     for (int i = 0; i < R; ++i) {
+        if (ev_.merged_products) {     // rescale(2 u^2 - 1) in one go: the next step (or the first SlotsToCoeffs stage) rescales it anyway
+            u = ev_.mult_affine_rescale_batch(u, u, 2, -1.0, {});
+            continue;
+        }
         std::vector<CtPtr> t = ev_.mult_batch(u, u);
         t = ev_.add_batch(t, t);
         for (size_t k = 0; k < t.size(); ++k) u[k] = ev_.add_real(t[k], -1.0);

@@ -21,6 +21,7 @@ Composite::Composite(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {
     if (const char* e = std::getenv("FHELIN_FUSE_RELARGE")) fuse_relarge = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_BULK_UNWRAP")) bulk_unwrap = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_MERGED_RESCALE")) ev_.merged_rescale = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FHELIN_MERGED_PRODUCTS")) ev_.merged_products = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_CHEB_LEAF_AT")) ev_.cheb_leaf_at_product = std::atoi(e) != 0;
     if (const char* b = std::getenv("FHELIN_BATCH")) {
         int v = std::atoi(b);

@@ -338,7 +338,7 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
         if (ell >= 2 && K >= 1) {   // ModDown + rescale in one conversion: drop B = (p_0..p_{k-1}, q_{ell-1})
             const u64 ql = chain.q[ell - 1];
             const int e1 = ell - 1;
-            std::vector<u64> mhi(2 * (K + 1)), mhm((size_t)(K + 1) * e1), minv(2 * e1);
+            std::vector<u64> mhi(2 * (K + 1)), mhm((size_t)(K + 1) * e1), minv(2 * e1), mmod(e1);
             for (int j = 0; j <= K; ++j) {
                 const u64 b = j < K ? chain.p[j] : ql;
                 const u64 hat_b = j < K ? h_mulmod(prod_mod(chain.p, j, b), ql % b, b) : prod_mod(chain.p, -1, b);
@@ -352,13 +352,15 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
             }
             for (int t = 0; t < e1; ++t) {
                 const u64 qt = chain.q[t];
-                const u64 inv = h_invmod(h_mulmod(prod_mod(chain.p, -1, qt), ql % qt, qt), qt);
+                mmod[t] = h_mulmod(prod_mod(chain.p, -1, qt), ql % qt, qt);
+                const u64 inv = h_invmod(mmod[t], qt);
                 minv[2 * t] = inv;
                 minv[2 * t + 1] = h_shoup(inv, qt);
             }
             lt.md_hatinv = upload_table(mhi);
             lt.md_hatmod = upload_table(mhm);
             lt.md_minv = upload_table(minv);
+            lt.md_mmod = upload_table(mmod);
         }
     }
 }

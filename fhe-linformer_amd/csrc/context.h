@@ -84,6 +84,7 @@ struct LevelTables {
     const u64* md_hatinv = nullptr;   // [k+1][2]      (M/b)^{-1} mod b, shoup
     const u64* md_hatmod = nullptr;   // [k+1][ell-1]  (M/b) mod q_t, pre-split (pack30)
     const u64* md_minv = nullptr;     // [ell-1][2]    M^{-1} mod q_t, shoup
+    const u64* md_mmod = nullptr;     // [ell-1]       M mod q_t (the centred conversion takes one off per source above b/2)
 };
 
 // host-side operation counters (bench.py scales the CPU baseline sample with these)

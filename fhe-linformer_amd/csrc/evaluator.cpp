@@ -478,7 +478,7 @@ std::vector<CtPtr> Evaluator::hoisted_dot_rows(const std::vector<CtPtr>& xin, co
                 c_.ntt(tb, true);
             }
             conv = c_.dalloc<u64>((size_t)B * 2 * (ell - 1) * N);
-            launch_moddown_rescale_conv(c_.dt, sh, conv, accP, top, lt.md_hatinv, lt.md_hatmod, s);
+            launch_moddown_rescale_conv(c_.dt, sh, conv, accP, top, lt.md_hatinv, lt.md_hatmod, lt.md_mmod, s);
             c_.ntt(LimbBatch{conv, B * 2 * (ell - 1), nullptr, 0, ell - 1}, false);
             launch_moddown_rescale_finish(c_.dt, sh, o[0]->d, accQ, conv, lt.md_minv, s);
         }
@@ -1453,6 +1453,122 @@ std::vector<CtPtr> Evaluator::mult_batch(const std::vector<CtPtr>& a, const std:
         }
     }
     launch_ok("mult_batch");
+    return out;
+}
+
+std::vector<CtPtr> Evaluator::mult_affine_rescale_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b, int f, double cadd,
+                                                        const std::vector<CtPtr>& sub) {
+    if (a.size() != b.size() || (!sub.empty() && sub.size() != a.size())) throw Error(FHELIN_ERR_ARG, "mult_affine_rescale_batch: operand count mismatch");
+    if (f != 1 && f != 2) throw Error(FHELIN_ERR_ARG, "mult_affine_rescale_batch: factor 1 or 2");
+    if (!relin_key) throw Error(FHELIN_ERR_KEY, "no relinearisation key (EvalMultKeyGen not called)");
+    if (c_.K < 1 || c_.K + 1 > 16) throw Error(FHELIN_ERR_STATE, "mult_affine_rescale_batch: 1..15 special primes");
+    const size_t n = a.size();
+    // operands exactly as mult_batch takes them: degree 2 rescaled first (every distinct ciphertext once), pairs brought to one level
+    std::vector<CtPtr> in;
+    std::map<const Ciphertext*, size_t> slot;
+    for (const auto* side : {&a, &b})
+        for (const CtPtr& c : *side) {
+            if (c->npoly != 2) throw Error(FHELIN_ERR_STATE, "mult: operands must have 2 components");
+            if (c->deg >= 2 && !slot.count(c.get())) {
+                slot[c.get()] = in.size();
+                in.push_back(c);
+            }
+        }
+    std::vector<CtPtr> resc = in.empty() ? std::vector<CtPtr>() : rescale_batch(in);
+    auto ready = [&](const CtPtr& c) { return c->deg >= 2 ? resc[slot[c.get()]] : c; };
+    std::vector<CtPtr> x(n), y(n), out(n);
+    for (size_t i = 0; i < n; ++i) match(ready(a[i]), ready(b[i]), x[i], y[i]);
+    const size_t N = c_.N;
+    const int K = c_.K, L1 = c_.L + 1;
+    hipStream_t s = c_.stream;
+    std::vector<char> done(n, 0);
+    for (size_t first = 0; first < n; ++first) {
+        if (done[first]) continue;
+        std::vector<size_t> idx;
+        for (size_t i = first; i < n && (int)idx.size() < batch_limit; ++i)
+            if (!done[i] && x[i]->ell == x[first]->ell && fabsl(x[i]->scale * y[i]->scale / (x[first]->scale * y[first]->scale) - 1.0L) < 1e-12L)
+                idx.push_back(i);
+        const int B = (int)idx.size(), ell = x[first]->ell;
+        if (ell < 2) throw Error(FHELIN_ERR_STATE, "mult_affine_rescale_batch: no limb left to drop");
+        const size_t pn = (size_t)ell * N;
+        const long double sc = x[first]->scale * y[first]->scale;
+        const LevelTables& lt = c_.lvl[ell];
+        const int nt = ell + K;
+        std::vector<CtPtr> d = new_ct_batch(B, 3, ell, 2, 0, x[first]->slots);   // tensor products, contiguous [B][3][ell][N]
+        for (int k0 = 0; k0 < B; k0 += EwItems::MAX_ITEMS) {
+            EwItems it;
+            it.n = std::min(B - k0, (int)EwItems::MAX_ITEMS);
+            for (int k = 0; k < it.n; ++k) {
+                it.out[k] = d[k0 + k]->d;
+                it.a[k] = x[idx[k0 + k]]->d;
+                it.b[k] = y[idx[k0 + k]]->d;
+            }
+            launch_tensor_items(c_.dt, it, ell, s);
+        }
+        // the subtrahends at the products' (limbs, degree 2, scale), in one block
+        std::vector<CtPtr> sadj;
+        if (!sub.empty()) {
+            for (int k = 0; k < B; ++k) sadj.push_back(adjust(sub[idx[k]], ell, 2, sc));
+            sadj = make_contiguous(sadj, 7);
+        }
+        ScalarSet cst;
+        if (cadd != 0.0) real_to_scalars(c_, (long double)cadd * sc, ell, cst);
+        // key switch of d2 up to the accumulator
+        KsShape sh{ell, K, c_.alpha, lt.beta, L1, B, 3 * pn, (size_t)2 * (ell - 1) * N, pn, 0};
+        c_.stats.keyswitch += (u64)B;
+        c_.stats.keyswitch_limbs += (u64)B * ell;
+        c_.stats.rescale += (u64)B;
+        c_.stats.rescale_limbs += (u64)B * ell;
+        const u64* c_ntt = d[0]->d + 2 * pn;
+        u64* cc = c_.dalloc<u64>((size_t)B * ell * N);
+        {
+            LimbBatch ib{cc, B * ell, nullptr, 0, ell, c_ntt};
+            if (B > 1) {
+                ib.src_group = ell;
+                ib.src_group_stride = 3 * pn;
+            }
+            c_.ntt(ib, true);
+        }
+        u64* ext = c_.dalloc<u64>((size_t)B * lt.beta * nt * N);
+        launch_modup_conv(c_.dt, sh, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod, s);
+        LimbBatch eb{ext, B * lt.beta * nt, lt.ext_limb_tab, 0, 1};
+        eb.tab_len = lt.beta * nt;
+        eb.lazy_out = true;
+        c_.ntt(eb, false, B * (lt.beta * nt - ell));
+        u64* accQ = c_.dalloc<u64>((size_t)B * 2 * ell * N);
+        u64* accP = c_.dalloc<u64>((size_t)B * 2 * K * N);
+        launch_ks_inner(c_.dt, sh, accQ, accP, ext, relin_key->d, c_ntt, s);
+        // X_Q = f acc_Q + P (f (d0, d1) + constant - subtrahend),  X_P = f acc_P
+        launch_affine_acc(c_.dt, sh, accQ, d[0]->d, sadj.empty() ? nullptr : sadj[0]->d, cst, cadd != 0.0 ? 1 : 0, f, c_.d_pmod, s);
+        if (f == 2) launch_ew_add(c_.dt, accP, accP, accP, B * 2 * K, B * 2 * K, L1, K, s);
+        // P and the top limb dropped together
+        c_.ntt(LimbBatch{accP, B * 2 * K, nullptr, L1, K}, true);
+        u64* top = c_.dalloc<u64>((size_t)B * 2 * N);
+        {
+            LimbBatch tb{top, B * 2, nullptr, ell - 1, 1, accQ + (size_t)(ell - 1) * N};
+            tb.src_group = 1;
+            tb.src_group_stride = pn;
+            c_.ntt(tb, true);
+        }
+        u64* conv = c_.dalloc<u64>((size_t)B * 2 * (ell - 1) * N);
+        launch_moddown_rescale_conv(c_.dt, sh, conv, accP, top, lt.md_hatinv, lt.md_hatmod, lt.md_mmod, s);
+        c_.ntt(LimbBatch{conv, B * 2 * (ell - 1), nullptr, 0, ell - 1}, false);
+        std::vector<CtPtr> o = new_ct_batch(B, 2, ell - 1, 1, 0, x[first]->slots);
+        launch_moddown_rescale_finish(c_.dt, sh, o[0]->d, accQ, conv, lt.md_minv, s);
+        launch_ok("mult_affine_rescale_batch");
+        c_.pool.free(cc);
+        c_.pool.free(ext);
+        c_.pool.free(accQ);
+        c_.pool.free(accP);
+        c_.pool.free(top);
+        c_.pool.free(conv);
+        for (int k = 0; k < B; ++k) {
+            const size_t i = idx[k];
+            o[k]->scale = x[i]->scale * y[i]->scale / (long double)c_.chain.q[ell - 1];
+            out[i] = o[k];
+            done[i] = 1;
+        }
+    }
     return out;
 }
 

@@ -75,6 +75,9 @@ struct EvalKey {
 };
 typedef std::shared_ptr<EvalKey> KeyPtr;
 
+// round(v) (half away from zero, 80-bit v) modulo the first ell limbs, with Shoup companions (polyeval.cpp)
+void real_to_scalars(const Context& c, long double v, int ell, ScalarSet& sc);
+
 class Evaluator {
 public:
     explicit Evaluator(Context& c) : c_(c) {}
@@ -137,6 +140,11 @@ public:
     // function from hoisted_dot_rows + rescale (one rounding instead of two), same value up to rounding noise.
     std::vector<CtPtr> hoisted_dot_rows(const std::vector<CtPtr>& xs, const std::vector<PtPtr>& pts, const std::vector<int>& indices,
                                         bool rescale_out = false);
+    // the power steps of a Chebyshev evaluation and EvalMod's double angle through mult_affine_rescale_batch.  OFF by default
+    // (FHELIN_MERGED_PRODUCTS=1 turns it on): measured at no gain (282.0 vs 281.2 ms per pass: the launches it saves are replaced by its
+    // own) and at 3 x the logit error (0.017 vs 0.006: the merged conversion's rounding has three times the standard deviation of a
+    // centred rescale, and these chains are where rounding noise is amplified) - DESIGN.md 6c
+    bool merged_products = false;
     bool merged_rescale = true; // results that are rescaled right after their key switch drop P and the top limb in one conversion; FHELIN_MERGED_RESCALE=0: ModDown, then rescale
     bool double_hoist = true;   // Composite::matmulRElarge takes its first step through hoisted_dot_rows; FHELIN_DOUBLE_HOIST=0: rotate_each_sum_rows
     struct FoldedKey {
@@ -193,6 +201,14 @@ public:
     std::vector<CtPtr> sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b);        // a[i] - b[i]
     // a[i] * b[i] with relinearisation: one batched key switch (shared relin key) per chunk of rows
     std::vector<CtPtr> mult_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b);
+    // rescale(f * a[i] * b[i] + cadd - sub[i]) (f = 1 or 2; sub empty = none): relinearised products that are rescaled right away - the
+    // power steps T_2k = 2 T_k^2 - 1, T_(j+k) = 2 T_j T_k - T_(j-k) of a Chebyshev evaluation, EvalMod's double angle.  Operands as in
+    // mult_batch; the constant and the subtrahend (adjusted to the product's limbs / degree 2 / scale) enter the key switch's
+    // accumulator times P, and ModDown and rescale run as ONE basis conversion: 2 ell fewer transforms and five fewer launches per
+    // product than mult_batch, add_batch, add_real / sub_batch, rescale_batch.  One rounding where those have two (oracle:
+    // orc_mult_affine_rescale).  Output: degree 1, one limb fewer, scale a.scale * b.scale / q_top.
+    std::vector<CtPtr> mult_affine_rescale_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b, int f, double cadd,
+                                                 const std::vector<CtPtr>& sub);
     // the same Chebyshev series on several ciphertexts at once: every product of the evaluation runs as mult_batch over
     // all ciphertexts AND all independent nodes of the same depth (baby powers of one doubling round)
     std::vector<CtPtr> eval_chebyshev_many(const std::vector<CtPtr>& xs, const std::vector<double>& coeffs, double a, double b);

@@ -183,13 +183,23 @@ void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, co
                          hipStream_t s);
 // ModDown and rescale as ONE basis conversion: with B = (p_0..p_{k-1}, q_{ell-1}), M = P q_{ell-1} and X the accumulator over
 // (q_0..q_{ell-1}, p_0..p_{k-1}):      out_t = (X_t - sum_{b in B} [X_b (M/b)^{-1}]_b [(M/b)]_t) M^{-1}  mod q_t,   t < ell - 1
-// (no centring, like K8).  A key switch whose result is rescaled right away then costs 2(k+1) inverse and 2(ell-1) forward transforms
+// with the sources y_b = [X_b (M/b)^{-1}]_b taken CENTRED (y_b - b above b/2; mmod[t] = M mod q_t comes off once per such source): the
+// conversion then misses round(X / M) by an integer of mean zero and |u| <= (k+1)/2 - without centring every coefficient would carry
+// a common offset of ~ -(k+1)/2 at the result's own scale, which the slots next to the root of unity 1 see N/pi-fold (K8's own
+// non-centred error is divided away by the rescale that follows it; here nothing follows).  A key switch whose result is rescaled right away then costs 2(k+1) inverse and 2(ell-1) forward transforms
 // where ModDown + rescale cost 2k + 2 inverse and 2 ell + 2(ell-1) forward ones.  Addends that do not pass through the key switch must
 // be in X already (multiplied by P: HoistAdd::acc).
 //   conv:   accP [batch][2][k][N] and top [batch][2][N] (= X mod q_{ell-1}) in coefficient form -> conv [batch][2][ell-1][N] (coefficient form)
 //   finish: out [batch][2][ell-1][N] = (accQ[.][.][t] - NTT(conv)) * minv_t      (accQ [batch][2][ell][N]; sh.out_stride per batch row)
+// A relinearised product that is rescaled right away (Evaluator::mult_affine_rescale_batch): what does not pass through the key switch
+// enters the accumulator's Q part times P, so that ModDown and rescale can be one conversion:
+//     accQ[b][c][t] = f * accQ[b][c][t] + pmod_t * (f * d[b][c][t] + (c == 0 ? cst_t : 0) - sub[b][c][t])        f = 1 or 2
+// d: the tensor block [batch][3][ell][N] (components 0, 1 are read); sub: [batch][2][ell][N] or null; cst: per-limb constants
+// (ScalarSet::v[2 t]) or has_cst = 0.  The special limbs of the accumulator are scaled by f separately (launch_ew_add).
+void launch_affine_acc(const DeviceTables& t, const KsShape& sh, u64* accQ, const u64* d, const u64* sub, const ScalarSet& cst, int has_cst, int f,
+                       const u64* pmod, hipStream_t s);
 void launch_moddown_rescale_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* top, const u64* hatinv,
-                                 const u64* hatmod, hipStream_t s);
+                                 const u64* hatmod, const u64* mmod, hipStream_t s);
 void launch_moddown_rescale_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* minv,
                                    hipStream_t s);
 // K8b: out[c][t][j] = (accQ[c][t][m] - conv[c][t][m]) * P^{-1} + add_c[t][m] (+ post[c][t][j]),  m = map ? map[j] : j

@@ -487,23 +487,60 @@ __global__ __launch_bounds__(256) void hoist_addends_kernel(DeviceTables t, KsSh
     reinterpret_cast<u64x2*>(pre + (size_t)bi * 2 * sh.ell * N)[(size_t)v * row + n2] = o;
 }
 
+// grid (N/512, batch * 2 * ell)
+__global__ __launch_bounds__(256) void affine_acc_kernel(DeviceTables t, KsShape sh, u64* __restrict__ accQ, const u64* __restrict__ d,
+                                                         const u64* __restrict__ sub, ScalarSet cst, int has_cst, int f, const u64* __restrict__ pmod) {
+    const int bi = blockIdx.y / (2 * sh.ell), v = blockIdx.y % (2 * sh.ell);
+    const int c = v / sh.ell, tt = v % sh.ell;
+    const u64 q = t.moduli[tt];
+    const size_t row = ((size_t)1 << t.log_n) >> 1;
+    const size_t n2 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    u64x2 x = reinterpret_cast<const u64x2*>(d)[((size_t)bi * 3 * sh.ell + v) * row + n2];
+    if (f == 2) {
+        x.x = add_mod(x.x, x.x, q);
+        x.y = add_mod(x.y, x.y, q);
+    }
+    if (has_cst && c == 0) {
+        x.x = add_mod(x.x, cst.v[2 * tt], q);
+        x.y = add_mod(x.y, cst.v[2 * tt], q);
+    }
+    if (sub) {
+        const u64x2 sv = reinterpret_cast<const u64x2*>(sub)[((size_t)bi * 2 * sh.ell + v) * row + n2];
+        x.x = sub_mod(x.x, sv.x, q);
+        x.y = sub_mod(x.y, sv.y, q);
+    }
+    u64x2* A = reinterpret_cast<u64x2*>(accQ) + ((size_t)bi * 2 * sh.ell + v) * row + n2;
+    u64x2 a = *A;
+    if (f == 2) {
+        a.x = add_mod(a.x, a.x, q);
+        a.y = add_mod(a.y, a.y, q);
+    }
+    const u64 w = pmod[2 * tt], ws = pmod[2 * tt + 1];
+    a.x = add_mod(a.x, mul_shoup(x.x, w, ws, q), q);
+    a.y = add_mod(a.y, mul_shoup(x.y, w, ws, q), q);
+    *A = a;
+}
+
 // ModDown + rescale, conversion (launch_moddown_rescale_conv): grid (N/256, batch * 2, ceil((ell-1)/TCH)); sources = the k special
 // limbs of accP and the top Q limb (coefficient form), targets t < ell - 1
 __global__ __launch_bounds__(256) void moddown_rescale_conv_kernel(DeviceTables t, KsShape sh, u64* __restrict__ conv, const u64* __restrict__ accP,
                                                                    const u64* __restrict__ top, const u64* __restrict__ hatinv,
-                                                                   const u64* __restrict__ hatmod) {
+                                                                   const u64* __restrict__ hatmod, const u64* __restrict__ mmod) {
     constexpr int MAXS = 16;
     const int bi = blockIdx.y >> 1, c = blockIdx.y & 1;
     const size_t N = (size_t)1 << t.log_n;
     const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int e1 = sh.ell - 1, ns = sh.k + 1;
     u32 z0[MAXS], z1[MAXS];
+    u32 neg = 0;        // sources taken as y_b - b (centred conversion)
 #pragma unroll
     for (int p = 0; p < MAXS; ++p) {
         if (p < ns) {
             const u64 x = p < sh.k ? accP[(((size_t)bi * 2 + c) * sh.k + p) * N + n] : top[((size_t)bi * 2 + c) * N + n];
             const u64 m = t.moduli[p < sh.k ? sh.L1 + p : sh.ell - 1];
-            split30(mul_shoup(x, hatinv[2 * p], hatinv[2 * p + 1], m), z0[p], z1[p]);
+            const u64 y = mul_shoup(x, hatinv[2 * p], hatinv[2 * p + 1], m);
+            neg += y > (m >> 1);
+            split30(y, z0[p], z1[p]);
         } else {
             z0[p] = z1[p] = 0;
         }
@@ -524,7 +561,7 @@ __global__ __launch_bounds__(256) void moddown_rescale_conv_kernel(DeviceTables 
                 }
             acc30_flush(acc, slo, shi);
         }
-        dst[(size_t)tt * N] = barrett_reduce128(slo, shi, br);
+        dst[(size_t)tt * N] = sub_mod(barrett_reduce128(slo, shi, br), barrett_reduce128((u64)neg * mmod[tt], 0, br), br.q);
     }
 }
 
@@ -555,10 +592,15 @@ void launch_hoist_addends(const DeviceTables& t, const KsShape& sh, const HoistA
     hipLaunchKernelGGL(hoist_addends_kernel, dim3((1u << t.log_n) / 512, (unsigned)(sh.batch * 2 * sh.ell)), dim3(256), 0, s, t, sh, h, pre, ct);
 }
 
+void launch_affine_acc(const DeviceTables& t, const KsShape& sh, u64* accQ, const u64* d, const u64* sub, const ScalarSet& cst, int has_cst, int f,
+                       const u64* pmod, hipStream_t s) {
+    hipLaunchKernelGGL(affine_acc_kernel, dim3((1u << t.log_n) / 512, (unsigned)(sh.batch * 2 * sh.ell)), dim3(256), 0, s, t, sh, accQ, d, sub, cst,
+                       has_cst, f, pmod);
+}
 void launch_moddown_rescale_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* top, const u64* hatinv,
-                                 const u64* hatmod, hipStream_t s) {
+                                 const u64* hatmod, const u64* mmod, hipStream_t s) {
     dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * 2), (unsigned)((sh.ell - 1 + TCH - 1) / TCH));
-    hipLaunchKernelGGL(moddown_rescale_conv_kernel, g, dim3(256), 0, s, t, sh, conv, accP, top, hatinv, hatmod);
+    hipLaunchKernelGGL(moddown_rescale_conv_kernel, g, dim3(256), 0, s, t, sh, conv, accP, top, hatinv, hatmod, mmod);
 }
 void launch_moddown_rescale_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* minv,
                                    hipStream_t s) {

@@ -8,7 +8,7 @@
 
 namespace fhelin {
 
-static void real_to_scalars(const Context& c, long double v, int ell, ScalarSet& sc) {
+void real_to_scalars(const Context& c, long double v, int ell, ScalarSet& sc) {
     const bool neg = v < 0;
     const long double mag = roundl(fabsl(v));
     const long double two64 = 18446744073709551616.0L;
@@ -326,26 +326,56 @@ std::vector<CtPtr> Evaluator::eval_chebyshev_many(const std::vector<CtPtr>& xs, 
                 lhs.push_back(T[k / 2][i]);
                 rhs.push_back(T[k - k / 2][i]);
             }
-        CtRow t = mult_batch(lhs, rhs);
-        t = add_batch(t, t);
-        CtRow odd_a, odd_b;
-        std::vector<size_t> odd_pos;
+        CtRow t;
         size_t p = 0;
-        for (int k = h + 1; k <= k_hi; ++k)
-            for (size_t i = 0; i < rows; ++i, ++p) {
-                if (k % 2 == 0) {
-                    t[p] = add_real(t[p], -1.0);
-                } else {
-                    odd_a.push_back(t[p]);
-                    odd_b.push_back(T[1][i]);
-                    odd_pos.push_back(p);
+        if (merged_products) {
+            // rescale(2 T_j T_k - 1) / rescale(2 T_j T_k - T_1) in one go each (mult_affine_rescale_batch): the even and the odd powers of
+            // the round as one batched call each
+            CtRow ea, eb, oa, ob, osub;
+            std::vector<size_t> epos, opos;
+            for (int k = h + 1; k <= k_hi; ++k)
+                for (size_t i = 0; i < rows; ++i, ++p) {
+                    if (k % 2 == 0) {
+                        ea.push_back(lhs[p]);
+                        eb.push_back(rhs[p]);
+                        epos.push_back(p);
+                    } else {
+                        oa.push_back(lhs[p]);
+                        ob.push_back(rhs[p]);
+                        osub.push_back(T[1][i]);
+                        opos.push_back(p);
+                    }
                 }
+            t.resize(lhs.size());
+            if (!ea.empty()) {
+                CtRow r = mult_affine_rescale_batch(ea, eb, 2, -1.0, {});
+                for (size_t j = 0; j < epos.size(); ++j) t[epos[j]] = r[j];
             }
-        if (!odd_a.empty()) {
-            CtRow d = sub_batch(odd_a, odd_b);
-            for (size_t j = 0; j < odd_pos.size(); ++j) t[odd_pos[j]] = d[j];
+            if (!oa.empty()) {
+                CtRow r = mult_affine_rescale_batch(oa, ob, 2, 0.0, osub);
+                for (size_t j = 0; j < opos.size(); ++j) t[opos[j]] = r[j];
+            }
+        } else {
+            t = mult_batch(lhs, rhs);
+            t = add_batch(t, t);
+            CtRow odd_a, odd_b;
+            std::vector<size_t> odd_pos;
+            for (int k = h + 1; k <= k_hi; ++k)
+                for (size_t i = 0; i < rows; ++i, ++p) {
+                    if (k % 2 == 0) {
+                        t[p] = add_real(t[p], -1.0);
+                    } else {
+                        odd_a.push_back(t[p]);
+                        odd_b.push_back(T[1][i]);
+                        odd_pos.push_back(p);
+                    }
+                }
+            if (!odd_a.empty()) {
+                CtRow d = sub_batch(odd_a, odd_b);
+                for (size_t j = 0; j < odd_pos.size(); ++j) t[odd_pos[j]] = d[j];
+            }
+            t = rescale_batch(t);
         }
-        t = rescale_batch(t);
         p = 0;
         for (int k = h + 1; k <= k_hi; ++k) {
             T[k].resize(rows);
@@ -355,6 +385,10 @@ std::vector<CtPtr> Evaluator::eval_chebyshev_many(const std::vector<CtPtr>& xs, 
     std::map<int, CtRow> G;
     G[baby] = T[baby];
     for (int m = baby; m * 2 <= n; m *= 2) {
+        if (merged_products) {
+            G[2 * m] = mult_affine_rescale_batch(G[m], G[m], 2, -1.0, {});
+            continue;
+        }
         CtRow t = mult_batch(G[m], G[m]);
         t = add_batch(t, t);
         for (size_t i = 0; i < rows; ++i) t[i] = add_real(t[i], -1.0);

@@ -65,6 +65,7 @@ def _load(name):
             "orc_rotate_sum": (None, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
             "orc_rotate_each_sum": (None, [vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
             "orc_dot": (None, [vp, vp, i32, vp, i32, i32, vp]),
+            "orc_mult_affine_rescale": (None, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
             "orc_hoisted_dot": (None, [vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
             "orc_is_fast_build": (i32, []),
             "orc_automorph_coeff": (None, [vp, vp, i32, u64, u64]),
@@ -292,6 +293,21 @@ def hoisted_dot(ct, evks, gs, pts, alpha, q, p, psi_q, psi_p, drop=False):
     out = np.empty((2, ell - 1 if drop else ell, n), dtype=np.uint64)
     lib().orc_hoisted_dot(_p(ct), _p(evks), _p(gs), R, _p(pts), _p(out), int(bool(drop)), ell, len(q), len(p), alpha, int(np.log2(n)),
                           _p(q), _p(p), _p(psi_q), _p(psi_p))
+    return out
+
+
+def mult_affine_rescale(a, b, evk, f, addq, alpha, q, p, psi_q, psi_p):
+    """rescale(f * EvalMult(a, b) + addq) with ModDown and rescale as one basis conversion; a, b [2][ell][N]; addq [2][ell][N] or None
+    -> [2][ell-1][N]"""
+    a, b, evk, q, p, psi_q, psi_p = _u(a), _u(b), _u(evk), _u(q), _u(p), _u(psi_q), _u(psi_p)
+    _, ell, n = a.shape
+    assert b.shape == a.shape and f in (1, 2) and ell >= 2
+    if addq is not None:
+        addq = _u(addq)
+        assert addq.shape == a.shape
+    out = np.empty((2, ell - 1, n), dtype=np.uint64)
+    lib().orc_mult_affine_rescale(_p(a), _p(b), _p(evk), int(f), _p(addq) if addq is not None else None, _p(out), ell, len(q), len(p), alpha,
+                                  int(np.log2(n)), _p(q), _p(p), _p(psi_q), _p(psi_p))
     return out
 
 

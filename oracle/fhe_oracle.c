@@ -591,7 +591,13 @@ static void ks_moddown(const ks_par* P, u64* acc, u64* out) {
 
 /* ModDown and rescale as ONE basis conversion (csrc/kernels_elem.h launch_moddown_rescale_conv).  acc [2][ell+k][N] NTT form
  * (destroyed) -> out [2][ell-1][N].  The dropped basis is B = (p_0..p_{k-1}, q_{ell-1}), M = P q_{ell-1}:
- *     out_t = (acc_t - sum_{b in B} [acc_b * (M/b)^{-1}]_b * [(M/b)]_t) * M^{-1}  mod q_t,   t < ell-1     (no centring) */
+ *     y_b   = [acc_b * (M/b)^{-1}]_b, taken CENTRED: y_b - b where y_b > floor(b/2)
+ *     out_t = (acc_t - sum_{b in B} y_b * [(M/b)]_t) * M^{-1}  mod q_t,   t < ell-1.
+ * With centred y_b the sum is X_c + u M for the centred residue X_c of X mod M and an integer |u| <= (k+1)/2 of mean zero, so the
+ * result is round(X / M) - u: an UNBIASED error of a few units.  (Non-centred y_b - as in ks_moddown, whose error is divided away by the
+ * rescale that follows it - would put a common offset of about -(k+1)/2 on every coefficient here, at the rescaled ciphertext's own
+ * scale: a polynomial with all coefficients equal evaluates to ~N/pi of them in the slots next to the root of unity 1, which EvalMod
+ * and the degree-300 tanh amplify into the logits - measured, round 3.) */
 static void ks_moddown_rescale(const ks_par* P, u64* acc, u64* out) {
     size_t n = (size_t)1 << P->log_n;
     int ell = P->ell, k = P->k, nt = ell + k, e1 = ell - 1, nb = k + 1;
@@ -615,11 +621,17 @@ static void ks_moddown_rescale(const ks_par* P, u64* acc, u64* out) {
             const modq mt = mq_make(qt);
             u64 hmod[65];
             for (int j = 0; j < nb; ++j) hmod[j] = prodmod_skip(bm, 0, nb, j, qt);
+            u64 mmod = prodmod_skip(bm, 0, nb, -1, qt);      /* M mod q_t: one of it comes off per source taken as y_b - b */
             u64* conv = malloc(8 * n);
             for (size_t x = 0; x < n; ++x) {
                 u128 s = 0;
-                for (int j = 0; j < nb; ++j) s += (u128)mq_red((u128)a[(size_t)(j < k ? ell + j : e1) * n + x], &mt) * hmod[j];
-                conv[x] = mq_red(s, &mt);
+                u64 neg = 0;
+                for (int j = 0; j < nb; ++j) {
+                    u64 y = a[(size_t)(j < k ? ell + j : e1) * n + x];
+                    neg += y > (bm[j] >> 1);
+                    s += (u128)mq_red((u128)y, &mt) * hmod[j];
+                }
+                conv[x] = submod(mq_red(s, &mt), mq_red((u128)neg * mmod, &mt), qt);
             }
             orc_ntt_forward(conv, P->log_n, qt, P->psi_q[t]);
             u64 minv = invmod(prodmod_skip(bm, 0, nb, -1, qt), qt);
@@ -819,6 +831,58 @@ void orc_mult_relin(const u64* a, const u64* b, const u64* evk, u64* out, int el
     orc_add(out + pn, t, out + pn, ell, log_n, q);
     orc_add(out + pn, ks + pn, out + pn, ell, log_n, q);
     free(d2); free(t); free(ks);
+}
+
+/* rescale(f * EvalMult(a, b) + addq) with ModDown and rescale as ONE conversion (Evaluator::mult_affine_rescale_batch: the power
+ * steps T_2k = 2 T_k^2 - 1, T_(a+b) = 2 T_a T_b - T_(a-b) of a Chebyshev evaluation and EvalMod's double-angle steps):
+ *     acc   = sum_j ModUp_j(a1 b1) * evk_j                                  over (q_0..q_{ell-1}, p_0..p_{k-1})
+ *     X_Q   = f * acc_Q + P * (f * (a0 b0, a0 b1 + a1 b0) + addq),   X_P = f * acc_P
+ *     out   = ModDownRescale(X)                                             [2][ell-1][N]  (ks_moddown_rescale)
+ * a, b: [2][ell][N]; addq: [2][ell][N] or NULL (the addend in the Q basis at the product's scale: a constant on component 0, or
+ * minus a level-adjusted ciphertext); f = 1 or 2. */
+void orc_mult_affine_rescale(const u64* a, const u64* b, const u64* evk, int f, const u64* addq, u64* out, int ell, int L1, int k, int alpha,
+                             int log_n, const u64* q, const u64* p, const u64* psi_q, const u64* psi_p) {
+    const ks_par P = {ell, L1, k, alpha, log_n, q, p, psi_q, psi_p};
+    size_t n = (size_t)1 << log_n, pn = n * ell;
+    int nt = ell + k;
+    u64* d = malloc(8 * pn * 3);     /* d0, d1, d2 */
+    u64* t = malloc(8 * pn);
+    orc_mul(a, b, d, ell, log_n, q);
+    orc_mul(a, b + pn, d + pn, ell, log_n, q);
+    orc_mul(a + pn, b, t, ell, log_n, q);
+    orc_add(d + pn, t, d + pn, ell, log_n, q);
+    orc_mul(a + pn, b + pn, d + 2 * pn, ell, log_n, q);
+    free(t);
+    ks_tabs(&P);
+    u64* dig = malloc(8 * n * nt * ks_beta(&P));
+    ks_modup(&P, d + 2 * pn, dig);
+    u64* acc = calloc((size_t)2 * nt * n, 8);
+    ks_inner_acc(&P, dig, evk, acc, 0);
+    free(dig);
+    for (int c = 0; c < 2; ++c) {
+        #pragma omp parallel for schedule(static)
+        for (int tt = 0; tt < nt; ++tt) {
+            u64 m = ks_mod(&P, tt);
+            const modq mm = mq_make(m);
+            u64* x = acc + ((size_t)c * nt + tt) * n;
+            if (tt >= ell) {
+                if (f == 2) for (size_t i = 0; i < n; ++i) x[i] = addmod(x[i], x[i], m);
+                continue;
+            }
+            u64 pm = prodmod_skip(p, 0, k, -1, m);
+            const u64* dc = d + ((size_t)c * ell + tt) * n;
+            const u64* ad = addq ? addq + ((size_t)c * ell + tt) * n : 0;
+            for (size_t i = 0; i < n; ++i) {
+                u64 v = f == 2 ? addmod(dc[i], dc[i], m) : dc[i];
+                if (ad) v = addmod(v, ad[i], m);
+                u64 xa = f == 2 ? addmod(x[i], x[i], m) : x[i];
+                x[i] = addmod(xa, mq_mul(v, pm, &mm), m);
+            }
+        }
+    }
+    free(d);
+    ks_moddown_rescale(&P, acc, out);
+    free(acc);
 }
 
 int orc_is_fast_build(void) {

@@ -118,6 +118,9 @@ class ResidueBootstrapper:
         rev = self.rev
         u = rev.eval_chebyshev(x, self.desc["cheb"], -1.0, 1.0)
         for _ in range(self.desc["R"]):
+            if rev.merged_products:          # 2 u^2 - 1 rescaled at once (Evaluator::mult_affine_rescale_batch)
+                u = rev.mult_affine_rescale(u, u, 2, -1.0)
+                continue
             t = rev.mult(u, u)
             t = rev.add(t, t)
             u = rev.add_real(t, -1.0)

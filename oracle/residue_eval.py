@@ -224,6 +224,30 @@ class ResidueEvaluator:
         d = orc.mult_relin(x.d, y.d, self.keys["relin"], self.alpha, self.q, self.p, self.psi_q, self.psi_p)
         return RCt(d, x.deg + y.deg, x.scale * y.scale)
 
+    merged_products = False     # Evaluator::merged_products (FHELIN_MERGED_PRODUCTS=1, off by default): the power steps of a Chebyshev
+                                # evaluation / EvalMod's double angle through mult_affine_rescale
+
+    def mult_affine_rescale(self, a, b, f, cadd=0.0, sub=None):
+        """rescale(f * mult(a, b) + cadd - sub) as Evaluator::mult_affine_rescale_batch runs it: operands as in mult(); the constant is
+        round(cadd * scale) on component 0 and `sub` is adjusted to the product's (limbs, degree 2, scale), both at the product's
+        scale a.scale * b.scale; they enter the key switch's accumulator times P and ModDown + rescale are ONE conversion
+        (orc_mult_affine_rescale).  One rounding where mult / add / rescale have two."""
+        x = self.rescale(a) if a.deg >= 2 else a
+        y = x if b is a else (self.rescale(b) if b.deg >= 2 else b)
+        x, y = self.match(x, y)
+        sc = x.scale * y.scale
+        ql = self.q[:x.ell]
+        addq = None
+        if sub is not None:
+            s_adj = self.adjust(sub, x.ell, 2, sc)
+            addq = np.stack([orc.sub(np.zeros_like(s_adj.d[c]), s_adj.d[c], ql) for c in range(2)])
+        if cadd != 0.0:
+            if addq is None:
+                addq = np.zeros_like(x.d)
+            addq[0] = orc.add_scalar(addq[0], self.real_scalars(LD(cadd) * sc, x.ell), ql)
+        d = orc.mult_affine_rescale(x.d, y.d, self.keys["relin"], f, addq, self.alpha, self.q, self.p, self.psi_q, self.psi_p)
+        return RCt(d, 1, sc / LD(int(self.q[x.ell - 1])))
+
     def real_scalars(self, v, ell):
         """polyeval.cpp real_to_scalars: round(|v|) (half away from zero, 80-bit v) with the sign restored, modulo each limb"""
         k = _llround(v)
@@ -346,6 +370,9 @@ class ResidueEvaluator:
         h = 1
         while h < baby:
             for k in range(h + 1, min(2 * h, baby) + 1):
+                if self.merged_products:
+                    T[k] = self.mult_affine_rescale(T[k // 2], T[k - k // 2], 2, -1.0 if k % 2 == 0 else 0.0, None if k % 2 == 0 else T[1])
+                    continue
                 t = self.mult(T[k // 2], T[k - k // 2])
                 t = self.add(t, t)
                 t = self.add_real(t, -1.0) if k % 2 == 0 else self.sub(t, T[1])
@@ -354,6 +381,10 @@ class ResidueEvaluator:
         G = {baby: T[baby]}
         m = baby
         while m * 2 <= n:
+            if self.merged_products:
+                G[2 * m] = self.mult_affine_rescale(G[m], G[m], 2, -1.0)
+                m *= 2
+                continue
             t = self.mult(G[m], G[m])
             t = self.add_real(self.add(t, t), -1.0)
             G[2 * m] = self.rescale(t)

@@ -82,6 +82,25 @@ def test_chebyshev_evaluation_bit_exact(poly_eng, orc, degree, a, b, ell, deg_in
         assert other.d.shape != want.d.shape or not np.array_equal(other.d, want.d)
 
 
+def test_chebyshev_with_merged_products_bit_exact(fa, orc, monkeypatch):
+    """FHELIN_MERGED_PRODUCTS=1 (off by default: no gain, 3 x the rounding noise - DESIGN.md 6c): the power steps rescale(2 T_j T_k - 1),
+    rescale(2 T_j T_k - T_1) through Evaluator::mult_affine_rescale_batch (constant / level-adjusted subtrahend into the key switch's
+    accumulator times P, ModDown and rescale as one centred conversion) == orc_mult_affine_rescale, composed the same way"""
+    monkeypatch.setenv("FHELIN_MERGED_PRODUCTS", "1")
+    e = fa.Engine("boot12", seed=9)
+    try:
+        relin = _uniform_key(orc, e, 31)
+        e.key_import(0, 0, relin)
+        rev = _rev(e, {"relin": relin})
+        rev.merged_products = True
+        for degree, ell, deg_in in ((31, 10, 2), (47, 12, 1)):
+            coeffs = _cheb_fit(np.sin if degree == 31 else np.cos, -1.0, 1.0, degree)
+            c, r = _pair(e, rev, _uniform_ct(orc, e, 140 + degree, ell), deg_in)
+            _same(e.eval_chebyshev(c, coeffs, -1.0, 1.0), rev.eval_chebyshev(r, coeffs, -1.0, 1.0), ("merged products", degree))
+    finally:
+        e.close()
+
+
 def test_chebyshev_batch_and_sparse_coefficients_bit_exact(poly_eng, orc):
     """fhelin_eval_chebyshev_batch (the GELU containers of one sample, src/main.cpp:354-358) == the single evaluation per row; an odd
     function's fit has zero even coefficients: remainders that are constants / empty take their own paths in the recursion"""

@@ -244,6 +244,44 @@ def test_mult_relin_by_decryption(orc):
     assert max(abs(e) for e in err) < 2 ** 40
 
 
+@pytest.mark.parametrize("f,with_add", [(2, True), (1, False)])
+def test_mult_affine_rescale_is_rescale_of_the_product(orc, f, with_add):
+    """rescale(f * mult_relin(a, b) + add) with ModDown and rescale as ONE conversion (orc_mult_affine_rescale) against the same
+    thing step by step (orc_mult_relin, doubling, addition, orc_rescale): equal up to the roundings of the two conversions, and
+    not the same integer function"""
+    log_n, L1, k, alpha = 12, 4, 2, 2
+    q, p, psi_q, psi_p = _chain(orc, log_n, L1, k)
+    rng = np.random.default_rng(18)
+    n = 1 << log_n
+    s = [int(v) for v in rng.integers(-1, 2, size=n)]
+    s_q = np.array([[v % int(m) for v in s] for m in q], dtype=np.uint64)
+    s_ntt = orc.ntt_batch(s_q, q, psi_q)
+    s2_coeff = orc.ntt_batch(orc.mul(s_ntt, s_ntt, q), q, psi_q, inverse=True)
+    s2 = _crt2(s2_coeff[0], s2_coeff[1], int(q[0]), int(q[1]))
+    evk, _ = _toy_keys(orc, log_n, q, p, psi_q, psi_p, alpha, s2, s, rng)
+    a = np.array([[rng.integers(0, int(m), size=n, dtype=np.uint64) for m in q] for _ in range(2)])
+    b = np.array([[rng.integers(0, int(m), size=n, dtype=np.uint64) for m in q] for _ in range(2)])
+    add = np.array([[rng.integers(0, int(m), size=n, dtype=np.uint64) for m in q] for _ in range(2)]) if with_add else None
+    one = orc.mult_affine_rescale(a, b, evk, f, add, alpha, q, p, psi_q, psi_p)
+    t = orc.mult_relin(a, b, evk, alpha, q, p, psi_q, psi_p)
+    if f == 2:
+        t = np.stack([orc.add(t[c], t[c], q) for c in range(2)])
+    if with_add:
+        t = np.stack([orc.add(t[c], add[c], q) for c in range(2)])
+    two = orc.rescale(t, q, psi_q)
+    assert one.shape == two.shape == (2, L1 - 1, n)
+    q1, p1, s1 = q[:L1 - 1], psi_q[:L1 - 1], s_ntt[:L1 - 1]
+    d = orc.ntt_batch(orc.sub(_phase(orc, one, s1, q1), _phase(orc, two, s1, q1), q1), q1, p1, inverse=True)
+    assert max(abs(e) for e in _crt2(d[0], d[1], int(q1[0]), int(q1[1]))) < 2 ** 20
+    assert not np.array_equal(one, two)
+    # coefficient by coefficient the two differ by a few units of MEAN ZERO (centred conversion): a common offset would be seen
+    # N/pi-fold by the slots next to the root of unity 1
+    for c in range(2):
+        dc = orc.ntt_batch(orc.sub(one[c], two[c], q1), q1, p1, inverse=True)
+        e = np.array(_crt2(dc[0], dc[1], int(q1[0]), int(q1[1])), dtype=np.float64)
+        assert np.max(np.abs(e)) <= (k + 1) // 2 + 2 and abs(np.mean(e)) < 0.1, (np.max(np.abs(e)), np.mean(e))
+
+
 def _rot_keys(orc, log_n, q, p, psi_q, psi_p, alpha, s, rots, rng):
     """rotation keys (s -> sigma_{g^-1}(s)) for every index in rots, stacked [R][dnum][2][L1+k][N]; galois elements"""
     n = 1 << log_n
