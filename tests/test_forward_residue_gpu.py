@@ -26,8 +26,9 @@ def desc_depth(eng):
                                      # level plan - client encryptions at the planned limbs, bootstraps raising to fewer limbs
     pytest.param("reference", False, "main_2", marks=pytest.mark.skipif(
         not __import__("os").environ.get("FHELIN_SLOW_TESTS"),
-        reason="src/main_2.cpp (attention for every token: 11.8 k key switches, +2 minutes of CPU oracle time); last run recorded in "
-               "profiles/r03_u_cpu_forward_pass_main2_n15.json (same residues: true); FHELIN_SLOW_TESTS=1 runs it")),
+        reason="src/main_2.cpp (attention for every token; +2 minutes of CPU oracle time); last runs recorded in "
+               "profiles/r03_u_cpu_forward_pass_main2_n15.json (same residues: true) and, on the final build of round 3, "
+               "profiles/r03_bq_main2_residue_test.txt (1 passed); FHELIN_SLOW_TESTS=1 runs it")),
 ])
 def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc, preset, planned, variant):
     from fhe_linformer_amd import linformer as lf
