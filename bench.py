@@ -615,6 +615,14 @@ def main():
         if oe is not eng:
             oe.close()
 
+    by_batch = None
+    if rank == 0 and args.ntt_batch == 8:
+        # SURVEY 8(d)'s other two batch sizes (one ciphertext; 64), outside the timed regions: the same section, fewer steps
+        by_batch = {"8": round(n_ntt / (ntt_ms * 1e-3), 1)}
+        for bsz, st in ((1, 30), (64, 4)):
+            nb, msb, _, _ = ntt_section(eng, orc, np, bsz, st)
+            by_batch[str(bsz)] = round(nb / (msb * 1e-3), 1)
+
     if rank == 0:
         alg_bytes = 16.0 * eng.N                            # read N + write N u64 per limb-NTT
         achieved = n_ntt * alg_bytes / (ntt_ms * 1e-3) / 1e9
@@ -629,6 +637,7 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "kernel": "ntt_cols_kernel + ntt_rows_kernel (one limb-NTT = one tile pass of each)",
                     "limb_ntt_per_s_per_gpu": round(n_ntt / (ntt_ms * 1e-3), 1),
+                    "limb_ntt_per_s_by_batch_of_ciphertexts": by_batch,
                     "algorithmic_bytes_per_limb_ntt": alg_bytes,
                     "traffic_source": "profiles/r03_pmc_traffic.json: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch / 384 limb vectors, measured in "
                                       "round 3 on these kernels in separate --pmc passes (a static file: the bench run itself does not collect counters)",
