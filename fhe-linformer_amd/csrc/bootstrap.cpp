@@ -434,12 +434,16 @@ std::vector<CtPtr> Bootstrapper::apply_batch(const LinStage& st, const std::vect
     std::vector<CtPtr> slab_plain, slab_rot;
     if (n_plain) slab_plain = ev_.new_ct_batch((int)(B * n_plain), 2, x->ell, 2, 0, x->slots);
     if (G > n_plain) slab_rot = ev_.new_ct_batch((int)(B * (G - n_plain)), 2, x->ell, 2, 0, x->slots);
-    std::vector<std::vector<CtPtr>> rows(B);
-    for (size_t i = 0; i < B; ++i) {
-        std::vector<CtPtr> dest;
+    std::vector<std::vector<CtPtr>> rows(B), dests(B);
+    for (size_t i = 0; i < B; ++i)
         for (size_t k = 0; k < G; ++k)
-            dest.push_back(k < n_plain ? slab_plain[i * n_plain + k] : slab_rot[i * (G - n_plain) + (k - n_plain)]);
-        if (!ev_.dot_plain_groups(brot[i], pts, pt_scale, dest)) {
+            dests[i].push_back(k < n_plain ? slab_plain[i * n_plain + k] : slab_rot[i * (G - n_plain) + (k - n_plain)]);
+    // ONE pass for the whole batch where the operands are equally spaced (they are: the babies come out of one block per index,
+    // the inputs out of one rescale): every diagonal is fetched once for all ciphertexts
+    const bool batched = G <= (size_t)EwDotGroups::MAX_G && ev_.dot_plain_groups_batch(brot, pts, pt_scale, dests);
+    for (size_t i = 0; i < B; ++i) {
+        std::vector<CtPtr>& dest = dests[i];
+        if (!batched && !ev_.dot_plain_groups(brot[i], pts, pt_scale, dest)) {
             for (size_t k = 0; k < G; ++k) {
                 std::vector<CtPtr> cts;
                 std::vector<PtPtr> ps;

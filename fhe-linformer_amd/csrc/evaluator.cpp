@@ -1265,6 +1265,70 @@ bool Evaluator::dot_plain_groups(const std::vector<CtPtr>& cts, const std::vecto
     return true;
 }
 
+bool Evaluator::dot_plain_groups_batch(const std::vector<std::vector<CtPtr>>& cts, const std::vector<std::vector<PtPtr>>& pts, long double pt_scale,
+                                       const std::vector<std::vector<CtPtr>>& dest) {
+    const size_t nb = cts.size();
+    if (!dot_groups || nb < 2 || dest.size() != nb || cts[0].empty() || cts[0].size() > (size_t)EwDotGroups::MAX_A || pts.empty() ||
+        pts.size() > (size_t)EwDotGroups::MAX_G)
+        return false;
+    const size_t na = cts[0].size(), ng = pts.size();
+    const CtPtr& f = cts[0][0];
+    for (size_t x = 0; x < nb; ++x) {
+        if (cts[x].size() != na || dest[x].size() != ng) return false;
+        for (const CtPtr& c : cts[x])
+            if (c->npoly != 2 || c->deg != 1 || c->ell != f->ell || fabsl(c->scale / f->scale - 1.0L) > 1e-9L) return false;
+        for (const CtPtr& o : dest[x])
+            if (!o || o->npoly != 2 || o->ell != f->ell) return false;
+    }
+    EwDotGroups d;
+    d.na = (int)na;
+    d.ng = (int)ng;
+    d.ell = f->ell;
+    d.nbatch = (int)nb;
+    // equally spaced over the batch, ascending addresses
+    for (size_t b = 0; b < na; ++b) {
+        if (cts[1][b]->d <= cts[0][b]->d) return false;
+        const size_t st = (size_t)(cts[1][b]->d - cts[0][b]->d);
+        for (size_t x = 0; x < nb; ++x)
+            if (cts[x][b]->d != cts[0][b]->d + x * st) return false;
+        d.a[b] = cts[0][b]->d;
+        d.a_stride[b] = st;
+    }
+    for (size_t g = 0; g < ng; ++g) {
+        if (dest[1][g]->d <= dest[0][g]->d) return false;
+        const size_t st = (size_t)(dest[1][g]->d - dest[0][g]->d);
+        for (size_t x = 0; x < nb; ++x)
+            if (dest[x][g]->d != dest[0][g]->d + x * st) return false;
+        d.out[g] = dest[0][g]->d;
+        d.out_stride[g] = st;
+    }
+    const long double sf = pt_scale > 0 ? pt_scale : c_.sf_real[f->level()];
+    u64 terms = 0;
+    std::vector<std::shared_ptr<Encoding>> hold;
+    for (size_t g = 0; g < ng; ++g) {
+        if (pts[g].size() != na) return false;
+        for (size_t b = 0; b < na; ++b) {
+            if (pts[g][b]) {
+                hold.push_back(pts[g][b]->at(f->ell, sf));
+                d.p[g][b] = hold.back()->d;
+                ++terms;
+            } else {
+                d.p[g][b] = nullptr;
+            }
+        }
+        for (size_t x = 0; x < nb; ++x) {
+            dest[x][g]->deg = f->deg + 1;
+            dest[x][g]->scale = cts[x][0]->scale * sf;
+            dest[x][g]->slots = f->slots;
+        }
+    }
+    launch_ew_dot_groups(c_.dt, d, c_.stream);
+    launch_ok("dot_plain_groups_batch");
+    c_.stats.ct_pt_mult += terms * nb;
+    c_.stats.ct_pt_limbs += terms * nb * (u64)f->ell;
+    return true;
+}
+
 bool Evaluator::dot_plain_cyclic(const std::vector<CtPtr>& cts, const std::vector<PtPtr>& pts, const std::vector<CtPtr>& dest) {
     constexpr int P = EwCyclic::PERIOD;
     if (cts.empty() || (int)cts.size() > P || (int)pts.size() != P || (int)dest.size() != P) return false;

@@ -193,6 +193,11 @@ public:
     // cur / prev: 32 entries each, null = zero; all present ciphertexts of one shape, degree 1; accumulate: dest holds earlier blocks' sums
     bool dot_plain_window(const std::vector<CtPtr>& cur, const std::vector<CtPtr>& prev, const std::vector<PtPtr>& pts,
                           const std::vector<CtPtr>& dest, bool accumulate);
+    // dot_plain_groups for SEVERAL sets of ciphertexts and ONE set of plaintexts in one launch (a batch of bootstraps: the stage's
+    // diagonals are fetched once for the batch): out[x][g] = sum_b cts[x][b] * pts[g][b].  Needs every cts[.][b] and every dest[.][g]
+    // equally spaced over x (views of one block); false otherwise (caller: dot_plain_groups per set).  Same residues.
+    bool dot_plain_groups_batch(const std::vector<std::vector<CtPtr>>& cts, const std::vector<std::vector<PtPtr>>& pts, long double pt_scale,
+                                const std::vector<std::vector<CtPtr>>& dest);
     CtPtr dot_plain(const std::vector<CtPtr>& v, const std::vector<PtPtr>& p, long double pt_scale = 0,
                     const CtPtr& dest = CtPtr());   // pt_scale > 0: encode the plaintexts at this scale instead of the level's own;
                                                     // dest: write the sum there (a slice of a caller's batch block)

@@ -71,6 +71,12 @@ struct EwDotGroups {
     const u64* a[MAX_A];
     const u64* p[MAX_G][MAX_A];
     u64* out[MAX_G];
+    // nbatch > 1: the same plaintexts applied to nbatch sets of ciphertexts in ONE launch (the inner sums of a bootstrapping stage
+    // over a batch of bootstraps): set x reads a[b] + x * a_stride[b] and writes out[g] + x * out_stride[g].  The sets of one
+    // (limb, tile) run back to back on one XCD: every plaintext tile comes from HBM once for the whole batch.
+    int nbatch = 1;
+    size_t a_stride[MAX_A] = {};
+    size_t out_stride[MAX_G] = {};
 };
 void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& d, hipStream_t s);
 // The 32 CYCLIC plaintext-weighted sums over n <= 32 ciphertexts of one shape (Composite::relarge_container):

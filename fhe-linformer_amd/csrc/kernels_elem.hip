@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256) void ew_dot_groups_kernel(DeviceTables t, EwDo
     const unsigned nx = gridDim.x, nblk = gridDim.x * gridDim.y;
     unsigned id = blockIdx.y * nx + blockIdx.x;
     if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
-    const int comp = (int)(id & 1), bx = (int)((id >> 1) % nx), tt = (int)((id >> 1) / nx);
+    const int comp = (int)(id & 1);
+    const unsigned rest = id >> 1;
+    const int xb = (int)(rest % (unsigned)d.nbatch);                 // batch element: fastest after the component
+    const int bx = (int)((rest / (unsigned)d.nbatch) % nx), tt = (int)((rest / (unsigned)d.nbatch) / nx);
     const Barrett br = load_barrett(t, tt);
     const size_t n2 = (size_t)bx * 256 + threadIdx.x;
     const size_t row = ((size_t)1 << t.log_n) >> 1;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void ew_dot_groups_kernel(DeviceTables t, EwDo
     u64x2 a[NA];
 #pragma unroll
     for (int b = 0; b < NA; ++b)
-        if (b < d.na) a[b] = reinterpret_cast<const u64x2*>(d.a[b])[oc];
+        if (b < d.na) a[b] = reinterpret_cast<const u64x2*>(d.a[b] + (size_t)xb * d.a_stride[b])[oc];
     for (int g = 0; g < d.ng; ++g) {
         Acc128 x = {0, 0}, y = {0, 0};
 #pragma unroll
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void ew_dot_groups_kernel(DeviceTables t, EwDo
         u64x2 r;
         r.x = barrett_reduce128(x.lo, x.hi, br);
         r.y = barrett_reduce128(y.lo, y.hi, br);
-        reinterpret_cast<u64x2*>(d.out[g])[oc] = r;
+        reinterpret_cast<u64x2*>(d.out[g] + (size_t)xb * d.out_stride[g])[oc] = r;
     }
 }
 
@@ -550,10 +553,11 @@ void launch_ew_dot(const DeviceTables& t, u64* out, const EwItems& it, int limb_
 }
 void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& d, hipStream_t s) {
     if (d.na <= 0 || d.ng <= 0 || d.ell <= 0) return;
+    const int nb = d.nbatch > 0 ? d.nbatch : 1;
     if (d.na <= 8)
-        hipLaunchKernelGGL((ew_dot_groups_kernel<8>), grid2(t.log_n, 2 * d.ell), dim3(256), 0, s, t, d);
+        hipLaunchKernelGGL((ew_dot_groups_kernel<8>), grid2(t.log_n, 2 * d.ell * nb), dim3(256), 0, s, t, d);
     else
-        hipLaunchKernelGGL((ew_dot_groups_kernel<16>), grid2(t.log_n, 2 * d.ell), dim3(256), 0, s, t, d);
+        hipLaunchKernelGGL((ew_dot_groups_kernel<16>), grid2(t.log_n, 2 * d.ell * nb), dim3(256), 0, s, t, d);
 }
 void launch_ew_cyclic_dot(const DeviceTables& t, const EwCyclic& d, hipStream_t s) {
     if (d.n <= 0 || d.ell <= 0) return;
