@@ -324,7 +324,7 @@ std::vector<CtPtr> Evaluator::rotate_sum_batch(const std::vector<CtPtr>& vin, co
     return out;
 }
 
-const Evaluator::FoldedKey& Evaluator::folded_key(const PtPtr& p, int index, long double scale) {
+Evaluator::FoldedKey Evaluator::folded_key(const PtPtr& p, int index, long double scale) {
     const u64 g = c_.galois_element(index);
     auto kit = rot_keys.find(g);
     if (kit == rot_keys.end()) throw Error(FHELIN_ERR_KEY, "no rotation key for index " + std::to_string(index) + " (EvalRotateKeyGen list)");
@@ -351,7 +351,7 @@ const Evaluator::FoldedKey& Evaluator::folded_key(const PtPtr& p, int index, lon
         folded_keys.erase(folded_keys.begin());
     }
     folded_keys.push_back(f);
-    return folded_keys.back();
+    return f;
 }
 
 std::vector<CtPtr> Evaluator::hoisted_dot_rows(const std::vector<CtPtr>& xin, const std::vector<PtPtr>& pts, const std::vector<int>& indices,

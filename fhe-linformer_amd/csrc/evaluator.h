@@ -157,7 +157,7 @@ public:
     };
     std::vector<FoldedKey> folded_keys;  // bounded (MAX_FOLDED), oldest first
     static constexpr size_t MAX_FOLDED = 12;
-    const FoldedKey& folded_key(const PtPtr& p, int index, long double scale);
+    FoldedKey folded_key(const PtPtr& p, int index, long double scale);   // by value: the cache may evict the entry on a later call
     // hoisted rotations: rot(a, i) for every i in `indices` with ONE ModUp of a (results identical to rotate(a, i))
     std::vector<CtPtr> rotate_many(const CtPtr& a, const std::vector<int>& indices);
     // the same for several ciphertexts of one shape and ONE index list (the baby steps of a batch of bootstraps): one ModUp over
