@@ -180,6 +180,17 @@ def load_library():
         "fhelin_bootstrap_describe": (i32, [vp, C.POINTER(i32), i32, C.POINTER(i32)]),
         "fhelin_bootstrap_diag": (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
         "fhelin_bootstrap_cheb": (i32, [vp, C.POINTER(C.c_double), i32, C.POINTER(i32)]),
+        "fhelin_fcb_matmulScores": (i32, [vp, C.POINTER(vp), i32, C.POINTER(vp), i32, C.POINTER(vp)]),
+        "fhelin_fcb_matmul_ct": (i32, [vp, C.POINTER(vp), C.POINTER(vp), i32, i32, i32, C.POINTER(vp)]),
+        "fhelin_fcb_wrapUpRepeated": (i32, [vp, C.POINTER(vp), i32, i32, C.POINTER(vp)]),
+        "fhelin_fcb_wrapUpExpanded": (i32, [vp, C.POINTER(vp), i32, i32, C.POINTER(vp)]),
+        "fhelin_fcb_unwrapExpanded": (i32, [vp, C.POINTER(vp), i32, i32, C.POINTER(vp)]),
+        "fhelin_fcb_unwrapRepeatedLarge": (i32, [vp, C.POINTER(vp), i32, i32, i32, C.POINTER(vp)]),
+        "fhelin_fcb_generate_containers": (i32, [vp, C.POINTER(vp), i32, i32, vp, C.POINTER(vp), C.POINTER(i32)]),
+        "fhelin_fc_rotsum_batch": (i32, [vp, C.POINTER(vp), i32, i32, i32, i32, C.POINTER(vp)]),
+        "fhelin_add_plain_batch": (i32, [vp, C.POINTER(vp), i32, vp, C.POINTER(vp)]),
+        "fhelin_eval_poly_batch": (i32, [vp, C.POINTER(vp), i32, C.POINTER(C.c_double), i32, C.POINTER(vp)]),
+        "fhelin_mult_many_batch": (i32, [vp, C.POINTER(vp), i32, i32, C.POINTER(vp)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)
@@ -261,6 +272,7 @@ class Engine:
         a, d = C.c_int32(), C.c_int32()
         self._ck(self.lib.fhelin_ctx_info(self.h, None, C.byref(a), C.byref(d)))
         self.alpha, self.has_device = a.value, bool(d.value)
+        self.lazy_heavy = os.environ.get("FHELIN_LAZY_HEAVY", "1") != "0"   # the library reads the same knob (capi.cpp)
 
     def _ck(self, rc):
         if rc != 0:
@@ -789,6 +801,61 @@ class Engine:
         h = C.c_void_p()
         self._ck(self.lib.fhelin_fc_wrap_containers(self.h, self._harr(v), len(v), inputs_number, C.byref(h)))
         return Ct(self, h)
+
+
+    # ---- the composite calls on a batch of samples (include/fhelin.h fhelin_fcb_*): flat handle lists are sample-major
+    def fcb_matmulScores(self, queries, n, keys):
+        """queries: B*n handles (sample-major), keys: B handles -> B handles"""
+        outs = self._outs(len(keys))
+        self._ck(self.lib.fhelin_fcb_matmulScores(self.h, self._harr(queries), n, self._harr(keys), len(keys), outs))
+        return self._cts(outs, len(keys))
+
+    def fcb_matmul_ct(self, rows, ws, slots, padding):
+        outs = self._outs(len(rows))
+        self._ck(self.lib.fhelin_fcb_matmul_ct(self.h, self._harr(rows), self._harr(ws), len(rows), slots, padding, outs))
+        return self._cts(outs, len(rows))
+
+    def fcb_wrapUpRepeated(self, v, n, B):
+        outs = self._outs(B)
+        self._ck(self.lib.fhelin_fcb_wrapUpRepeated(self.h, self._harr(v), n, B, outs))
+        return self._cts(outs, B)
+
+    def fcb_wrapUpExpanded(self, v, n, B):
+        outs = self._outs(B)
+        self._ck(self.lib.fhelin_fcb_wrapUpExpanded(self.h, self._harr(v), n, B, outs))
+        return self._cts(outs, B)
+
+    def fcb_unwrapExpanded(self, cs, n):
+        outs = self._outs(len(cs) * n)
+        self._ck(self.lib.fhelin_fcb_unwrapExpanded(self.h, self._harr(cs), len(cs), n, outs))
+        return self._cts(outs, len(cs) * n)
+
+    def fcb_unwrapRepeatedLarge(self, containers, nc, B, input_number):
+        outs = self._outs(B * input_number * 4)
+        self._ck(self.lib.fhelin_fcb_unwrapRepeatedLarge(self.h, self._harr(containers), nc, B, input_number, outs))
+        return self._cts(outs, B * input_number * 4)
+
+    def fcb_generate_containers(self, inputs, n, B, bias=None):
+        per = (n + 31) // 32
+        outs = self._outs(B * per)
+        k = C.c_int32()
+        self._ck(self.lib.fhelin_fcb_generate_containers(self.h, self._harr(inputs), n, B, bias.h if bias else None, outs, C.byref(k)))
+        return self._cts(outs, B * k.value), k.value
+
+    def rotsum_batch(self, v, slots, padding, repeat=False):
+        return self._rows(self.lib.fhelin_fc_rotsum_batch, v, len(v), slots, padding, 1 if repeat else 0)
+
+    def add_plain_batch(self, v, pt):
+        return self._rows(self.lib.fhelin_add_plain_batch, v, len(v), pt.h)
+
+    def eval_poly_batch(self, xs, coeffs):
+        cf = np.ascontiguousarray(coeffs, dtype=np.float64)
+        return self._rows(self.lib.fhelin_eval_poly_batch, xs, len(xs), cf.ctypes.data_as(C.POINTER(C.c_double)), cf.size)
+
+    def mult_many_batch(self, v, n, B):
+        outs = self._outs(B)
+        self._ck(self.lib.fhelin_mult_many_batch(self.h, self._harr(v), n, B, outs))
+        return self._cts(outs, B)
 
 
 class Pt:

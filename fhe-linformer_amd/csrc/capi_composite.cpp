@@ -33,33 +33,72 @@ static void emit_lazy(fhelin_ctx* c, const std::shared_ptr<LazyRows>& g, int n, 
 }
 
 namespace fhelin {
+// Evaluate the listed rows of several deferred groups.  Groups that are the SAME call on different inputs (one driver call per
+// sample of a batch: same weights / same row list) are evaluated TOGETHER - their rows share the batched key switches - and every
+// row still holds the residues its own group's evaluation gives (rows are independent).
+void force_rows_multi(fhelin_ctx* c, std::vector<std::pair<LazyRows*, std::vector<int>>>& reqs) {
+    struct Todo { LazyRows* g; std::vector<int> rows; };
+    std::vector<Todo> todo;
+    for (auto& e : reqs) {
+        Todo t{e.first, {}};
+        for (int i : e.second)
+            if (!t.g->done[i] && std::find(t.rows.begin(), t.rows.end(), i) == t.rows.end()) t.rows.push_back(i);
+        if (!t.rows.empty()) todo.push_back(t);
+    }
+    std::vector<char> taken(todo.size(), 0);
+    for (size_t first = 0; first < todo.size(); ++first) {
+        if (taken[first]) continue;
+        const LazyRows& f = *todo[first].g;
+        std::vector<size_t> grp;
+        for (size_t k = first; k < todo.size(); ++k) {
+            if (taken[k]) continue;
+            const LazyRows& g = *todo[k].g;
+            bool same = g.kind == f.kind;
+            if (same && g.kind == LazyRows::MatmulPt) same = g.w == f.w && g.bias == f.bias && g.slots == f.slots && g.padding == f.padding;
+            if (same && g.kind == LazyRows::RElarge) same = g.weights == f.weights && g.bias == f.bias && g.mask_val == f.mask_val;
+            if (same && g.kind == LazyRows::UnwrapExpanded) same = g.n == f.n && todo[k].rows == todo[first].rows;
+            if (same) {
+                grp.push_back(k);
+                taken[k] = 1;
+            }
+        }
+        std::vector<CtVec> res(grp.size());
+        if (f.kind == LazyRows::UnwrapExpanded) {
+            CtVec srcs;
+            for (size_t k : grp) srcs.push_back(todo[k].g->src);
+            res = c->comp.unwrapExpanded_rows_multi(srcs, f.n, todo[first].rows);
+        } else {
+            CtVec sub;
+            for (size_t k : grp)
+                for (int i : todo[k].rows) sub.push_back(todo[k].g->rows[i]);
+            const CtVec r = f.kind == LazyRows::MatmulPt ? c->comp.matmul_pt(sub, f.w, f.bias, f.slots, f.padding)
+                                                          : c->comp.matmulRElarge(sub, f.weights, f.bias, f.mask_val);
+            size_t p = 0;
+            for (size_t j = 0; j < grp.size(); ++j) {
+                const size_t cnt = todo[grp[j]].rows.size();
+                res[j].assign(r.begin() + p, r.begin() + p + cnt);
+                p += cnt;
+            }
+        }
+        for (size_t j = 0; j < grp.size(); ++j) {
+            LazyRows& g = *todo[grp[j]].g;
+            const std::vector<int>& rows = todo[grp[j]].rows;
+            for (size_t k = 0; k < rows.size(); ++k) {
+                g.done[rows[k]] = res[j][k];
+                if (!g.node.empty() && c->plan.live(g.node[rows[k]], g.node_epoch)) c->plan.nodes[g.node[rows[k]]].eff = LevelPlan::eff_of(*res[j][k]);
+            }
+            bool all = true;
+            for (const CtPtr& d : g.done) all = all && d;
+            if (all) {  // nothing left to evaluate: release the inputs
+                g.rows.clear();
+                g.src.reset();
+            }
+        }
+    }
+}
 void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx) {
-    std::vector<int> todo;
-    for (int i : idx)
-        if (!g.done[i]) todo.push_back(i);
-    if (todo.empty()) return;
-    CtVec r;
-    if (g.kind == LazyRows::MatmulPt) {
-        CtVec sub;
-        for (int i : todo) sub.push_back(g.rows[i]);
-        r = c->comp.matmul_pt(sub, g.w, g.bias, g.slots, g.padding);
-    } else if (g.kind == LazyRows::RElarge) {
-        CtVec sub;
-        for (int i : todo) sub.push_back(g.rows[i]);
-        r = c->comp.matmulRElarge(sub, g.weights, g.bias, g.mask_val);
-    } else {
-        r = c->comp.unwrapExpanded_rows(g.src, g.n, todo);
-    }
-    for (size_t k = 0; k < todo.size(); ++k) {
-        g.done[todo[k]] = r[k];
-        if (!g.node.empty() && c->plan.live(g.node[todo[k]], g.node_epoch)) c->plan.nodes[g.node[todo[k]]].eff = LevelPlan::eff_of(*r[k]);
-    }
-    bool all = true;
-    for (const CtPtr& d : g.done) all = all && d;
-    if (all) {  // nothing left to evaluate: release the inputs
-        g.rows.clear();
-        g.src.reset();
-    }
+    std::vector<std::pair<LazyRows*, std::vector<int>>> one{{&g, idx}};
+    force_rows_multi(c, one);
 }
 // Deferred heavy operations: everything pending, in dependency order; per round the ready operations of one kind, one
 // parameter set and one input shape go through ONE batched call.
@@ -197,21 +236,25 @@ void force_many(fhelin_ctx* c, const fhelin_ct* const* v, int n) {
         if (it == groups.end()) it = groups.insert(groups.end(), {g, {}});
         if (std::find(it->second.begin(), it->second.end(), h->lazy_idx) == it->second.end()) it->second.push_back(h->lazy_idx);
     }
-    for (auto& e : groups) force_group(c, *e.first, e.second);
+    // per group the rows its read pattern asks for (force_group's rule), then ONE merged evaluation over the groups
+    for (auto& e : groups) e.second = rows_for_read(*e.first, e.second);
+    force_rows_multi(c, groups);
 }
-void force_group(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx) {
+// A consumer asks for rows `idx` of a deferred group: which rows to evaluate now.  The first partial read evaluates just those rows
+// (a driver that uses Q[0] only); a second one means the driver is walking over the rows: everything that is left is evaluated in
+// one batched call instead of row by row.
+std::vector<int> rows_for_read(LazyRows& g, const std::vector<int>& idx) {
     std::vector<int> rest;
     for (int i = 0; i < (int)g.done.size(); ++i)
         if (!g.done[i]) rest.push_back(i);
     bool wanted = false, partial = false;
     for (int i : idx) wanted |= !g.done[i];
-    if (!wanted) return;
+    if (!wanted) return {};
     for (int i : rest) partial |= std::find(idx.begin(), idx.end(), i) == idx.end();
-    if (partial && g.partial_reads++ == 0)
-        force_rows(c, g, idx);
-    else
-        force_rows(c, g, rest);
+    if (partial && g.partial_reads++ == 0) return idx;
+    return rest;
 }
+void force_group(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx) { force_rows(c, g, rows_for_read(g, idx)); }
 }  // namespace fhelin
 static void emit(fhelin_ctx* c, const CtVec& v, fhelin_ct** outs) {
     for (size_t i = 0; i < v.size(); ++i) outs[i] = wrap(c, v[i]);
@@ -234,7 +277,7 @@ int fhelin_ct_force(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n) {
         if (it == groups.end()) it = groups.insert(groups.end(), {g, {}});
         if (std::find(it->second.begin(), it->second.end(), h->lazy_idx) == it->second.end()) it->second.push_back(h->lazy_idx);
     }
-    for (auto& e : groups) force_rows(c, *e.first, e.second);   // exactly these rows (force_group would widen a second partial read)
+    force_rows_multi(c, groups);   // exactly these rows (force_group would widen a second partial read); same calls on several samples merged
     FHELIN_CATCH
 }
 int fhelin_rotate_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t index, fhelin_ct** outs) {
@@ -463,6 +506,135 @@ int fhelin_fc_wrap_containers(fhelin_ctx* c, const fhelin_ct* const* v, int32_t 
     NEED(c && v && out);
     FHELIN_TRY
     *out = wrap(c, c->comp.wrap_containers(vec_of(c, v, n), inputs_number));
+    FHELIN_CATCH
+}
+
+/* ---- the composite calls on a BATCH OF SAMPLES (include/fhelin.h: fhelin_fcb_*) ---- */
+static std::vector<CtVec> groups_of(fhelin_ctx* c, const fhelin_ct* const* v, int n, int B) {
+    if (n < 0 || B < 0) throw Error(FHELIN_ERR_ARG, "negative count");
+    const CtVec flat = vec_of(c, v, n * B);     // the deferred rows of ALL samples are evaluated together (force_many)
+    std::vector<CtVec> g(B);
+    for (int x = 0; x < B; ++x) g[x].assign(flat.begin() + (size_t)x * n, flat.begin() + (size_t)(x + 1) * n);
+    return g;
+}
+int fhelin_fcb_matmulScores(fhelin_ctx* c, const fhelin_ct* const* queries, int32_t n, const fhelin_ct* const* keys, int32_t B, fhelin_ct** outs) {
+    NEED(c && queries && keys && outs);
+    FHELIN_TRY
+    emit(c, c->comp.matmulScores_multi(groups_of(c, queries, n, B), vec_of(c, keys, B)), outs);
+    FHELIN_CATCH
+}
+int fhelin_fcb_matmul_ct(fhelin_ctx* c, const fhelin_ct* const* rows, const fhelin_ct* const* ws, int32_t n, int32_t slots, int32_t padding,
+                         fhelin_ct** outs) {
+    NEED(c && rows && ws && outs && n >= 0);
+    FHELIN_TRY
+    emit(c, c->comp.matmul_ct_each(vec_of(c, rows, n), vec_of(c, ws, n), slots, padding), outs);
+    FHELIN_CATCH
+}
+int fhelin_fcb_wrapUpRepeated(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t B, fhelin_ct** outs) {
+    NEED(c && v && outs);
+    FHELIN_TRY
+    CtVec r;
+    for (const CtVec& g : groups_of(c, v, n, B)) r.push_back(c->comp.wrapUpRepeated(g));   // one inner-product pass per sample fills the GPU
+    emit(c, r, outs);
+    FHELIN_CATCH
+}
+int fhelin_fcb_wrapUpExpanded(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t B, fhelin_ct** outs) {
+    NEED(c && v && outs);
+    FHELIN_TRY
+    emit(c, c->comp.wrapUpExpanded_multi(groups_of(c, v, n, B)), outs);
+    FHELIN_CATCH
+}
+int fhelin_fcb_unwrapExpanded(fhelin_ctx* c, const fhelin_ct* const* cs, int32_t B, int32_t n, fhelin_ct** outs) {
+    NEED(c && cs && outs && B >= 0 && n >= 0);
+    FHELIN_TRY
+    if (c->lazy_rows && n > 1) {
+        // one deferred group per sample, as B calls of fhelin_fc_unwrapExpanded make them: each keeps the read pattern of its own sample
+        // (which rows, how many together - that decides the form), and groups read together are evaluated together (force_rows_multi)
+        for (int x = 0; x < B; ++x) {
+            if (!cs[x]) throw Error(FHELIN_ERR_ARG, "null ciphertext handle in array");
+            auto g = std::make_shared<LazyRows>();
+            g->kind = LazyRows::UnwrapExpanded;
+            plan_inputs().clear();
+            g->src = ct_in(c, cs[x]);
+            g->n = n;
+            emit_lazy(c, g, n, outs + (size_t)x * n);
+        }
+    } else {
+        std::vector<int> all(n);
+        for (int i = 0; i < n; ++i) all[i] = i;
+        const std::vector<CtVec> r = c->comp.unwrapExpanded_rows_multi(vec_of(c, cs, B), n, all);
+        for (int x = 0; x < B; ++x) emit(c, r[x], outs + (size_t)x * n);
+    }
+    FHELIN_CATCH
+}
+int fhelin_fcb_unwrapRepeatedLarge(fhelin_ctx* c, const fhelin_ct* const* containers, int32_t nc, int32_t B, int32_t input_number,
+                                   fhelin_ct** outs) {
+    NEED(c && containers && outs);
+    FHELIN_TRY
+    const auto r = c->comp.unwrapRepeatedLarge_multi(groups_of(c, containers, nc, B), input_number);
+    for (int x = 0; x < B; ++x)
+        for (size_t i = 0; i < r[x].size(); ++i) emit(c, r[x][i], outs + ((size_t)x * input_number + i) * 4);
+    FHELIN_CATCH
+}
+int fhelin_fcb_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs, int32_t n, int32_t B, const fhelin_pt* bias,
+                                   fhelin_ct** outs, int32_t* n_out) {
+    NEED(c && inputs && outs && n >= 0 && B >= 0);
+    FHELIN_TRY
+    // every input an unread row of matmulRElarge with one set of weights: the two calls as one (Composite::relarge_containers_multi)
+    const int total = n * B;
+    bool fused = total > 0 && c->comp.fuse_relarge;
+    const LazyRows* g0 = nullptr;
+    for (int i = 0; fused && i < total; ++i) {
+        const fhelin_ct* h = inputs[i];
+        if (!h) throw Error(FHELIN_ERR_ARG, "null ciphertext handle in array");
+        const LazyRows* g = (!h->p && !h->heavy && h->lazy) ? h->lazy.get() : nullptr;
+        fused = g && g->kind == LazyRows::RElarge && !g->done[h->lazy_idx] && g->rows.size() == g->done.size();
+        if (!fused) break;
+        if (!g0) g0 = g;
+        fused = g->weights == g0->weights && g->bias == g0->bias && g->mask_val == g0->mask_val;
+    }
+    std::vector<CtVec> r;
+    if (fused) {
+        std::vector<CtVec> x(B);
+        for (int i = 0; i < total; ++i) {
+            const fhelin_ct* h = inputs[i];
+            x[i / n].push_back(h->lazy->rows[h->lazy_idx]);
+            // level plan: the containers consume what the rows of matmulRElarge would have consumed
+            if (c->plan.live(h->node, h->node_epoch))
+                for (int in : c->plan.nodes[h->node].in) plan_inputs().push_back(in);
+        }
+        r = c->comp.relarge_containers_multi(x, g0->weights, g0->bias, g0->mask_val, opt(bias));
+    } else {
+        r = c->comp.generate_containers_multi(groups_of(c, inputs, n, B), opt(bias));
+    }
+    const size_t per = r.empty() ? 0 : r[0].size();
+    for (int x = 0; x < B; ++x) emit(c, r[x], outs + (size_t)x * per);
+    if (n_out) *n_out = (int)per;
+    FHELIN_CATCH
+}
+int fhelin_fc_rotsum_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t slots, int32_t padding, int32_t repeat, fhelin_ct** outs) {
+    NEED(c && v && outs && n >= 0);
+    FHELIN_TRY
+    emit(c, repeat ? c->comp.repeat_batch(vec_of(c, v, n), slots, padding) : c->comp.rotsum_batch(vec_of(c, v, n), slots, padding), outs);
+    FHELIN_CATCH
+}
+int fhelin_add_plain_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const fhelin_pt* p, fhelin_ct** outs) {
+    NEED(c && v && p && outs && n >= 0);
+    FHELIN_TRY
+    emit(c, c->ev.add_plain_batch(vec_of(c, v, n), p->p), outs);
+    FHELIN_CATCH
+}
+int fhelin_eval_poly_batch(fhelin_ctx* c, const fhelin_ct* const* xs, int32_t n, const double* coeffs, int32_t n_coeffs, fhelin_ct** outs) {
+    NEED(c && xs && coeffs && outs && n >= 0);
+    FHELIN_TRY
+    emit(c, c->ev.eval_poly_many(vec_of(c, xs, n), std::vector<double>(coeffs, coeffs + n_coeffs)), outs);
+    FHELIN_CATCH
+}
+int fhelin_mult_many_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t B, fhelin_ct** outs) {
+    NEED(c && v && outs);
+    FHELIN_TRY
+    // handles that are the SAME object repeat as the same ciphertext (EvalMultMany({r, r, ...}) squares)
+    emit(c, c->ev.mult_many_rows(groups_of(c, v, n, B)), outs);
     FHELIN_CATCH
 }
 

@@ -145,6 +145,10 @@ namespace fhelin {
 int capi_fail(int code, const std::string& msg);
 // evaluate the listed rows of a deferred group in ONE batched call (capi_composite.cpp)
 void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx);
+// the same for several groups at once; groups that are the same call on different inputs (one call per sample of a batch) share
+// their batched key switches
+void force_rows_multi(fhelin_ctx* c, std::vector<std::pair<LazyRows*, std::vector<int>>>& reqs);
+std::vector<int> rows_for_read(LazyRows& g, const std::vector<int>& idx);
 // A consumer asks for rows `idx` of a deferred group.  The first partial read evaluates just those rows (a driver that
 // uses Q[0] only); a second one means the driver is walking over the rows (for (i...) output[i] = add(output[i],
 // inputs[i]), src/main.cpp:237-239): everything that is left is evaluated in one batched call instead of row by row.

@@ -85,15 +85,16 @@ CtPtr Composite::mask_heads(const CtPtr& c, double val) {
     return ev_.mult_plain(c, mask_cache_[key]);
 }
 
-CtPtr Composite::mask_heads_128(const CtPtr& c, double val) {
+PtPtr Composite::heads_128_mask(double val) {
     const std::string key = mkey("mod", 128, 0, val);
     if (!mask_cache_.count(key)) {
         std::vector<double> m(num_slots(), 0.0);
         for (int i = 0; i < num_slots(); i += 128) m[i] = val;
         mask_plain(key, m);
     }
-    return ev_.mult_plain(c, mask_cache_[key]);
+    return mask_cache_[key];
 }
+CtPtr Composite::mask_heads_128(const CtPtr& c, double val) { return ev_.mult_plain(c, heads_128_mask(val)); }
 
 PtPtr Composite::mod_n_mask(int n, int padding) {
     if (n <= 0) throw Error(FHELIN_ERR_ARG, "mask_mod_n: n must be positive");
@@ -275,8 +276,15 @@ CtVec Composite::matmul_pt(const CtVec& rows_in, const PtPtr& w, const PtPtr& bi
 }
 
 CtVec Composite::matmul_ct(const CtVec& rows, const CtPtr& w, int slots, int padding) {
-    CtVec prod;
-    for (const CtPtr& row : rows) prod.push_back(ev_.mult(row, w));
+    return matmul_ct_each(rows, CtVec(rows.size(), w), slots, padding);
+}
+
+// row i against its own ciphertext weight (the same ciphertext-weight matmul on several samples: each sample's rows meet that
+// sample's weight): the products of all rows through ONE batched relinearisation, then the trees of all rows together
+CtVec Composite::matmul_ct_each(const CtVec& rows, const CtVec& ws, int slots, int padding) {
+    if (rows.size() != ws.size()) throw Error(FHELIN_ERR_ARG, "matmul_ct: one weight per row");
+    if (rows.empty()) return {};
+    CtVec prod = rows.size() == 1 ? CtVec{ev_.mult(rows[0], ws[0])} : ev_.mult_batch(rows, ws);
     return rotsum_batch(prod, slots, padding);
 }
 
@@ -381,8 +389,8 @@ CtVec Composite::relarge_tail(const CtVec& u, const PtPtr& bias, double mask_val
 //   C = sum_{k<32} rot(W_k, 512 k) + sum_{i<q} rot(bias, -512 i),      W_k = sum_{i<q} mask_{(i + k) mod 32} * U_i.
 // 32 plaintext-weighted sums over the q rows (the mask product the tree form has too: same depth) and ONE shift sum of 32 terms -
 // 31 ModUps and 5 ModDowns for the group, where the tree form runs 2 key switches per row and then the container's own shift sum.
-CtPtr Composite::relarge_container(const CtVec& uin, const PtPtr& bias, double mask_val) {
-    const int q = (int)uin.size(), ns = num_slots();
+CtVec Composite::relarge_w(const CtVec& uin, double mask_val) {
+    const int q = (int)uin.size();
     CtVec u = uin;
     {
         bool any2 = false;
@@ -401,51 +409,104 @@ CtPtr Composite::relarge_container(const CtVec& uin, const PtPtr& bias, double m
             w[k] = ev_.dot_plain(u, pk);
         }
     }
-    CtPtr c = shift_sum(w, 512);
-    if (bias) {
-        char key[96];
-        snprintf(key, sizeof key, "relarge_bias:%016llx:%d", (unsigned long long)hash_plain(bias, 1469598103934665603ull), q);
-        auto it = relarge_cache_.find(key);
-        PtPtr tiled;
-        if (it != relarge_cache_.end()) {
-            tiled = it->second[0];
-        } else {
-            std::vector<double> v(ns, 0.0);
-            for (int i = 0; i < q; ++i)
-                for (int s = 0; s < ns; ++s) {
-                    const double b = s < (int)bias->values.size() ? bias->values[s] : 0.0;
-                    if (b != 0.0) v[(s + 512 * i) % ns] += b;       // rot(bias, -512 i): slot s lands at s + 512 i
-                }
-            tiled = encode_vec(v, bias->level);
-            if (relarge_cache_.size() > 16) relarge_cache_.clear();
-            relarge_cache_[key] = {tiled};
+    return w;
+}
+
+// sum_{i<q} rot(bias, -512 i) as one plaintext (cached per (bias, q))
+PtPtr Composite::relarge_tiled_bias(const PtPtr& bias, int q) {
+    const int ns = num_slots();
+    char key[96];
+    snprintf(key, sizeof key, "relarge_bias:%016llx:%d", (unsigned long long)hash_plain(bias, 1469598103934665603ull), q);
+    auto it = relarge_cache_.find(key);
+    if (it != relarge_cache_.end()) return it->second[0];
+    std::vector<double> v(ns, 0.0);
+    for (int i = 0; i < q; ++i)
+        for (int s = 0; s < ns; ++s) {
+            const double b = s < (int)bias->values.size() ? bias->values[s] : 0.0;
+            if (b != 0.0) v[(s + 512 * i) % ns] += b;       // rot(bias, -512 i): slot s lands at s + 512 i
         }
-        c = ev_.add_plain(c, tiled);
-    }
-    return c;
+    PtPtr tiled = encode_vec(v, bias->level);
+    if (relarge_cache_.size() > 16) relarge_cache_.clear();
+    relarge_cache_[key] = {tiled};
+    return tiled;
+}
+
+CtPtr Composite::relarge_container(const CtVec& uin, const PtPtr& bias, double mask_val) {
+    CtPtr c = shift_sum(relarge_w(uin, mask_val), 512);
+    return bias ? ev_.add_plain(c, relarge_tiled_bias(bias, (int)uin.size())) : c;
 }
 
 CtVec Composite::relarge_containers(const CtVec& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias, double mask_val, const PtPtr& cbias) {
-    if (!fuse_relarge || !relarge_shared(inputs, weights)) return generate_containers(matmulRElarge(inputs, weights, bias, mask_val), cbias);
-    const CtVec u = relarge_u(inputs, weights);
-    const int total = (int)u.size();
-    CtVec containers;
-    // the groups of generate_containers (:1164-1191): 32 rows each, a shorter last one
-    for (int lo = 0; lo < total; lo += 32) {
-        const int q = std::min(32, total - lo);
-        CtVec ug(u.begin() + lo, u.begin() + lo + q);
-        bool uniform = q >= RELARGE_FUSE_MIN;
-        for (const CtPtr& c : ug)
-            uniform = uniform && c->npoly == 2 && c->ell == ug[0]->ell && c->deg == ug[0]->deg && fabsl(c->scale / ug[0]->scale - 1.0L) < 1e-9L;
-        if (uniform) {
-            containers.push_back(relarge_container(ug, bias, mask_val));
-        } else {
-            CtVec rows = relarge_tail(ug, bias, mask_val);
-            std::reverse(rows.begin(), rows.end());
-            containers.push_back(wrap_containers(rows, q));
-        }
+    return relarge_containers_multi(std::vector<CtVec>{inputs}, weights, bias, mask_val, cbias)[0];
+}
+
+// the fused form for several samples (one input count): the first step U of ALL rows in one batched call, the 32 cyclic sums per
+// (sample, group), then ONE shift sum over the groups of one size of all samples.  Every container holds the residues the
+// single-sample call gives (rows / groups of a batched key switch are independent).
+std::vector<CtVec> Composite::relarge_containers_multi(const std::vector<CtVec>& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias,
+                                                       double mask_val, const PtPtr& cbias) {
+    const size_t X = inputs.size();
+    if (!X) return {};
+    CtVec flat_in;
+    for (const CtVec& in : inputs) {
+        if (in.size() != inputs[0].size()) throw Error(FHELIN_ERR_ARG, "generate_containers: samples must have one input count");
+        flat_in.insert(flat_in.end(), in.begin(), in.end());
     }
-    if (cbias) containers = ev_.add_plain_batch(containers, cbias);
+    if (!fuse_relarge || !relarge_shared(flat_in, weights)) {
+        std::vector<CtVec> rows(X);
+        const CtVec r = matmulRElarge(flat_in, weights, bias, mask_val);
+        const size_t n = inputs[0].size();
+        for (size_t x = 0; x < X; ++x) rows[x].assign(r.begin() + x * n, r.begin() + (x + 1) * n);
+        return generate_containers_multi(rows, cbias);
+    }
+    const CtVec u = relarge_u(flat_in, weights);
+    const int total = (int)inputs[0].size();
+    const int n_cont = (total + 31) / 32;
+    std::vector<CtVec> containers(X, CtVec(n_cont));
+    // the groups of generate_containers (:1164-1191): 32 rows each, a shorter last one
+    std::map<int, std::vector<std::pair<size_t, int>>> fused, tree;   // rows in the group -> (sample, container)
+    std::map<int, std::vector<CtVec>> fused_w, tree_rows;
+    for (size_t x = 0; x < X; ++x)
+        for (int i = 0, lo = 0; lo < total; lo += 32, ++i) {
+            const int q = std::min(32, total - lo);
+            CtVec ug(u.begin() + x * total + lo, u.begin() + x * total + lo + q);
+            bool uniform = q >= RELARGE_FUSE_MIN;
+            for (const CtPtr& c : ug)
+                uniform = uniform && c->npoly == 2 && c->ell == ug[0]->ell && c->deg == ug[0]->deg && fabsl(c->scale / ug[0]->scale - 1.0L) < 1e-9L;
+            if (uniform) {
+                fused[q].push_back({x, i});
+                fused_w[q].push_back(relarge_w(ug, mask_val));
+            } else {
+                tree[q].push_back({x, i});
+                tree_rows[q].push_back(ug);
+            }
+        }
+    for (const auto& e : fused) {
+        CtVec c = shift_sum_multi(fused_w[e.first], 512);
+        if (bias) c = ev_.add_plain_batch(c, relarge_tiled_bias(bias, e.first));
+        for (size_t k = 0; k < e.second.size(); ++k) containers[e.second[k].first][e.second[k].second] = c[k];
+    }
+    for (const auto& e : tree) {
+        // short groups (the driver's last tokens): the 5-step trees of all their rows together, then the container sums together
+        const int q = e.first;
+        CtVec flat;
+        for (const CtVec& ug : tree_rows[q]) flat.insert(flat.end(), ug.begin(), ug.end());
+        const CtVec rows = relarge_tail(flat, bias, mask_val);
+        std::vector<CtVec> groups;
+        for (size_t k = 0; k < e.second.size(); ++k) {
+            CtVec g(rows.begin() + k * q, rows.begin() + (k + 1) * q);
+            std::reverse(g.begin(), g.end());
+            groups.push_back(g);
+        }
+        const CtVec c = wrap_containers_multi(groups, q);
+        for (size_t k = 0; k < e.second.size(); ++k) containers[e.second[k].first][e.second[k].second] = c[k];
+    }
+    if (cbias) {
+        CtVec flat;
+        for (const CtVec& c : containers) flat.insert(flat.end(), c.begin(), c.end());
+        flat = ev_.add_plain_batch(flat, cbias);
+        for (size_t x = 0; x < X; ++x) containers[x].assign(flat.begin() + x * n_cont, flat.begin() + (x + 1) * n_cont);
+    }
     return containers;
 }
 
@@ -518,45 +579,73 @@ CtVec Composite::matmulCRlarge(const std::vector<CtVec>& rows, const std::vector
 // (ceil(log2 n) dependent levels, one batched key switch with one key per level).
 CtPtr Composite::shift_sum(const CtVec& terms, int step) {
     if (terms.empty()) throw Error(FHELIN_ERR_ARG, "shift_sum: empty vector");
-    CtVec cur = terms;
+    return shift_sum_multi(std::vector<CtVec>{terms}, step)[0];
+}
+
+// the same sum for several independent groups of ONE size (the same call of a driver on several samples): every level's key
+// switches of all groups share their launches.  A group's result holds the residues shift_sum gives for that group alone
+// (rows of a batched key switch are independent).
+CtVec Composite::shift_sum_multi(const std::vector<CtVec>& groups, int step) {
+    if (groups.empty()) return {};
+    const size_t G = groups.size();
+    for (const CtVec& g : groups)
+        if (g.empty() || g.size() != groups[0].size()) throw Error(FHELIN_ERR_ARG, "shift_sum: groups must be non-empty and of one size");
+    std::vector<CtVec> cur = groups;
     int unit = step;
-    while (cur.size() > 1 && merge_rot_) {
-        const int width = (int)std::min<size_t>(8, cur.size());
+    while (cur[0].size() > 1 && merge_rot_) {
+        const size_t n = cur[0].size();
+        const int width = (int)std::min<size_t>(8, n);
         std::vector<int> need;
         for (int k = 1; k < width; ++k) need.push_back(unit * k);
-        if (!ev_.have_rotation_keys(need, cur[0]->slots)) break;
+        if (!ev_.have_rotation_keys(need, cur[0][0]->slots)) break;
         // full groups of eight go through one batched call, a shorter last group through its own
-        const size_t full = cur.size() / 8;
-        CtVec nxt;
+        const size_t full = n / 8;
+        std::vector<CtVec> nxt(G);
         if (full) {
-            std::vector<CtVec> rows(full);
-            for (size_t m = 0; m < full; ++m) rows[m].assign(cur.begin() + 8 * m, cur.begin() + 8 * m + 8);
+            std::vector<CtVec> rows;
+            for (size_t g = 0; g < G; ++g)
+                for (size_t m = 0; m < full; ++m) rows.emplace_back(cur[g].begin() + 8 * m, cur[g].begin() + 8 * m + 8);
             std::vector<int> idx;
             for (int k = 0; k < 8; ++k) idx.push_back(unit * k);
-            nxt = ev_.rotate_each_sum_rows(rows, idx);
+            const CtVec r = ev_.rotate_each_sum_rows(rows, idx);
+            for (size_t g = 0; g < G; ++g) nxt[g].assign(r.begin() + g * full, r.begin() + (g + 1) * full);
         }
-        if (cur.size() % 8) {
-            CtVec tail(cur.begin() + 8 * full, cur.end());
-            std::vector<int> idx;
-            for (size_t k = 0; k < tail.size(); ++k) idx.push_back(unit * (int)k);
-            nxt.push_back(tail.size() == 1 ? tail[0] : ev_.rotate_each_sum(tail, idx));
+        if (n % 8) {
+            const size_t tn = n - 8 * full;
+            if (tn == 1) {
+                for (size_t g = 0; g < G; ++g) nxt[g].push_back(cur[g].back());
+            } else {
+                std::vector<CtVec> tails;
+                for (size_t g = 0; g < G; ++g) tails.emplace_back(cur[g].begin() + 8 * full, cur[g].end());
+                std::vector<int> idx;
+                for (size_t k = 0; k < tn; ++k) idx.push_back(unit * (int)k);
+                const CtVec r = ev_.rotate_each_sum_rows(tails, idx);
+                for (size_t g = 0; g < G; ++g) nxt[g].push_back(r[g]);
+            }
         }
         cur.swap(nxt);
         unit *= 8;
     }
-    if (cur.size() == 1) return cur[0];
     // binary tree over what is left (all of it when the radix-8 keys are missing), rotations by unit * 2^level
-    for (int level = 0; cur.size() > 1; ++level) {
-        CtVec odd;
-        for (size_t j = 1; j < cur.size(); j += 2) odd.push_back(cur[j]);
-        CtVec rot = ev_.rotate_batch(odd, unit * (1 << level));
-        CtVec even;
-        for (size_t j = 0; j + 1 < cur.size(); j += 2) even.push_back(cur[j]);
-        CtVec nxt = ev_.add_batch(even, rot);
-        if (cur.size() & 1) nxt.push_back(cur.back());
+    for (int level = 0; cur[0].size() > 1; ++level) {
+        const size_t n = cur[0].size();
+        CtVec odd, even;
+        for (size_t g = 0; g < G; ++g) {
+            for (size_t j = 1; j < n; j += 2) odd.push_back(cur[g][j]);
+            for (size_t j = 0; j + 1 < n; j += 2) even.push_back(cur[g][j]);
+        }
+        const CtVec sum = ev_.add_batch(even, ev_.rotate_batch(odd, unit * (1 << level)));
+        const size_t half = n / 2;
+        std::vector<CtVec> nxt(G);
+        for (size_t g = 0; g < G; ++g) {
+            nxt[g].assign(sum.begin() + g * half, sum.begin() + (g + 1) * half);
+            if (n & 1) nxt[g].push_back(cur[g].back());
+        }
         cur.swap(nxt);
     }
-    return cur[0];
+    CtVec out(G);
+    for (size_t g = 0; g < G; ++g) out[g] = cur[g][0];
+    return out;
 }
 
 // rot(c, step * i) for the listed i (all below n).  Default form (round 3): i = 64 a + 8 b + k, three levels of HOISTED rotations -
@@ -575,7 +664,8 @@ CtVec Composite::shift_fan_rows(const CtPtr& c, int n, int step, const std::vect
     for (int b = 1; b < 8 && 8 * b <= top; ++b) need.push_back(8 * step * b);
     for (int a = 1; 64 * a <= top; ++a) need.push_back(64 * step * a);
     const bool hoisted = merge_rot_ && (need.empty() || ev_.have_rotation_keys(need, c->slots));
-    if (!hoisted) {
+    if (hoisted) return shift_fan_rows_multi(CtVec{c}, n, step, idx)[0];
+    {
         std::map<int, CtPtr> fan;
         fan[0] = c;
         std::vector<char> want(std::max(n, 1), 0);
@@ -601,6 +691,27 @@ CtVec Composite::shift_fan_rows(const CtPtr& c, int n, int step, const std::vect
         for (size_t k = 0; k < idx.size(); ++k) out[k] = fan.at(idx[k]);
         return out;
     }
+}
+
+// the hoisted form for several source ciphertexts of ONE shape and one row list (the same call on several samples): every level
+// is one batched hoisted key switch over all sources.  out[x] holds the residues shift_fan_rows(cs[x], ...) gives.
+std::vector<CtVec> Composite::shift_fan_rows_multi(const CtVec& cs, int n, int step, const std::vector<int>& idx) {
+    std::vector<CtVec> out(cs.size(), CtVec(idx.size()));
+    if (idx.empty() || cs.empty()) return out;
+    for (int i : idx)
+        if (i < 0 || i >= n) throw Error(FHELIN_ERR_ARG, "shift_fan: row out of range");
+    {
+        const int top = n - 1;
+        std::vector<int> need;
+        for (int k = 1; k < 8 && k <= top; ++k) need.push_back(step * k);
+        for (int b = 1; b < 8 && 8 * b <= top; ++b) need.push_back(8 * step * b);
+        for (int a = 1; 64 * a <= top; ++a) need.push_back(64 * step * a);
+        if (!(merge_rot_ && (need.empty() || ev_.have_rotation_keys(need, cs[0]->slots)))) {
+            for (size_t x = 0; x < cs.size(); ++x) out[x] = shift_fan_rows(cs[x], n, step, idx);
+            return out;
+        }
+    }
+    const size_t X = cs.size();
     // level 1: the 64-blocks that hold a wanted row
     std::vector<int> as;
     for (int i : idx)
@@ -608,7 +719,7 @@ CtVec Composite::shift_fan_rows(const CtPtr& c, int n, int step, const std::vect
     std::sort(as.begin(), as.end());
     std::vector<int> a_idx;
     for (int a : as) a_idx.push_back(64 * step * a);
-    const CtVec A = ev_.rotate_many(c, a_idx);                         // index 0 -> c itself
+    const std::vector<CtVec> A = ev_.rotate_many_batch(cs, a_idx);      // [x][a]; index 0 -> the source itself
     // level 2: per 64-block the 8-blocks that hold a wanted row (the union over the blocks: one index list for the batch)
     std::vector<int> bs;
     for (int i : idx)
@@ -616,7 +727,9 @@ CtVec Composite::shift_fan_rows(const CtPtr& c, int n, int step, const std::vect
     std::sort(bs.begin(), bs.end());
     std::vector<int> b_idx;
     for (int b : bs) b_idx.push_back(8 * step * b);
-    const std::vector<CtVec> Bm = ev_.rotate_many_batch(A, b_idx);     // [a][b]
+    CtVec Aflat;
+    for (size_t x = 0; x < X; ++x) Aflat.insert(Aflat.end(), A[x].begin(), A[x].end());
+    const std::vector<CtVec> Bm = ev_.rotate_many_batch(Aflat, b_idx);  // [x * |as| + a][b]
     // level 3: the (a, b) pairs that hold a wanted row, all their k at once
     std::vector<std::pair<int, int>> ab;
     for (int i : idx) {
@@ -630,18 +743,20 @@ CtVec Composite::shift_fan_rows(const CtPtr& c, int n, int step, const std::vect
     std::vector<int> k_idx;
     for (int k : ks) k_idx.push_back(step * k);
     CtVec Bsel;
-    for (const auto& e : ab) {
-        const size_t ai = std::find(as.begin(), as.end(), e.first) - as.begin();
-        const size_t bi = std::find(bs.begin(), bs.end(), e.second) - bs.begin();
-        Bsel.push_back(Bm[ai][bi]);
-    }
-    const std::vector<CtVec> Km = ev_.rotate_many_batch(Bsel, k_idx);  // [(a, b)][k]
-    for (size_t r = 0; r < idx.size(); ++r) {
-        const int i = idx[r];
-        const size_t abi = std::find(ab.begin(), ab.end(), std::pair<int, int>{i / 64, (i % 64) / 8}) - ab.begin();
-        const size_t ki = std::find(ks.begin(), ks.end(), i % 8) - ks.begin();
-        out[r] = Km[abi][ki];
-    }
+    for (size_t x = 0; x < X; ++x)
+        for (const auto& e : ab) {
+            const size_t ai = std::find(as.begin(), as.end(), e.first) - as.begin();
+            const size_t bi = std::find(bs.begin(), bs.end(), e.second) - bs.begin();
+            Bsel.push_back(Bm[x * as.size() + ai][bi]);
+        }
+    const std::vector<CtVec> Km = ev_.rotate_many_batch(Bsel, k_idx);   // [x * |ab| + (a, b)][k]
+    for (size_t x = 0; x < X; ++x)
+        for (size_t r = 0; r < idx.size(); ++r) {
+            const int i = idx[r];
+            const size_t abi = std::find(ab.begin(), ab.end(), std::pair<int, int>{i / 64, (i % 64) / 8}) - ab.begin();
+            const size_t ki = std::find(ks.begin(), ks.end(), i % 8) - ks.begin();
+            out[x][r] = Km[x * ab.size() + abi][ki];
+        }
     return out;
 }
 
@@ -652,13 +767,29 @@ CtVec Composite::shift_fan(const CtPtr& c, int n, int step) {
 }
 
 CtPtr Composite::matmulScores(const CtVec& queries, const CtPtr& key) {
-    if (queries.empty()) throw Error(FHELIN_ERR_ARG, "matmulScores: no queries");
-    CtVec scores = matmul_ct(queries, key, 128, 1);
+    return matmulScores_multi(std::vector<CtVec>{queries}, CtVec{key})[0];
+}
+
+// matmulScores for several samples at once (queries[x] against keys[x], one group size): one batched relinearisation, one set of
+// trees and one shift sum per level for all of them
+CtVec Composite::matmulScores_multi(const std::vector<CtVec>& queries, const CtVec& keys) {
+    if (queries.empty() || queries.size() != keys.size()) throw Error(FHELIN_ERR_ARG, "matmulScores: one key per group of queries");
+    CtVec rows, ws;
+    for (size_t x = 0; x < queries.size(); ++x) {
+        if (queries[x].empty() || queries[x].size() != queries[0].size()) throw Error(FHELIN_ERR_ARG, "matmulScores: no queries");
+        for (const CtPtr& q : queries[x]) {
+            rows.push_back(q);
+            ws.push_back(keys[x]);
+        }
+    }
+    const CtVec scores = matmul_ct_each(rows, ws, 128, 1);
     const double r = 1 / 8.0;  // "later corrected with e^(x/r)"  (:1031)
     // :1036-1044 rotate-by(-1)-and-add chain == sum_i rot(masked_i, -i)
-    CtVec masked;
-    for (const auto& sc : scores) masked.push_back(mask_heads_128(sc, 1 / 8.0 * r));
-    return shift_sum(masked, -1);
+    const CtVec masked = ev_.mult_plain_batch(scores, heads_128_mask(1 / 8.0 * r));
+    const size_t nq = queries[0].size();
+    std::vector<CtVec> groups;
+    for (size_t x = 0; x < queries.size(); ++x) groups.emplace_back(masked.begin() + x * nq, masked.begin() + (x + 1) * nq);
+    return shift_sum_multi(groups, -1);
 }
 
 CtPtr Composite::wrapUpRepeated(const CtVec& v) {
@@ -669,8 +800,21 @@ CtPtr Composite::wrapUpRepeated(const CtVec& v) {
 
 CtPtr Composite::wrapUpExpanded(const CtVec& v) {
     if (v.empty()) throw Error(FHELIN_ERR_ARG, "wrapUpExpanded: empty vector");
-    // :1072-1084 rotate-by(-1)-and-add chain == sum_i rot(mask(v_i), -i)
-    return shift_sum(ev_.mult_plain_batch(v, mod_n_mask(128, 0)), -1);
+    return wrapUpExpanded_multi(std::vector<CtVec>{v})[0];
+}
+
+CtVec Composite::wrapUpExpanded_multi(const std::vector<CtVec>& groups) {
+    // :1072-1084 rotate-by(-1)-and-add chain == sum_i rot(mask(v_i), -i); several samples' groups (one size) share every launch
+    CtVec flat;
+    for (const CtVec& g : groups) {
+        if (g.empty() || g.size() != groups[0].size()) throw Error(FHELIN_ERR_ARG, "wrapUpExpanded: groups must be non-empty and of one size");
+        flat.insert(flat.end(), g.begin(), g.end());
+    }
+    const CtVec masked = ev_.mult_plain_batch(flat, mod_n_mask(128, 0));
+    const size_t n = groups[0].size();
+    std::vector<CtVec> mg;
+    for (size_t x = 0; x < groups.size(); ++x) mg.emplace_back(masked.begin() + x * n, masked.begin() + (x + 1) * n);
+    return shift_sum_multi(mg, -1);
 }
 
 CtVec Composite::unwrapExpanded(CtPtr c, int n) {
@@ -682,54 +826,87 @@ CtVec Composite::unwrapExpanded(CtPtr c, int n) {
 }
 
 CtVec Composite::unwrapExpanded_rows(CtPtr c, int n, const std::vector<int>& idx) {
+    return unwrapExpanded_rows_multi(CtVec{c}, n, idx)[0];
+}
+
+// the rows `idx` of unwrapExpanded(cs[x], n) for several sources of one shape (the same call on several samples): out[x]
+std::vector<CtVec> Composite::unwrapExpanded_rows_multi(const CtVec& cs, int n, const std::vector<int>& idx) {
+    if (cs.empty()) return {};
     if (bulk_unwrap && merge_rot_ && (int)idx.size() >= UNWRAP_BULK_MIN && n <= 128 && num_slots() % 128 == 0) {
         std::vector<int> need;
         for (int k = 1; k < 8; ++k) need.push_back(-k), need.push_back(-8 * k);
         need.push_back(-64);
-        if (ev_.have_rotation_keys(need, c->slots)) return unwrapExpanded_bulk(c, n, idx);
+        if (ev_.have_rotation_keys(need, cs[0]->slots)) return unwrapExpanded_bulk_multi(cs, n, idx);
     }
     // row i of the fan is the same composition whichever rows are asked for (shift_fan_rows)
-    return repeat_batch(ev_.mult_plain_batch(shift_fan_rows(c, n, 1, idx), mod_n_mask(128, 0)), 128, 1);
+    const std::vector<CtVec> fans = shift_fan_rows_multi(cs, n, 1, idx);
+    CtVec flat;
+    for (const CtVec& f : fans) flat.insert(flat.end(), f.begin(), f.end());
+    const CtVec rep = repeat_batch(ev_.mult_plain_batch(flat, mod_n_mask(128, 0)), 128, 1);
+    std::vector<CtVec> out;
+    for (size_t x = 0; x < cs.size(); ++x) out.emplace_back(rep.begin() + x * idx.size(), rep.begin() + (x + 1) * idx.size());
+    return out;
 }
 
-CtVec Composite::unwrapExpanded_bulk(CtPtr c, int n, const std::vector<int>& idx) {
+CtVec Composite::unwrapExpanded_bulk(CtPtr c, int n, const std::vector<int>& idx) { return unwrapExpanded_bulk_multi(CtVec{c}, n, idx)[0]; }
+
+std::vector<CtVec> Composite::unwrapExpanded_bulk_multi(const CtVec& cs_in, int n, const std::vector<int>& idx) {
     for (int i : idx)
         if (i < 0 || i >= n) throw Error(FHELIN_ERR_ARG, "unwrapExpanded: row out of range");
-    if (c->deg >= 2) c = ev_.rescale(c);
+    CtVec cs = cs_in;
+    {
+        CtVec need;
+        std::vector<size_t> pos;
+        for (size_t x = 0; x < cs.size(); ++x)
+            if (cs[x]->deg >= 2) {
+                need.push_back(cs[x]);
+                pos.push_back(x);
+            }
+        if (!need.empty()) {
+            const CtVec r = ev_.rescale_batch(need);   // a single one goes through rescale() itself
+            for (size_t k = 0; k < pos.size(); ++k) cs[pos[k]] = r[k];
+        }
+    }
     const int imin = *std::min_element(idx.begin(), idx.end()), imax = *std::max_element(idx.begin(), idx.end());
     // D_j = rot(c, j) for j in [imin - 127, imax]: the fan of the call for j >= 0, the fan by -1 (128 rows) for j < 0
     std::vector<int> pj, nj;
     for (int j = 0; j <= imax; ++j) pj.push_back(j);
     for (int j = 1; j <= 127 - imin; ++j) nj.push_back(j);
-    const CtVec pos = shift_fan_rows(c, n, 1, pj);
-    const CtVec neg = nj.empty() ? CtVec() : shift_fan_rows(c, 128, -1, nj);
-    auto D = [&](int d) -> CtPtr {
-        if (d >= 0) return d <= imax ? pos[d] : CtPtr();
-        return -d <= 127 - imin ? neg[-d - 1] : CtPtr();
-    };
+    const std::vector<CtVec> pos_all = shift_fan_rows_multi(cs, n, 1, pj);
+    const std::vector<CtVec> neg_all = nj.empty() ? std::vector<CtVec>(cs.size()) : shift_fan_rows_multi(cs, 128, -1, nj);
     std::vector<PtPtr> mask(128);
     for (int k = 0; k < 128; ++k) mask[k] = mod_n_mask(128, k);
-    CtVec out(idx.size());
-    std::vector<char> block_wanted(4, 0);
-    for (int i : idx) block_wanted[i / 32] = 1;
-    for (int g = 0; g < 4; ++g) {
-        if (!block_wanted[g]) continue;
-        // x_i = sum_{k<128} mask_k * D_{i-k} for the 32 rows i = 32 g + t: four tap chunks of 32, accumulated in place
-        CtVec dest = ev_.new_ct_batch(32, 2, c->ell, c->deg + 1, c->scale, c->slots);
-        for (int ch = 0; ch < 4; ++ch) {
-            const int p = 32 * g - 32 * ch;
-            CtVec cur(32), prev(32);
-            for (int j = 0; j < 32; ++j) {
-                cur[j] = D(p + j);
-                prev[j] = p - 32 + j >= -127 ? D(p - 32 + j) : CtPtr();
+    std::vector<CtVec> out_all;
+    for (size_t x = 0; x < cs.size(); ++x) {
+        const CtPtr& c = cs[x];
+        const CtVec &pos = pos_all[x], &neg = neg_all[x];
+        auto D = [&](int d) -> CtPtr {
+            if (d >= 0) return d <= imax ? pos[d] : CtPtr();
+            return -d <= 127 - imin ? neg[-d - 1] : CtPtr();
+        };
+        CtVec out(idx.size());
+        std::vector<char> block_wanted(4, 0);
+        for (int i : idx) block_wanted[i / 32] = 1;
+        for (int g = 0; g < 4; ++g) {
+            if (!block_wanted[g]) continue;
+            // x_i = sum_{k<128} mask_k * D_{i-k} for the 32 rows i = 32 g + t: four tap chunks of 32, accumulated in place
+            CtVec dest = ev_.new_ct_batch(32, 2, c->ell, c->deg + 1, c->scale, c->slots);
+            for (int ch = 0; ch < 4; ++ch) {
+                const int p = 32 * g - 32 * ch;
+                CtVec cur(32), prev(32);
+                for (int j = 0; j < 32; ++j) {
+                    cur[j] = D(p + j);
+                    prev[j] = p - 32 + j >= -127 ? D(p - 32 + j) : CtPtr();
+                }
+                const std::vector<PtPtr> m(mask.begin() + 32 * ch, mask.begin() + 32 * ch + 32);
+                if (!ev_.dot_plain_window(cur, prev, m, dest, ch > 0)) throw Error(FHELIN_ERR_INTERNAL, "unwrapExpanded_bulk: window operands");
             }
-            const std::vector<PtPtr> m(mask.begin() + 32 * ch, mask.begin() + 32 * ch + 32);
-            if (!ev_.dot_plain_window(cur, prev, m, dest, ch > 0)) throw Error(FHELIN_ERR_INTERNAL, "unwrapExpanded_bulk: window operands");
+            for (size_t r = 0; r < idx.size(); ++r)
+                if (idx[r] / 32 == g) out[r] = dest[idx[r] % 32];
         }
-        for (size_t r = 0; r < idx.size(); ++r)
-            if (idx[r] / 32 == g) out[r] = dest[idx[r] % 32];
+        out_all.push_back(out);
     }
-    return out;
+    return out_all;
 }
 
 CtVec Composite::unwrapScoresExpanded(CtPtr c, int n) {
@@ -750,8 +927,20 @@ CtVec Composite::unwrap_512_in_4_128(const CtPtr& c, int index) {
 }
 
 std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int input_number, int first, int count) {
+    return unwrapRepeatedLarge_multi(std::vector<CtVec>{containers}, input_number, first, count)[0];
+}
+
+// unwrapRepeatedLarge for several samples (one container count, one token count): every stage's key switches of all samples share
+// their launches.  out[x][token][k]; sample x's outputs hold the residues the single-sample call gives.
+std::vector<std::vector<CtVec>> Composite::unwrapRepeatedLarge_multi(const std::vector<CtVec>& containers, int input_number, int first, int count) {
     if (count < 0) count = input_number - first;
     if (first < 0 || first + count > input_number) throw Error(FHELIN_ERR_ARG, "unwrapRepeatedLarge: token range out of bounds");
+    const size_t X = containers.size();
+    std::vector<std::vector<CtVec>> out(X);
+    if (!X) return out;
+    for (const CtVec& cv : containers)
+        if (cv.size() != containers[0].size()) throw Error(FHELIN_ERR_ARG, "unwrapRepeatedLarge: samples must have one container count");
+    const size_t nc = containers[0].size();
     std::vector<int> quantities;
     for (int i = 0; i < input_number / 32.0; ++i) {
         int q = 32;
@@ -761,24 +950,26 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
     const int ns = num_slots();
     const bool shared = merge_rot_ && ns == 16384 &&
                         ev_.have_rotation_keys({128, 256, 384, -128, -256, -384, 512, 1024, 1536, 2048, 2560, 3072, 3584, 4096, 8192, 12288},
-                                               containers.empty() ? 0 : containers[0]->slots);
+                                               nc == 0 ? 0 : containers[0][0]->slots);
     if (!shared) {
         // unwrap_512_in_4_128 (:1142-1162) for every (container, token): mask the four 128-slot blocks, then one batched
         // repeat(128, -128) over all of them
         CtVec src;
         std::vector<PtPtr> masks;
-        for (size_t i = 0; i < containers.size() && i < quantities.size(); ++i)
-            for (int j = 0; j < quantities[i]; ++j) {
-                const int token = (int)i * 32 + j;
-                if (token < first || token >= first + count) continue;
-                for (int k = 0; k < 4; ++k) {
-                    src.push_back(containers[i]);
-                    masks.push_back(block_mask(j * 512 + 128 * k, j * 512 + 128 * (k + 1), 1));
+        for (size_t x = 0; x < X; ++x)
+            for (size_t i = 0; i < nc && i < quantities.size(); ++i)
+                for (int j = 0; j < quantities[i]; ++j) {
+                    const int token = (int)i * 32 + j;
+                    if (token < first || token >= first + count) continue;
+                    for (int k = 0; k < 4; ++k) {
+                        src.push_back(containers[x][i]);
+                        masks.push_back(block_mask(j * 512 + 128 * k, j * 512 + 128 * (k + 1), 1));
+                    }
                 }
-            }
         CtVec rep = repeat_batch(ev_.mult_plain_each(src, masks), 128, -128);
-        std::vector<CtVec> out;
-        for (size_t i = 0; i + 3 < rep.size(); i += 4) out.push_back(CtVec(rep.begin() + i, rep.begin() + i + 4));
+        const size_t per = rep.size() / X;
+        for (size_t x = 0; x < X; ++x)
+            for (size_t i = 0; i + 3 < per; i += 4) out[x].push_back(CtVec(rep.begin() + x * per + i, rep.begin() + x * per + i + 4));
         return out;
     }
     // The same slot values with four of the seven doubling steps SHARED between tokens.  The reference masks block k of
@@ -792,27 +983,28 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
     //         merged key switch of seven rotations per output (the 32 shifts 512 i = the 4 x 8 shifts 4096 a' + 512 i')
     // One key switch per output instead of three, 5 shared ones per (container, k, a); the same two mask levels as the
     // one-stage shared form this replaces (which needed two key switches per output).
-    std::vector<CtVec> out;
-    // the (container, range) pairs that hold a wanted token
-    std::vector<std::pair<int, int>> groups;
-    for (size_t i = 0; i < containers.size() && i < quantities.size(); ++i)
-        for (int a = 0; a < 4; ++a) {
-            bool wanted = false;
-            for (int j = 8 * a; j < 8 * a + 8 && j < quantities[i]; ++j) {
-                const int token = (int)i * 32 + j;
-                wanted = wanted || (token >= first && token < first + count);
+    // the (sample, container, range) triples that hold a wanted token
+    struct Grp { size_t x; int i, a; };
+    std::vector<Grp> groups;
+    for (size_t x = 0; x < X; ++x)
+        for (size_t i = 0; i < nc && i < quantities.size(); ++i)
+            for (int a = 0; a < 4; ++a) {
+                bool wanted = false;
+                for (int j = 8 * a; j < 8 * a + 8 && j < quantities[i]; ++j) {
+                    const int token = (int)i * 32 + j;
+                    wanted = wanted || (token >= first && token < first + count);
+                }
+                if (wanted) groups.push_back({x, (int)i, a});
             }
-            if (wanted) groups.push_back({(int)i, a});
-        }
     // stage 1, batched over the groups: per block k one masked product, one rescale, one merged key switch; then ONE
     // replication over the four ranges for all of them
     CtVec Ball;
     for (int k = 0; k < 4; ++k) {
         CtVec from;
         std::vector<PtPtr> mk;
-        for (const auto& g : groups) {
-            from.push_back(containers[g.first]);
-            mk.push_back(mod_range_mask(512, 128 * k, 128 * (k + 1), 4096 * g.second, 4096 * (g.second + 1)));
+        for (const Grp& g : groups) {
+            from.push_back(containers[g.x][g.i]);
+            mk.push_back(mod_range_mask(512, 128 * k, 128 * (k + 1), 4096 * g.a, 4096 * (g.a + 1)));
         }
         CtVec A = ev_.rescale_batch(ev_.mult_plain_each(from, mk));
         std::vector<int> idx;
@@ -832,7 +1024,7 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
     std::vector<std::vector<int>> bs_of;
     for (int k = 0; k < 4; ++k)
         for (size_t gi = 0; gi < groups.size(); ++gi) {
-            const int i = groups[gi].first, a = groups[gi].second;
+            const int i = groups[gi].i, a = groups[gi].a;
             std::vector<int> bs;
             for (int j = 8 * a; j < 8 * a + 8 && j < quantities[i]; ++j) {
                 const int token = i * 32 + j;
@@ -847,15 +1039,16 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
     std::vector<int> ridx;
     for (int m = 0; m < 8; ++m) ridx.push_back(512 * m);
     const std::vector<CtVec> rot = ev_.rotate_many_batch(dsel, ridx);      // [input][m], m = 0: the input itself
-    // all outputs in ONE block in the order their consumer reads them ([token][k]: matmulCRlarge rescales and multiplies them in that
+    // a sample's outputs in ONE block in the order their consumer reads them ([token][k]: matmulCRlarge rescales and multiplies them in that
     // order, so its batched rescale takes them as they stand - no gather copies)
-    CtVec all_out = rot.empty() ? CtVec() : ev_.new_ct_batch(count * 4, 2, rot[0][0]->ell, 2, 0, rot[0][0]->slots);
-    std::map<std::pair<int, int>, CtPtr> made;                             // (token, k) -> output
-    for (size_t x = 0; x < d_of.size(); ++x) {
-        const int k = (int)(d_of[x] / groups.size());
-        const size_t gi = d_of[x] % groups.size();
-        const int i = groups[gi].first, a = groups[gi].second;
-        const std::vector<int>& bs = bs_of[x];
+    std::vector<CtVec> all_out(X);
+    for (size_t x = 0; x < X && !rot.empty(); ++x) all_out[x] = ev_.new_ct_batch(count * 4, 2, rot[0][0]->ell, 2, 0, rot[0][0]->slots);
+    std::vector<std::map<std::pair<int, int>, CtPtr>> made(X);             // per sample: (token, k) -> output
+    for (size_t z = 0; z < d_of.size(); ++z) {
+        const int k = (int)(d_of[z] / groups.size());
+        const Grp& g = groups[d_of[z] % groups.size()];
+        const int i = g.i, a = g.a;
+        const std::vector<int>& bs = bs_of[z];
         std::vector<std::vector<PtPtr>> pts(bs.size(), std::vector<PtPtr>(8));
         for (size_t q = 0; q < bs.size(); ++q)
             for (int m = 0; m < 8; ++m) {
@@ -863,47 +1056,76 @@ std::vector<CtVec> Composite::unwrapRepeatedLarge(const CtVec& containers, int i
                 pts[q][m] = mod_range_mask(4096, 512 * bb, 512 * (bb + 1));
             }
         CtVec dest;
-        for (int b : bs) dest.push_back(all_out[(size_t)(i * 32 + 8 * a + b - first) * 4 + k]);
-        if (!ev_.dot_plain_groups(rot[x], pts, 0, dest))
-            for (size_t q = 0; q < bs.size(); ++q) dest[q] = ev_.dot_plain(rot[x], pts[q], 0, dest[q]);
-        for (size_t q = 0; q < bs.size(); ++q) made[{i * 32 + 8 * a + bs[q], k}] = dest[q];
+        for (int b : bs) dest.push_back(all_out[g.x][(size_t)(i * 32 + 8 * a + b - first) * 4 + k]);
+        if (!ev_.dot_plain_groups(rot[z], pts, 0, dest))
+            for (size_t q = 0; q < bs.size(); ++q) dest[q] = ev_.dot_plain(rot[z], pts[q], 0, dest[q]);
+        for (size_t q = 0; q < bs.size(); ++q) made[g.x][{i * 32 + 8 * a + bs[q], k}] = dest[q];
     }
-    for (int token = first; token < first + count; ++token) {
-        CtVec four;
-        for (int k = 0; k < 4; ++k) four.push_back(made.at({token, k}));
-        out.push_back(four);
-    }
+    for (size_t x = 0; x < X; ++x)
+        for (int token = first; token < first + count; ++token) {
+            CtVec four;
+            for (int k = 0; k < 4; ++k) four.push_back(made[x].at({token, k}));
+            out[x].push_back(four);
+        }
     return out;
 }
 
-CtPtr Composite::wrap_containers(const CtVec& c, int n) {
-    if (c.empty() || n > (int)c.size()) throw Error(FHELIN_ERR_ARG, "wrap_containers: bad input count");
+CtPtr Composite::wrap_containers(const CtVec& c, int n) { return wrap_containers_multi(std::vector<CtVec>{c}, n)[0]; }
+
+CtVec Composite::wrap_containers_multi(const std::vector<CtVec>& cs, int n) {
     // :1186-1193 result = rot(result, -512) + c[i]  ==  sum_i rot(c[n-1-i], -512 i)
-    CtVec terms(c.begin(), c.begin() + n);
-    std::reverse(terms.begin(), terms.end());
-    return shift_sum(terms, -512);
+    std::vector<CtVec> groups;
+    for (const CtVec& c : cs) {
+        if (c.empty() || n > (int)c.size()) throw Error(FHELIN_ERR_ARG, "wrap_containers: bad input count");
+        CtVec terms(c.begin(), c.begin() + n);
+        std::reverse(terms.begin(), terms.end());
+        groups.push_back(terms);
+    }
+    return shift_sum_multi(groups, -512);
 }
 
 CtVec Composite::generate_containers(const CtVec& inputs, const PtPtr& bias) {
-    CtVec containers;
-    const int total = (int)inputs.size();
-    for (int i = 0; i < total / 32.0; ++i) {
+    return generate_containers_multi(std::vector<CtVec>{inputs}, bias)[0];
+}
+
+// generate_containers for several samples (one input count): container i of every sample is built in the same launches
+std::vector<CtVec> Composite::generate_containers_multi(const std::vector<CtVec>& inputs, const PtPtr& bias) {
+    const size_t X = inputs.size();
+    std::vector<CtVec> containers(X);
+    if (!X) return containers;
+    const int total = (int)inputs[0].size();
+    for (const CtVec& in : inputs)
+        if ((int)in.size() != total) throw Error(FHELIN_ERR_ARG, "generate_containers: samples must have one input count");
+    // all containers of one quantity (the full ones of every sample; the shorter last ones) go through ONE shift sum: their
+    // key switches share launches.  A container's residues do not depend on which others it shares a launch with.
+    std::map<int, std::vector<std::pair<size_t, int>>> by_q;   // quantity -> (sample, container)
+    int n_cont = 0;
+    for (int i = 0; i < total / 32.0; ++i, ++n_cont) {
         int quantity = 32;
         if ((i + 1) * 32 > total) quantity = total - i * 32;
-        // slicing(inputs, 32 i, 32 (i+1))  (:1338-1357): returns the whole vector when it has <= 32 entries
-        int X = i * 32, Y = (i + 1) * 32;
-        CtVec sliced;
-        if (Y - X >= total) {
-            sliced = inputs;
-        } else {
-            if (Y > total) Y = total;
-            sliced.assign(inputs.begin() + X, inputs.begin() + Y);
-        }
-        std::reverse(sliced.begin(), sliced.end());
-        CtPtr part = wrap_containers(sliced, quantity);
-        containers.push_back(part);
+        for (size_t x = 0; x < X; ++x) by_q[quantity].push_back({x, i});
     }
-    if (bias) containers = ev_.add_plain_batch(containers, bias);
+    for (size_t x = 0; x < X; ++x) containers[x].resize(n_cont);
+    for (const auto& e : by_q) {
+        std::vector<CtVec> sliced;
+        for (const auto& xi : e.second) {
+            // slicing(inputs, 32 i, 32 (i+1))  (:1338-1357): returns the whole vector when it has <= 32 entries
+            const CtVec& in = inputs[xi.first];
+            const int lo = xi.second * 32, hi = (xi.second + 1) * 32;
+            CtVec sl = hi - lo >= total ? in : CtVec(in.begin() + lo, in.begin() + std::min(hi, total));
+            std::reverse(sl.begin(), sl.end());
+            sliced.push_back(sl);
+        }
+        const CtVec part = wrap_containers_multi(sliced, e.first);
+        for (size_t k = 0; k < e.second.size(); ++k) containers[e.second[k].first][e.second[k].second] = part[k];
+    }
+    if (bias) {
+        CtVec flat;
+        for (const CtVec& c : containers) flat.insert(flat.end(), c.begin(), c.end());
+        flat = ev_.add_plain_batch(flat, bias);
+        const size_t per = containers[0].size();
+        for (size_t x = 0; x < X; ++x) containers[x].assign(flat.begin() + x * per, flat.begin() + (x + 1) * per);
+    }
     return containers;
 }
 

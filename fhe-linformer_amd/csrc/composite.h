@@ -27,6 +27,7 @@ public:
     CtPtr mask_block(const CtPtr& c, int from, int to, double v);
     CtPtr mask_heads(const CtPtr& c, double v);
     CtPtr mask_heads_128(const CtPtr& c, double v);
+    PtPtr heads_128_mask(double v);
     CtPtr mask_mod_n(const CtPtr& c, int n, int padding);
     CtPtr mask_first_n(const CtPtr& c, int n, double v);
     PtPtr first_n_mask(int n, double v);   // the cached mask plaintexts themselves (batched callers)
@@ -52,6 +53,24 @@ public:
     CtVec matmulRElarge(const CtVec& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias, double mask_val);
     CtVec matmulCRlarge(const std::vector<CtVec>& rows, const std::vector<PtPtr>& weights, const PtPtr& bias);
     CtPtr matmulScores(const CtVec& queries, const CtPtr& key);
+
+    // ---- the same calls on SEVERAL SAMPLES at once (BASELINE config 4's per-GPU unit: a batch of independent inputs through one
+    // engine, src/main.cpp:145-475 once per sample).  Group x of every argument belongs to sample x; all groups of a call have one
+    // size.  The single-sample methods above are these with one group, so a sample's results hold the same residues either way
+    // (rows / groups of a batched key switch are independent): what changes is that the small launches of a single pass - one
+    // query row, one container tail, one wrapped ciphertext - now carry every sample's rows.
+    CtVec matmul_ct_each(const CtVec& rows, const CtVec& ws, int slots, int padding);                     // row i against weight ws[i]
+    CtVec matmulScores_multi(const std::vector<CtVec>& queries, const CtVec& keys);
+    CtVec shift_sum_multi(const std::vector<CtVec>& groups, int step);
+    std::vector<CtVec> shift_fan_rows_multi(const CtVec& cs, int n, int step, const std::vector<int>& idx);
+    CtVec wrapUpExpanded_multi(const std::vector<CtVec>& groups);
+    std::vector<CtVec> unwrapExpanded_rows_multi(const CtVec& cs, int inputs_num, const std::vector<int>& idx);
+    std::vector<CtVec> unwrapExpanded_bulk_multi(const CtVec& cs, int n, const std::vector<int>& idx);
+    std::vector<std::vector<CtVec>> unwrapRepeatedLarge_multi(const std::vector<CtVec>& containers, int input_number, int first = 0, int count = -1);
+    CtVec wrap_containers_multi(const std::vector<CtVec>& cs, int inputs_number);
+    std::vector<CtVec> generate_containers_multi(const std::vector<CtVec>& inputs, const PtPtr& bias);
+    std::vector<CtVec> relarge_containers_multi(const std::vector<CtVec>& inputs, const std::vector<PtPtr>& weights, const PtPtr& bias,
+                                                double mask_val, const PtPtr& cbias);
 
     // shifted sums / fans shared by the layout shuffles (log-depth forms of the reference's rotate-by-one chains)
     CtPtr shift_sum(const CtVec& terms, int step);          // sum_i rot(terms[i], step * i)
@@ -97,6 +116,8 @@ private:
     CtVec relarge_u(const CtVec& inputs, const std::vector<PtPtr>& weights);        // the shared form's first step: U per row
     CtVec relarge_tail(const CtVec& u, const PtPtr& bias, double mask_val);          // its 5-step tree, mask and bias
     CtPtr relarge_container(const CtVec& u, const PtPtr& bias, double mask_val);     // tree + container sum of one group of rows
+    CtVec relarge_w(const CtVec& u, double mask_val);                                // its 32 cyclic plaintext-weighted sums
+    PtPtr relarge_tiled_bias(const PtPtr& bias, int q);
     bool early_rescale_ = true;   // FHELIN_EARLY_RESCALE: rescale a fresh product before its rotation tree
     bool merge_rot_ = true;       // FHELIN_MERGE_ROT: two tree steps as one merged key switch when the 3s key exists
     bool row_lanes_ = false;      // FHELIN_ROW_LANES: row chunks of a tree on separate streams (off: measured slower)

@@ -243,6 +243,9 @@ public:
     CtPtr eval_poly(const CtPtr& x, const std::vector<double>& coeffs);                 // power basis
     CtPtr eval_chebyshev(const CtPtr& x, const std::vector<double>& coeffs, double a, double b);  // sum' c_k T_k(u), u = affine map of [a,b] to [-1,1]
     CtPtr mult_many(const std::vector<CtPtr>& v);
+    // the same on several inputs / operand lists at once: every multiplication round is ONE batched relinearisation over all of them
+    std::vector<CtPtr> eval_poly_many(const std::vector<CtPtr>& xs, const std::vector<double>& coeffs);
+    std::vector<CtPtr> mult_many_rows(const std::vector<std::vector<CtPtr>>& vs);
     CtPtr rescale(const CtPtr& a);                           // drop one limb, divide the scale by it
     CtPtr level_reduce(const CtPtr& a, int new_ell);         // drop limbs without scaling
     // bring `a` to (ell, deg) with scale `scale` following the FLEXIBLEAUTO rules

@@ -108,18 +108,51 @@ CtPtr Evaluator::conjugate(const CtPtr& a) {
 
 CtPtr Evaluator::mult_many(const std::vector<CtPtr>& v) {
     if (v.empty()) throw Error(FHELIN_ERR_ARG, "mult_many: empty vector");
-    std::vector<CtPtr> cur = v;
-    while (cur.size() > 1) {
-        std::vector<CtPtr> nxt;
-        for (size_t i = 0; i + 1 < cur.size(); i += 2) {
-            // identical operand pairs give identical products: reuse (EvalMultMany({r,r,...}) squares repeatedly)
-            if (i >= 2 && cur[i] == cur[i - 2] && cur[i + 1] == cur[i - 1]) nxt.push_back(nxt.back());
-            else nxt.push_back(mult(cur[i], cur[i + 1]));
+    return mult_many_rows(std::vector<std::vector<CtPtr>>{v})[0];
+}
+
+// EvalMultMany on several operand lists of ONE length at once (the same call on several samples): every level of the product
+// tree is one batched relinearisation over all lists.  A list's result holds the residues of the tree evaluated alone.
+std::vector<CtPtr> Evaluator::mult_many_rows(const std::vector<std::vector<CtPtr>>& vs) {
+    if (vs.empty()) return {};
+    const size_t X = vs.size();
+    for (const auto& v : vs)
+        if (v.empty() || v.size() != vs[0].size()) throw Error(FHELIN_ERR_ARG, "mult_many: lists must be non-empty and of one length");
+    std::vector<std::vector<CtPtr>> cur = vs;
+    while (cur[0].size() > 1) {
+        const size_t n = cur[0].size();
+        // identical operand pairs give identical products: reuse (EvalMultMany({r,r,...}) squares repeatedly) - when EVERY list repeats there
+        std::vector<char> reuse(n / 2, 0);
+        for (size_t i = 2; i + 1 < n; i += 2) {
+            bool all = true;
+            for (size_t x = 0; x < X; ++x) all = all && cur[x][i] == cur[x][i - 2] && cur[x][i + 1] == cur[x][i - 1];
+            reuse[i / 2] = all ? 1 : 0;
         }
-        if (cur.size() & 1) nxt.push_back(cur.back());
+        std::vector<CtPtr> lhs, rhs;
+        for (size_t i = 0; i + 1 < n; i += 2)
+            if (!reuse[i / 2])
+                for (size_t x = 0; x < X; ++x) {
+                    lhs.push_back(cur[x][i]);
+                    rhs.push_back(cur[x][i + 1]);
+                }
+        const std::vector<CtPtr> prod = lhs.size() == 1 ? std::vector<CtPtr>{mult(lhs[0], rhs[0])} : mult_batch(lhs, rhs);
+        std::vector<std::vector<CtPtr>> nxt(X);
+        size_t p = 0;
+        for (size_t i = 0; i + 1 < n; i += 2) {
+            if (reuse[i / 2]) {
+                for (size_t x = 0; x < X; ++x) nxt[x].push_back(nxt[x].back());
+            } else {
+                for (size_t x = 0; x < X; ++x) nxt[x].push_back(prod[p * X + x]);
+                ++p;
+            }
+        }
+        if (n & 1)
+            for (size_t x = 0; x < X; ++x) nxt[x].push_back(cur[x].back());
         cur.swap(nxt);
     }
-    return cur[0];
+    std::vector<CtPtr> out(X);
+    for (size_t x = 0; x < X; ++x) out[x] = cur[x][0];
+    return out;
 }
 
 // bring a set of ciphertexts to one common (level, degree 1)
@@ -135,20 +168,40 @@ static void align_deg1(Evaluator& ev, std::vector<CtPtr>& v, int from) {
     for (size_t i = from; i < v.size(); ++i) v[i] = r[i - from];
 }
 
-CtPtr Evaluator::eval_poly(const CtPtr& x, const std::vector<double>& coeffs) {
+CtPtr Evaluator::eval_poly(const CtPtr& x, const std::vector<double>& coeffs) { return eval_poly_many(std::vector<CtPtr>{x}, coeffs)[0]; }
+
+// EvalPoly on several ciphertexts at once: the powers h < i <= 2h only need powers <= h, so each doubling round is ONE batched
+// multiplication over all its i and all inputs.  Every input's result holds the residues of the power tree evaluated alone.
+std::vector<CtPtr> Evaluator::eval_poly_many(const std::vector<CtPtr>& xs, const std::vector<double>& coeffs) {
     int n = (int)coeffs.size() - 1;
     while (n > 0 && coeffs[n] == 0.0) --n;
     if (n < 1) throw Error(FHELIN_ERR_ARG, "eval_poly: need degree >= 1");
-    std::vector<CtPtr> pw(n + 1);
-    pw[1] = x->deg >= 2 ? rescale(x) : x;
-    for (int i = 2; i <= n; ++i) {
-        int hi = 1;
-        while (hi * 2 <= i) hi *= 2;
-        pw[i] = (hi == i) ? mult(pw[i / 2], pw[i / 2]) : mult(pw[hi], pw[i - hi]);
+    const size_t X = xs.size();
+    if (!X) return {};
+    std::vector<CtRow> pw(n + 1, CtRow(X));
+    for (size_t x = 0; x < X; ++x) pw[1][x] = xs[x]->deg >= 2 ? rescale(xs[x]) : xs[x];
+    for (int h = 1; h < n; h *= 2) {
+        const int i_hi = std::min(2 * h, n);
+        CtRow lhs, rhs;
+        for (int i = h + 1; i <= i_hi; ++i)
+            for (size_t x = 0; x < X; ++x) {
+                lhs.push_back(pw[h][x]);                                  // x^i = x^h * x^(i-h), h the largest power of two <= i
+                rhs.push_back(i == 2 * h ? pw[h][x] : pw[i - h][x]);
+            }
+        const CtRow prod = lhs.size() == 1 ? CtRow{mult(lhs[0], rhs[0])} : mult_batch(lhs, rhs);
+        size_t p = 0;
+        for (int i = h + 1; i <= i_hi; ++i)
+            for (size_t x = 0; x < X; ++x) pw[i][x] = prod[p++];
     }
-    align_deg1(*this, pw, 1);
-    std::vector<CtPtr> terms(pw.begin() + 1, pw.begin() + n + 1);
-    return lincomb(terms, std::vector<double>(coeffs.begin() + 1, coeffs.begin() + n + 1), coeffs[0]);
+    std::vector<CtPtr> out(X);
+    const std::vector<double> cf(coeffs.begin() + 1, coeffs.begin() + n + 1);
+    for (size_t x = 0; x < X; ++x) {
+        std::vector<CtPtr> col(n + 1);
+        for (int i = 1; i <= n; ++i) col[i] = pw[i][x];
+        align_deg1(*this, col, 1);
+        out[x] = lincomb(std::vector<CtPtr>(col.begin() + 1, col.begin() + n + 1), cf, coeffs[0]);
+    }
+    return out;
 }
 
 // Chebyshev evaluation over a ROW of ciphertexts (one value per input): every op below acts on all inputs at once, the

@@ -168,6 +168,172 @@ class GpuController:
         return self._cheb(("tanh", mult), lambda x: math.tanh(x / mult), c, lo, hi, degree)
 
 
+class Batch(list):
+    """one value of the driver for each of B samples (B ciphertext handles, sample order)"""
+
+
+class BatchedController:
+    """B samples through ONE engine in lock step (BASELINE config 4's per-GPU unit: "the batch of independent input ciphertexts").
+
+    The driver below (`encoder1` / `pooler` / `classifier` = reference src/main.cpp:145-475 once per sample; samples never meet) runs
+    UNCHANGED: where it holds one ciphertext it now holds a `Batch` of B, where it holds a vector of rows it holds a list of Batches,
+    and every method hands the samples' rows TOGETHER to one entry point of the C ABI - the row loops concatenated into the batched
+    calls that exist for them (fhelin_fc_matmul_pt, _matmulRElarge, _matmulCRlarge, fhelin_bootstrap_batch, fhelin_eval_chebyshev_batch,
+    fhelin_mult_batch, ...), the calls that fold a row set into one ciphertext through their sample-batched forms (include/fhelin.h
+    fhelin_fcb_*).  One key set, one plaintext / mask cache (weights are read once, not per sample), one level plan, one launch set:
+    the single-ciphertext chains of a pass (scores, Taylor exp, 1/x, pooler, tanh, classifier) are B rows wide, and the 8 bootstraps
+    of a sample run in batches of 2B, 5B and B.  Sample x ends in EXACTLY the residues its own single pass gives
+    (tests/test_batched_forward_gpu.py).  All samples of a batch have one token count."""
+
+    def __init__(self, eng, B, verbose=False):
+        self.e, self.B, self.verbose = eng, int(B), verbose
+        self.num_slots = SLOTS
+        self.n_boot = 0
+
+    # ---- layout helpers: a list of n Batches <-> the flat sample-major handle list the C ABI takes
+    def _flat(self, rows):
+        return [r[x] for x in range(self.B) for r in rows]
+
+    def _unflat(self, flat, n):
+        return [Batch(flat[x * n + i] for x in range(self.B)) for i in range(n)]
+
+    # handles
+    def level(self, c):
+        return c[0].level
+
+    def clone(self, c):
+        return Batch(h.clone() for h in c)
+
+    # encode / encrypt: plaintexts are shared by all samples
+    def encode(self, v, level=0):
+        if np.isscalar(v):
+            v = np.full(SLOTS, float(v))
+        return self.e.encode(np.asarray(v, dtype=np.float64), level, SLOTS)
+
+    def encrypt(self, v, level=0):
+        """the server-side encryptions of the driver (src/main.cpp:220, :472): one fresh encryption per sample"""
+        v = np.asarray(v, dtype=np.float64)
+        return Batch(self.e.encrypt_batch(np.stack([v] * self.B), level, SLOTS))
+
+    def decrypt(self, c):
+        return [self.e.decrypt(h, SLOTS) for h in c]
+
+    def read_expanded_inputs_batch(self, rows_per_sample, scale=1.0):
+        """per sample the rows of read_expanded_inputs -> list of Batches (row-major)"""
+        cts = [self.e.encrypt_batch(np.stack([expanded(np.asarray(v) * scale) for v in rows]), 0, SLOTS) for rows in rows_per_sample]
+        return [Batch(cts[x][i] for x in range(self.B)) for i in range(len(cts[0]))]
+
+    def client_ingest_batch(self, w, x_embs):
+        encs = [self.e.client_ingest(w["cls_token"], w["posEmb"], w["E_w"], w["E_b"], w["F_w"], w["F_b"], emb=x) for x in x_embs]
+        return batch_inputs(encs)
+
+    read_plain_input = GpuController.read_plain_input
+    read_plain_repeated_input = GpuController.read_plain_repeated_input
+    read_plain_expanded_input = GpuController.read_plain_expanded_input
+
+    # leaf ops
+    def add(self, a, b):
+        if isinstance(b, Batch):
+            return Batch(self.e.add_batch(list(a), list(b)))
+        return Batch(self.e.add_plain_batch(list(a), b))
+
+    def mult(self, a, b):
+        if np.isscalar(b):
+            return Batch(self.e.mult_const(h, b) for h in a)
+        if isinstance(b, Batch):
+            return Batch(self.e.mult_batch(list(a), list(b)))
+        return Batch(self.e.mult_plain_batch(list(a), b))
+
+    def rotate(self, a, i):
+        return Batch(self.e.rotate_batch(list(a), i))
+
+    def bootstrap(self, a):
+        # one call per handle, as the single pass makes them: the C ABI defers bootstraps / Chebyshev evaluations and runs everything
+        # pending as ONE batch when a result is first read (fhelin_bootstrap_batch) - here the driver's loop over containers
+        # (src/main.cpp:354-358) times B samples: 5B wide.  With deferral off (FHELIN_LAZY_HEAVY=0) the B samples still share a batch.
+        self.n_boot += 1
+        if self.e.lazy_heavy:
+            return Batch(self.e.bootstrap(h) for h in a)
+        return Batch(self.e.bootstrap_batch(list(a)))
+
+    # composites: same names as the reference
+    def rotsum(self, a, slots, padding):
+        return Batch(self.e.rotsum_batch(list(a), slots, padding))
+
+    def matmulRE(self, rows, w, bias=None, row_size=128, padding=128):
+        if isinstance(w, Batch):      # ciphertext weight: sample x's rows against sample x's weight
+            flat = self._flat(rows)
+            ws = [w[x] for x in range(self.B) for _ in rows]
+            return self._unflat(self.e.fcb_matmul_ct(flat, ws, row_size, padding), len(rows))
+        return self._unflat(self.e.matmul_pt(self._flat(rows), w, bias, row_size, padding), len(rows))
+
+    def matmulCR(self, rows, w, bias=None):
+        if isinstance(w, Batch):
+            flat = self._flat(rows)
+            return self._unflat(self.e.fcb_matmul_ct(flat, [w[x] for x in range(self.B) for _ in rows], 64, 1), len(rows))
+        return self._unflat(self.e.matmul_pt(self._flat(rows), w, bias, 128, 1), len(rows))
+
+    def matmulRElarge(self, rows, weights, bias, mask_val=1.0):
+        return self._unflat(self.e.matmulRElarge(self._flat(rows), weights, bias, mask_val), len(rows))
+
+    def matmulCRlarge(self, rows, weights, bias):
+        flat = [[r[k][x] for k in range(4)] for x in range(self.B) for r in rows]
+        return self._unflat(self.e.matmulCRlarge(flat, weights, bias), len(rows))
+
+    def matmulScores(self, queries, key):
+        q = queries if not isinstance(queries, Batch) else [queries]
+        return Batch(self.e.fcb_matmulScores(self._flat(q), len(q), list(key)))
+
+    def wrapUpRepeated(self, v):
+        return Batch(self.e.fcb_wrapUpRepeated(self._flat(v), len(v), self.B))
+
+    def wrapUpExpanded(self, v):
+        return Batch(self.e.fcb_wrapUpExpanded(self._flat(v), len(v), self.B))
+
+    def unwrapExpanded(self, c, n):
+        return self._unflat(self.e.fcb_unwrapExpanded(list(c), n), n)
+
+    def unwrapRepeatedLarge(self, cs, n):
+        flat = self.e.fcb_unwrapRepeatedLarge(self._flat(cs), len(cs), self.B, n)
+        return [[Batch(flat[(x * n + i) * 4 + k] for x in range(self.B)) for k in range(4)] for i in range(n)]
+
+    def generate_containers(self, inputs, bias=None):
+        flat, per = self.e.fcb_generate_containers(self._flat(inputs), len(inputs), self.B, bias)
+        return self._unflat(flat, per)
+
+    # activations (reference src/FHEController.cpp:1289-1336)
+    def eval_exp(self, c, inputs_number):
+        res = self.e.eval_poly_batch(list(c), [1, 1, 1 / 2.0, 1 / 6.0, 1 / 24.0, 1 / 120.0, 1 / 720.0])
+        res = self.e.mult_many_batch([r for r in res for _ in range(8)], 8, self.B)
+        i = np.arange(SLOTS)
+        mask = np.where((i % 128 < inputs_number) & (i < 128 * inputs_number), 0.0, -1.0)
+        return Batch(self.e.add_plain_batch(res, self.encode(mask, res[0].level)))
+
+    def _cheb(self, key, f, c, a, b, degree):
+        key = key + (a, b, degree)
+        if key not in GpuController._fits:
+            GpuController._fits[key] = cheb_coeffs(f, a, b, degree)
+        if self.e.lazy_heavy:
+            return Batch(self.e.eval_chebyshev(h, GpuController._fits[key], a, b) for h in c)
+        return Batch(self.e.eval_chebyshev_batch(list(c), GpuController._fits[key], a, b))
+
+    eval_inverse_naive = GpuController.eval_inverse_naive
+    eval_gelu_function = GpuController.eval_gelu_function
+    eval_tanh_function = GpuController.eval_tanh_function
+
+
+def batched_level_plan(plan, B, n_client):
+    """the level plan of a batched pass from the plan recorded on ONE sample (Engine.level_plan_end): the sources of a batched pass
+    are the B samples' client encryptions (sample-major, n_client each) and then, call by call, B sources per source of the single pass"""
+    return [t for _ in range(B) for t in plan[:n_client]] + [t for t in plan[n_client:] for _ in range(B)]
+
+
+def batch_inputs(encs):
+    """B per-sample input dicts (encrypt_inputs / ingest_sample) -> one dict of lists of Batches"""
+    B = len(encs)
+    return {k: [Batch(encs[x][k][i] for x in range(B)) for i in range(len(encs[0][k]))] for k in ("inputs_E", "inputs_F", "inputs")}
+
+
 # ---- the circuit: reference src/main.cpp:145-475 (CLS-query variant, as built) -----------------------------
 def encrypt_inputs(ctl, x_in, X_E, X_F):
     """client side (main.cpp:159-173): x_in [S_total,128] (row 0 = CLS token), X_E / X_F [32,128] (Linformer projections)"""

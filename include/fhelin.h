@@ -279,6 +279,34 @@ int fhelin_fc_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs,
                                   fhelin_ct** outs, int32_t* n_out);                                    /* :1164 */
 int fhelin_fc_wrap_containers(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t inputs_number, fhelin_ct** out); /* :1193 */
 
+/* ---- the same FHEController calls on a BATCH OF B SAMPLES through one context (BASELINE config 4's per-GPU unit: "the batch of
+ * independent input ciphertexts"; a sample is one run of the driver, src/main.cpp:145-475, and samples never meet).  Arrays are
+ * sample-major: v[x * n + i] = row i of sample x; all samples of a call have one row count.  Sample x's outputs hold EXACTLY the
+ * residues the single-sample entry point gives on sample x's inputs - rows of a batched key switch are independent - but the small
+ * launches of one pass (a single query row, a container tail, one wrapped ciphertext: single-digit row counts that cannot fill 256
+ * CUs) now carry the rows of every sample: one key set, one plaintext cache, one launch set.  The row loops proper
+ * (fhelin_fc_matmul_pt, _matmulRElarge, _matmulCRlarge, fhelin_*_batch, fhelin_bootstrap_batch, fhelin_eval_chebyshev_batch) take the
+ * samples' rows concatenated as they are; deferred rows of several samples that are read by ONE call are evaluated together. */
+int fhelin_fcb_matmulScores(fhelin_ctx* c, const fhelin_ct* const* queries, int32_t n, const fhelin_ct* const* keys, int32_t B,
+                            fhelin_ct** outs);                                                        /* :1028,:1050; outs[B] */
+/* matmulRE / matmulCR with a ciphertext weight PER ROW (sample x's rows against sample x's wrapped keys / values, :901,:946,:960) */
+int fhelin_fcb_matmul_ct(fhelin_ctx* c, const fhelin_ct* const* rows, const fhelin_ct* const* ws, int32_t n, int32_t slots, int32_t padding,
+                         fhelin_ct** outs);
+int fhelin_fcb_wrapUpRepeated(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t B, fhelin_ct** outs);       /* :1060; outs[B] */
+int fhelin_fcb_wrapUpExpanded(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t B, fhelin_ct** outs);       /* :1070; outs[B] */
+int fhelin_fcb_unwrapExpanded(fhelin_ctx* c, const fhelin_ct* const* cs, int32_t B, int32_t inputs_num, fhelin_ct** outs); /* :1086; outs[B * inputs_num] */
+int fhelin_fcb_unwrapRepeatedLarge(fhelin_ctx* c, const fhelin_ct* const* containers, int32_t nc, int32_t B, int32_t input_number,
+                                   fhelin_ct** outs);                                                 /* :1102; outs[B * input_number * 4] */
+/* outs: B x ceil(n/32) handles; *n_out = containers per sample */
+int fhelin_fcb_generate_containers(fhelin_ctx* c, const fhelin_ct* const* inputs, int32_t n, int32_t B, const fhelin_pt* bias,
+                                   fhelin_ct** outs, int32_t* n_out);                                 /* :1164 */
+/* rotsum (:829) / repeat (:849, repeat != 0) over n independent ciphertexts: one batched key switch per tree step */
+int fhelin_fc_rotsum_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t slots, int32_t padding, int32_t repeat, fhelin_ct** outs);
+int fhelin_add_plain_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, const fhelin_pt* p, fhelin_ct** outs);  /* EvalAdd(ct,pt) per row */
+/* EvalPoly (:1291) on n ciphertexts, EvalMultMany (:1297) on B operand lists of n handles: one batched relinearisation per round */
+int fhelin_eval_poly_batch(fhelin_ctx* c, const fhelin_ct* const* xs, int32_t n, const double* coeffs, int32_t n_coeffs, fhelin_ct** outs);
+int fhelin_mult_many_batch(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n, int32_t B, fhelin_ct** outs);
+
 /* ---- polynomial evaluation (ADVANCEDSHE) -------------------------------------------------------- */
 int fhelin_mult_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out);              /* EvalMult(ct, double)            */
 int fhelin_add_real(fhelin_ctx* c, const fhelin_ct* a, double k, fhelin_ct** out);               /* EvalAdd(ct, double)             */
