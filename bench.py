@@ -49,8 +49,11 @@ def parse():
     ap.add_argument("--workload", choices=["forward", "ntt", "ops"], default="forward")
     ap.add_argument("--batch", type=int, default=0, help="samples per step over ALL ranks (0: one per rank per step); a rank's share of a "
                     "step goes through ONE engine as ONE batched pass (linformer.BatchedController: BASELINE config 4's per-GPU unit)")
+    ap.add_argument("--pass-width", type=int, default=4, help="with --batch: at most this many samples travel in ONE pass (a pass keeps ~17 GB of "
+                    "intermediates per sample at N=2^16 next to ~50 GB of keys: 4 fit 288 GB with room for the resident inputs, 8 do not); "
+                    "a rank's share of a step runs as ceil(share / width) passes")
     ap.add_argument("--batch-loop", action="store_true", help="with --batch: a rank runs its samples one after another instead (A/B)")
-    ap.add_argument("--resident-gb", type=float, default=100.0, help="with --batch: device memory for the resident input sets of the "
+    ap.add_argument("--resident-gb", type=float, default=75.0, help="with --batch: device memory for the resident input sets of the "
                     "timed region; steps cycle through the sets that fit (every pass still does all of its work)")
     ap.add_argument("--shard-rows", action="store_true", help="batch-1 latency mode: ONE sample per step, the rows inside its matmul / "
                     "unwrap loops split over the ranks (all-gather of ciphertext rows over RCCL/xGMI per row loop)")
@@ -442,7 +445,12 @@ def main():
         samples = []
         n_samples = (args.warmup + args.steps) * per_rank
         batched = args.batch > 0 and not row_mode and not args.batch_loop and per_rank >= 1
-        bctl = lf.BatchedController(eng, per_rank) if batched else None
+        # a rank's share of a step as passes of <= pass_width samples (equal widths: 8 -> 4 + 4, 6 -> 3 + 3)
+        n_pass = -(-per_rank // max(1, args.pass_width)) if batched else 1
+        while batched and per_rank % n_pass:
+            n_pass += 1
+        width = per_rank // n_pass if batched else 1
+        bctl = lf.BatchedController(eng, width) if batched else None
         n_sets = args.warmup + args.steps                    # distinct input sets (one set = a rank's samples of one step)
         if batched:
             n_sets = max(1, min(n_sets, int(args.resident_gb / (4.5 * per_rank * (eng.N / 65536.0)))))
@@ -464,7 +472,7 @@ def main():
             plan = eng.level_plan_end()
             del enc_rec
 
-        bplan = lf.batched_level_plan(plan, per_rank, n_client_sources) if (use_plan and batched) else []
+        bplan = lf.batched_level_plan(plan, width, n_client_sources) if (use_plan and batched) else []
 
         def server_pass(enc):
             if use_plan:
@@ -472,10 +480,13 @@ def main():
             return lf.forward_encrypted(ctl, w, enc)
 
         def server_pass_batched(encs):
-            # ONE pass of the driver with every value per_rank ciphertexts wide (all samples of this rank's share of the step)
-            if use_plan:
-                eng.level_plan_begin("apply", first_source=n_client_sources * per_rank)
-            return lf.forward_encrypted(bctl, w, lf.batch_inputs(encs))
+            # passes of the driver with every value `width` ciphertexts wide (this rank's share of the step: n_pass passes)
+            outs = []
+            for lo in range(0, len(encs), width):
+                if use_plan:
+                    eng.level_plan_begin("apply", first_source=n_client_sources * width)
+                outs.extend(lf.forward_encrypted(bctl, w, lf.batch_inputs(encs[lo:lo + width])))
+            return outs
 
         eng.sync()
         eng.stats(reset=True)
@@ -564,6 +575,8 @@ def main():
         if dist:
             elapsed = shard.max_over_ranks(dist, elapsed)
         stats = eng.stats()
+        pool_now = {"held_GB": round(stats.pop("pool_reserved_bytes") / 1e9, 1), "in_use_peak_GB": round(stats.pop("pool_live_peak_bytes") / 1e9, 1),
+                    "held_peak_GB": round(stats.pop("pool_reserved_peak_bytes") / 1e9, 1), "out_of_memory_trims_in_the_timed_region": stats.pop("pool_trims")}
         for k in stats:
             stats[k] = stats[k] // max(1, n_timed)          # per sample
         # parity of the timed path: EVERY timed sample vs the same op sequence in the clear (oracle/circuit_sim.py),
@@ -617,14 +630,15 @@ def main():
                 print(json.dumps({"metric": "encrypted Linformer-d128 forward ms/sample (profiling run)",
                                   "value": round(elapsed * 1e3 / (n_timed * world), 2), "unit": "ms/sample", "n_gpus": world,
                                   "steps": args.steps, "warmup": args.warmup, "log_n": args.log_n,
-                                  "host_issue_ms_per_sample": round(host_enqueue * 1e3 / n_timed, 2), "ops_per_sample": stats,
-                                  "level_plan": bool(plan)}))
+                                  "host_issue_ms_per_sample": round(host_enqueue * 1e3 / n_timed, 2), "ops_per_sample": stats, "device_pool": pool_now,
+                                  "samples_per_pass": width, "passes_per_step": n_pass if batched else per_rank, "distinct_input_sets": n_sets,
+                                  "logit_err_vs_circuit_oracle": round(err, 5), "level_plan": bool(plan)}))
             eng.close()
             if dist:
                 dist.destroy_process_group()
             return
         fwd = {"elapsed": elapsed, "stats": stats, "logit_err_vs_circuit_oracle": err, "logit_err_mean": err_sum / max(1, len(logits)),
-               "batched": batched, "n_sets": n_sets, "host_enqueue_ms": host_enqueue * 1e3 / max(1, n_timed), "pred": int(np.argmax(logits[-1])),
+               "batched": batched, "n_sets": n_sets, "pool": pool_now, "width": width, "n_pass": n_pass if batched else per_rank, "host_enqueue_ms": host_enqueue * 1e3 / max(1, n_timed), "pred": int(np.argmax(logits[-1])),
                "samples_checked": len(logits), "eager_ms": eager_ms, "client_ms": client_ms, "unplanned_ms": unplanned_ms, "literal_ms": literal_ms,
                "client_first_ms": client_first_ms, "client_pool": client_pool,
                "plan": plan, "n_client_sources": n_client_sources}
@@ -704,11 +718,13 @@ def main():
                            "ops_per_sample": fwd["stats"],
                            "parallelism": (f"ONE sample per step, rows of its matmul / unwrap loops over {world} ranks, keys replicated"
                                            if row_mode else f"independent samples x{world}, keys replicated (one key seed)"),
-                           "samples_per_pass": per_rank if fwd["batched"] else 1,
+                           "samples_per_pass": fwd["width"],
+                           "passes_per_step_per_gpu": fwd["n_pass"],
                            "samples_per_pass_note": ("ONE pass of the driver carries this many samples through one engine (linformer.BatchedController: one key set, "
                                                      "one plaintext cache, one launch set; every sample ends in the residues of its own single pass, "
                                                      "tests/test_batched_forward_gpu.py)" if fwd["batched"] else "one sample per pass"),
                            "distinct_input_sets_in_the_timed_region": fwd["n_sets"],
+                           "device_pool": fwd["pool"],
                            "host_issue_ms_per_sample": round(fwd["host_enqueue_ms"], 2),
                            "logit_err_vs_circuit_oracle": round(fwd["logit_err_vs_circuit_oracle"], 5),
                            "logit_err_vs_circuit_oracle_mean": round(fwd["logit_err_mean"], 5),

@@ -358,10 +358,11 @@ class Engine:
         self._ck(self.lib.fhelin_ntt(self.h, buf.ptr, nvec, limb_first, limb_count, 1 if inverse else 0))
 
     def stats(self, reset=False):
-        out = np.zeros(12, dtype=np.uint64)
-        self._ck(self.lib.fhelin_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), 12, 1 if reset else 0))
+        out = np.zeros(16, dtype=np.uint64)
+        self._ck(self.lib.fhelin_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64)), 16, 1 if reset else 0))
         keys = ["limb_ntt", "keyswitch", "keyswitch_limbs", "rescale", "ct_pt_mult", "bootstrap", "encode", "rescale_limbs", "ct_pt_limbs",
-                "pool_malloc_calls", "pool_malloc_bytes", "pool_malloc_ns"]
+                "pool_malloc_calls", "pool_malloc_bytes", "pool_malloc_ns", "pool_reserved_bytes", "pool_live_peak_bytes",
+                "pool_reserved_peak_bytes", "pool_trims"]
         return {k: int(v) for k, v in zip(keys, out)}
 
     # ---- keys

@@ -309,6 +309,13 @@ int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset) {
         out[9] = p.malloc_calls;
         out[10] = p.malloc_bytes;
         out[11] = p.malloc_ns;
+        if (cap >= 16) {   // bytes the pool holds now, high-water marks of bytes in use / held, out-of-memory trims
+            out[12] = p.bytes_reserved();
+            out[13] = p.live_peak;
+            out[14] = p.reserved_peak;
+            out[15] = p.trims;
+            if (reset) p.live_peak = p.reserved_peak = p.trims = 0;
+        }
         if (reset) p.malloc_calls = p.malloc_bytes = p.malloc_ns = 0;
     }
     if (reset) s = OpStats();

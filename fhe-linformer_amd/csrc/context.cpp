@@ -34,9 +34,15 @@ void* DevicePool::alloc(size_t bytes) {
         bytes = (bytes + step - 1) / step * step;
     }
     auto& idle = idle_[cur_lane];
-    auto it = idle.find(bytes);
+    // best fit: the smallest idle block of this lane that holds the request and wastes at most a quarter of itself again (a block
+    // keeps its own size: it goes back to the idle list as what it is).  Exact-size matching alone lets the pool hoard blocks of
+    // every size a pass has ever asked for - with many samples per pass that is what runs the device out of memory, and every
+    // out-of-memory costs a device-wide synchronisation (trim).
+    auto it = idle.lower_bound(bytes);
+    if (it != idle.end() && it->first > bytes + bytes / 4) it = idle.end();
     void* p = nullptr;
     if (it != idle.end()) {
+        bytes = it->first;
         p = it->second.p;
         if (it->second.ev) {
             // last used by work on another lane's stream: this lane's stream goes behind it (no host wait)
@@ -58,8 +64,11 @@ void* DevicePool::alloc(size_t bytes) {
         malloc_bytes += bytes;
         malloc_ns += (u64)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
         reserved_ += bytes;
+        if (reserved_ > reserved_peak) reserved_peak = reserved_;
     }
     live_[p] = Live{bytes, cur_lane};
+    live_bytes_ += bytes;
+    if (live_bytes_ > live_peak) live_peak = live_bytes_;
     return p;
 }
 void DevicePool::free(void* p) {
@@ -79,9 +88,11 @@ void DevicePool::free(void* p) {
         foreign_frees += 1;
     }
     idle_[it->second.lane].emplace(it->second.bytes, Idle{p, ev});  // back to the lane (stream) that owns it
+    live_bytes_ -= it->second.bytes;
     live_.erase(it);
 }
 void DevicePool::trim() {
+    trims += 1;
     (void)hipDeviceSynchronize();
     for (auto& lane : idle_) {
         for (auto& kv : lane) {

@@ -62,7 +62,10 @@ public:
     // growth diagnostics (fhelin_stats slots 9..11): blocks obtained from hipMalloc, their bytes, host time spent inside hipMalloc
     u64 malloc_calls = 0, malloc_bytes = 0, malloc_ns = 0;
     u64 foreign_frees = 0;
+    u64 trims = 0;                              // out-of-memory events: everything idle handed back (a device-wide synchronisation each)
+    size_t live_peak = 0, reserved_peak = 0;    // high-water marks: bytes in use, bytes held from the driver
 private:
+    size_t live_bytes_ = 0;
     struct Live { size_t bytes; int lane; };
     struct Idle { void* p; hipEvent_t ev; };   // ev: last use on a foreign lane's stream (null: none)
     std::unordered_map<void*, Live> live_;

@@ -125,7 +125,9 @@ int fhelin_ntt(fhelin_ctx* c, uint64_t* d_data, int32_t nvec, int32_t limb_first
 /* host-side operation counters since the last reset: [0] limb-NTTs, [1] key switches, [2] sum of live limbs over
  * key switches, [3] rescales, [4] ct x pt products, [5] bootstraps, [6] plaintext encodes, and with cap >= 9:
  * [7] sum of live limbs over rescales, [8] sum of live limbs over ct x pt products, and with cap >= 12 the growth of the
- * device pool: [9] blocks obtained from hipMalloc, [10] their bytes, [11] host nanoseconds spent inside hipMalloc */
+ * device pool: [9] blocks obtained from hipMalloc, [10] their bytes, [11] host nanoseconds spent inside hipMalloc, and with
+ * cap >= 16: [12] bytes the pool holds from the driver now, [13] / [14] high-water marks of bytes in use / held since the last
+ * reset, [15] out-of-memory events (everything idle handed back: a device-wide synchronisation each) */
 int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset);
 
 
