@@ -373,11 +373,13 @@ def encoder1(ctl, w, enc, trace=None, full_attention=False):
     Q = ctl.matmulRE(inputs, query_w, query_b)                                              # :183
     K = ctl.matmulRE(inputs_E, key_w, key_b)                                                # :184
     K_wrapped = ctl.wrapUpRepeated(K)                                                       # :186
+    t["K_wrapped"] = K_wrapped
     value_w = ctl.read_plain_input(w["WV"].T)
     value_b = ctl.read_plain_repeated_input(w["BV"])
     if not full_attention:
         # src/main.cpp:196-224 — attention for the CLS query only; the other tokens' attention output is an encrypted zero
-        scores = ctl.matmulScores(Q[0], K_wrapped)                                          # :196
+        q0 = t["Q0"] = Q[0]                                 # (the trace keeps handles for the tests; unread handles cost nothing)
+        scores = ctl.matmulScores(q0, K_wrapped)                                            # :196
         t["scores"] = scores
         scores = ctl.eval_exp(scores, 32)                                                   # :197
         t["exp"] = scores

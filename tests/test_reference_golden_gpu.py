@@ -1,0 +1,64 @@
+"""The encrypted pass against NUMBERS THE REFERENCE ITSELF PRODUCED.
+
+tests/golden/plain_forward_s129.json holds what the reference's own src/python/compute_simple.py main() printed for the synthetic
+model (weights seed 1234, tokens seed 4321, S = 129; tests/golden/make_golden.py ran it in the build container): `Q[0]`, `K`, `logits`,
+`x` and `exp_approx` (compute_simple.py:161-184).  Up to that point the encrypted circuit of src/main.cpp:176-197 computes the same
+quantities (its departures from the NumPy model - suffix-sum softmax denominators, per-token affine scales, DESIGN.md 7c - come later):
+  * Q[0]      = the CLS query projection, matmulRE row 0 (src/main.cpp:183): slots 0..127 of the repeated layout;
+  * K         = the key projections wrapped 32 x 128 (src/main.cpp:184-186): block i of K_wrapped is K[i] (the fixture holds rows 0, 1);
+  * logits    = Q[0] K^T: matmulScores leaves q.K_i / 64 at slot 128 i (src/FHEController.cpp:1028-1048: 1/8 for the softmax scale
+                r, 1/8 "later corrected with e^(x/r)"), so 64 x scores = logits;
+  * exp_approx = Taylor-6 of logits/8, where eval_exp computes (Taylor-6 of logits/64)^8 (src/FHEController.cpp:1289-1311): both are
+                e^(logits/8) up to their truncation errors.
+This is the only parity the image allows against reference-held numbers (OpenFHE is absent: the residue-level oracle stays
+"parity unpinned").  Tolerances: the fixture is float32 arithmetic printed with 8 digits (about 1e-6 absolute on these values), the
+encrypted values carry CKKS noise of about 1e-8 at this depth; stated bound 1e-5.  exp: |x| <= 0.1 on the synthetic model, the two
+truncations differ by < 1e-9 there, same 1e-5 bound (a wrong exponent - r = 1/8 vs 1/64, the ^8 left out - would be off by >= 1e-3)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOL = 1e-5
+
+
+def test_encrypted_attention_inputs_match_the_reference_fixture(fa):
+    from fhe_linformer_amd import linformer as lf
+    from oracle import plain_forward as pf
+    g = json.load(open(os.path.join(HERE, "golden", "plain_forward_s129.json")))
+    assert g["source"].startswith("reference src/python/compute_simple.py")
+    w = pf.synthetic_model(g["weights_seed"])
+    x_in, X_E, X_F = pf.client_inputs(w, pf.synthetic_tokens(g["S"], g["tokens_seed"]))
+    eng = fa.Engine("reference", seed=5)
+    try:
+        eng.keygen()
+        eng.gen_relin_key()
+        eng.gen_rotation_keys(fa.circuit_rotation_indices())
+        eng.bootstrap_setup(3, 3, 16384)
+        tr = {}
+        out = lf.forward(lf.GpuController(eng), w, x_in, X_E, X_F, tr)
+        q0 = eng.decrypt(tr["Q0"])
+        kw = eng.decrypt(tr["K_wrapped"])
+        sc = eng.decrypt(tr["scores"])
+        ex = eng.decrypt(tr["exp"])
+        lg = lf.logits_from_slots(eng.decrypt(out))
+    finally:
+        eng.close()
+    ref_q0, ref_k, ref_logits, ref_x, ref_exp = (np.array(g[k]) for k in ("Q[0]", "K", "logits", "x", "exp_approx"))
+    err = {"Q[0]": np.max(np.abs(q0[:128] - ref_q0)),
+           "Q[0] repeated": np.max(np.abs(q0 - np.tile(ref_q0, 128))),                     # the repeated layout of matmulRE's output
+           "K rows 0,1": np.max(np.abs(kw[:256] - ref_k)),
+           "logits": np.max(np.abs(64.0 * sc[np.arange(32) * 128] - ref_logits)),
+           "x": np.max(np.abs(8.0 * sc[np.arange(32) * 128] - ref_x)),
+           "exp_approx": np.max(np.abs(ex[np.arange(32) * 128] - ref_exp))}
+    print("max abs error vs the reference's printed values:", {k: float(f"{v:.3g}") for k, v in err.items()})
+    for k, v in err.items():
+        assert v < TOL, (k, v)
+    assert np.max(np.abs(ref_x)) < 0.1          # the premise of the exp bound
+    # ... and the pass these intermediates belong to ends where the circuit says (tests/test_forward_gpu.py has the tolerance story)
+    from oracle import circuit_sim as cs
+    ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, x_in, X_E, X_F))
+    assert np.max(np.abs(lg - ref)) < 2e-2
