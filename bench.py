@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--key-seed", type=int, default=2024, help="deterministic key seed, the same on every rank (replicated keys)")
     ap.add_argument("--tokens", type=int, default=129, help="tokens per sample (S); S+1 rows incl. CLS, 128 < S+1 <= 256")
     ap.add_argument("--log-n", type=int, default=16)
+    ap.add_argument("--variant", choices=["main", "main_2"], default="main", help="the driver: src/main.cpp as built (attention for the CLS query "
+                    "only) or src/main_2.cpp (attention for every token; BASELINE config 5 names it with --log-n 17 --n-q 30)")
     ap.add_argument("--n-q", type=int, default=28)
     ap.add_argument("--n-p", type=int, default=0, help="special limbs (0: OpenFHE's rule ceil(widest digit bits / 60) = 7 for 28 limbs)")
     ap.add_argument("--ntt-batch", type=int, default=8, help="ciphertexts per NTT step per GPU")
@@ -468,7 +470,7 @@ def main():
             eng.level_plan_begin("record")
             enc_rec = lf.encrypt_inputs(ctl0, *pf.client_inputs(w, x))
             n_client_sources = sum(len(v) for v in enc_rec.values())      # the client's encryptions are the pass's first sources
-            eng.decrypt(lf.forward_encrypted(ctl0, w, enc_rec))
+            eng.decrypt(lf.forward_encrypted(ctl0, w, enc_rec, None, args.variant))
             plan = eng.level_plan_end()
             del enc_rec
 
@@ -477,7 +479,7 @@ def main():
         def server_pass(enc):
             if use_plan:
                 eng.level_plan_begin("apply", first_source=n_client_sources)
-            return lf.forward_encrypted(ctl, w, enc)
+            return lf.forward_encrypted(ctl, w, enc, None, args.variant)
 
         def server_pass_batched(encs):
             # passes of the driver with every value `width` ciphertexts wide (this rank's share of the step: n_pass passes)
@@ -485,7 +487,7 @@ def main():
             for lo in range(0, len(encs), width):
                 if use_plan:
                     eng.level_plan_begin("apply", first_source=n_client_sources * width)
-                outs.extend(lf.forward_encrypted(bctl, w, lf.batch_inputs(encs[lo:lo + width])))
+                outs.extend(lf.forward_encrypted(bctl, w, lf.batch_inputs(encs[lo:lo + width]), None, args.variant))
             return outs
 
         eng.sync()
@@ -586,7 +588,7 @@ def main():
         oracle_cache = {}
         for x_i, lg in zip(timed_inputs, logits):
             if id(x_i) not in oracle_cache:                    # a set that the steps cycled through more than once: one oracle pass
-                oracle_cache[id(x_i)] = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, *pf.client_inputs(w, x_i)))
+                oracle_cache[id(x_i)] = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, *pf.client_inputs(w, x_i), None, args.variant))
             ref = oracle_cache[id(x_i)]
             e_i = float(np.max(np.abs(lg - ref)))
             top2 = np.sort(ref)[-2:]
@@ -617,10 +619,10 @@ def main():
             if use_plan:
                 eng.level_plan_begin("off")
                 enc_full = lf.encrypt_inputs(ctl0, *pf.client_inputs(w, samples[-1][0]))
-                unplanned_ms = timed_passes(lambda: lf.forward_encrypted(ctl, w, enc_full))
+                unplanned_ms = timed_passes(lambda: lf.forward_encrypted(ctl, w, enc_full, None, args.variant))
                 # ... with every row evaluated as well: the reference's literal operation sequence at the reference's own levels
                 eng.set_lazy_rows(False)
-                literal_ms = timed_passes(lambda: lf.forward_encrypted(ctl, w, enc_full))
+                literal_ms = timed_passes(lambda: lf.forward_encrypted(ctl, w, enc_full, None, args.variant))
                 eng.set_lazy_rows(True)
                 del enc_full
             else:
@@ -629,7 +631,7 @@ def main():
             if rank == 0:
                 print(json.dumps({"metric": "encrypted Linformer-d128 forward ms/sample (profiling run)",
                                   "value": round(elapsed * 1e3 / (n_timed * world), 2), "unit": "ms/sample", "n_gpus": world,
-                                  "steps": args.steps, "warmup": args.warmup, "log_n": args.log_n,
+                                  "steps": args.steps, "warmup": args.warmup, "log_n": args.log_n, "n_q": eng.n_q, "n_p": eng.n_p, "variant": args.variant,
                                   "host_issue_ms_per_sample": round(host_enqueue * 1e3 / n_timed, 2), "ops_per_sample": stats, "device_pool": pool_now,
                                   "samples_per_pass": width, "passes_per_step": n_pass if batched else per_rank, "distinct_input_sets": n_sets,
                                   "logit_err_vs_circuit_oracle": round(err, 5), "level_plan": bool(plan)}))
@@ -712,7 +714,7 @@ def main():
                 "ms_per_step": round(fwd["elapsed"] * 1e3 / args.steps, 2), "higher_is_better": False,
                 "scaling": "strong" if (args.batch > 0 or row_mode) else "weak",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-                "config": {"workload": f"forward: {per_rank} sample(s)/GPU/step, S={args.tokens}+CLS tokens, d=128, k=32, FFN 512, 20 classes, "
+                "config": {"workload": f"forward ({'src/main.cpp' if args.variant == 'main' else 'src/main_2.cpp'} call sequence): {per_rank} sample(s)/GPU/step, S={args.tokens}+CLS tokens, d=128, k=32, FFN 512, 20 classes, "
                                        f"N=2^{eng.log_n}, 16384 slots, {eng.n_q}+{eng.n_p} limbs, dnum 4, {fwd['stats']['bootstrap']} bootstraps; "
                                        f"deferred rows on, level plan {'on' if fwd['plan'] else 'off'} (ms_per_sample_cells has the other three combinations)",
                            "ops_per_sample": fwd["stats"],
@@ -764,7 +766,7 @@ def main():
                                                  "every sample of the run stays resident",
                            "client_ingest_first_touch_ms_per_sample": round(fwd["client_first_ms"], 2),
                            "client_ingest_first_touch_pool_growth": fwd["client_pool"]},
-                "ntt": {"metric": "NTT/s at N=2^16", "value": round(ntt_rate, 1), "unit": "limb-NTT/s",
+                "ntt": {"metric": f"NTT/s at N=2^{eng.log_n}", "value": round(ntt_rate, 1), "unit": "limb-NTT/s",
                         "workload": f"fwd+inv NTT of {args.ntt_batch} ciphertexts x 2 polys x {nq} limbs per GPU"},
                 "roofline": roofline,
             }
@@ -777,7 +779,7 @@ def main():
                     "roofline": roofline}
         else:
             line = {
-                "metric": "NTT/s at N=2^16 (limb-NTTs per second)", "value": round(ntt_rate, 1), "unit": "limb-NTT/s",
+                "metric": f"NTT/s at N=2^{eng.log_n} (limb-NTTs per second)", "value": round(ntt_rate, 1), "unit": "limb-NTT/s",
                 "n_gpus": world, "steps": args.ntt_steps, "warmup": 3, "ms_per_step": round(ntt_ms / args.ntt_steps, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                 "config": {"workload": f"ntt: fwd+inv negacyclic NTT of {args.ntt_batch} ciphertexts x 2 polys x {nq} limbs, N=2^{eng.log_n} per GPU",

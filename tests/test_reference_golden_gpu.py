@@ -12,8 +12,9 @@ quantities (its departures from the NumPy model - suffix-sum softmax denominator
                 e^(logits/8) up to their truncation errors.
 This is the only parity the image allows against reference-held numbers (OpenFHE is absent: the residue-level oracle stays
 "parity unpinned").  Tolerances: the fixture is float32 arithmetic printed with 8 digits (about 1e-6 absolute on these values), the
-encrypted values carry CKKS noise of about 1e-8 at this depth; stated bound 1e-5.  exp: |x| <= 0.1 on the synthetic model, the two
-truncations differ by < 1e-9 there, same 1e-5 bound (a wrong exponent - r = 1/8 vs 1/64, the ^8 left out - would be off by >= 1e-3)."""
+encrypted values carry CKKS noise of about 1e-8 at this depth; stated bound 2e-6 (measured: 1.3e-7 ... 1.6e-7, the fixture's own
+precision).  exp: |x| <= 0.1 on the synthetic model, the two
+truncations differ by < 1e-9 there, same bound (a wrong exponent - r = 1/8 vs 1/64, the ^8 left out - would be off by >= 1e-3)."""
 import json
 import os
 
@@ -22,7 +23,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-TOL = 1e-5
+TOL = 2e-6
 
 
 def test_encrypted_attention_inputs_match_the_reference_fixture(fa):
