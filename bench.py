@@ -690,7 +690,7 @@ def main():
         achieved = n_ntt * alg_bytes / (ntt_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # PMC passes of this round's kernels (tools/profile_kernels.sh)
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and eng.log_n == 16:     # the counters were collected at N=2^16
             try:
                 traffic = json.load(open(tpath)).get("ntt_bytes_per_limb_transform")
             except Exception:
