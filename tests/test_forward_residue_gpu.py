@@ -29,6 +29,13 @@ def desc_depth(eng):
         reason="src/main_2.cpp (attention for every token; +2 minutes of CPU oracle time); last runs recorded in "
                "profiles/r03_u_cpu_forward_pass_main2_n15.json (same residues: true) and, on the final build of round 3, "
                "profiles/r03_bq_main2_residue_test.txt (1 passed); FHELIN_SLOW_TESTS=1 runs it")),
+    # BASELINE config 5's ring (N=2^17, 30 limbs) under a level plan: minutes of CPU oracle time and ~50 GB of exported keys
+    pytest.param("deep", True, "main", marks=pytest.mark.skipif(
+        not __import__("os").environ.get("FHELIN_SLOW_TESTS"), reason="N=2^17: ~6 minutes of CPU oracle time; FHELIN_SLOW_TESTS=1 runs it "
+        "(recorded: profiles/r04_h_deep_residue_test.txt)")),
+    pytest.param("deep", True, "main_2", marks=pytest.mark.skipif(
+        __import__("os").environ.get("FHELIN_SLOW_TESTS") != "2", reason="N=2^17, src/main_2.cpp: ~12 minutes of CPU oracle time, more than one "
+        "GPU-box call allows next to the GPU pass; FHELIN_SLOW_TESTS=2 runs it")),
 ])
 def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc, preset, planned, variant):
     from fhe_linformer_amd import linformer as lf
@@ -40,7 +47,7 @@ def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc, preset, plan
     S = 129
     w = pf.synthetic_model(1234)
     x_in, X_E, X_F = pf.client_inputs(w, pf.synthetic_tokens(S, 4321))
-    eng = fa.Engine(preset, seed=11, n_q=28, n_p=-1)
+    eng = fa.Engine(preset, seed=11, n_q=30 if preset == "deep" else 28, n_p=-1)
     try:
         eng.keygen()
         eng.gen_relin_key()
@@ -74,10 +81,12 @@ def test_complete_forward_pass_bit_exact_vs_residue_oracle(fa, orc, preset, plan
             other = pf.client_inputs(w, pf.synthetic_tokens(S, 999))
             eng.decrypt(lf.forward(lf.GpuController(eng), w, *other, None, variant))
             plan = eng.level_plan_end()
-            # sources in call order: 194 client encryptions, the encrypted zero (src/main.cpp:220), 8 bootstraps, the encrypted mask (:472)
-            assert len(plan) == 194 + 1 + 8 + 1
+            # sources in call order: 194 client encryptions, the encrypted zero (src/main.cpp:220), 8 bootstraps, the encrypted mask (:472);
+            # src/main_2.cpp has neither of the two server-side encryptions
+            extra = 1 if variant == "main" else 0
+            assert len(plan) == 194 + 8 + 2 * extra
             out_ell = eng.n_q - desc_depth(eng)
-            drops = [max(0, out_ell - t) if t >= 1 else 0 for t in plan[195:203]]
+            drops = [max(0, out_ell - t) if t >= 1 else 0 for t in plan[194 + extra:202 + extra]]
             assert any(drops)
             eng.level_plan_begin("apply")
         tr = {}
