@@ -209,7 +209,16 @@ int fhelin_level_plan_set(fhelin_ctx* c, const int32_t* target, int32_t n) {
 int fhelin_sync(fhelin_ctx* c) {
     if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
     FHELIN_TRY
-    if (!c->pending_heavy.empty()) flush_heavy(c);   // deferred bootstraps / polynomial evaluations count as issued work
+    // deferred bootstraps / polynomial evaluations count as issued work; the first failure among them is this call's error
+    // (everything that could be evaluated has been: the device is synchronised either way)
+    if (!c->pending_heavy.empty()) {
+        try {
+            flush_heavy(c, true);
+        } catch (...) {
+            c->ctx.sync();
+            throw;
+        }
+    }
     c->ctx.sync();
     FHELIN_CATCH
 }
@@ -218,7 +227,7 @@ int fhelin_ctx_trim(fhelin_ctx* c) {
     if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
     FHELIN_TRY
     c->ctx.require_device();
-    if (!c->pending_heavy.empty()) flush_heavy(c);
+    if (!c->pending_heavy.empty()) flush_heavy(c, true);
     c->ctx.sync();
     c->ctx.pool.trim();
     FHELIN_CATCH
@@ -236,6 +245,7 @@ int fhelin_timer_stop(fhelin_ctx* c, float* ms) {
     if (!c || !ms) return capi_fail(FHELIN_ERR_ARG, "null argument");
     FHELIN_TRY
     c->ctx.require_device();
+    if (!c->pending_heavy.empty()) flush_heavy(c);   // deferred operations issued inside the timed region belong to it
     hip_check(hipEventRecord(c->ctx.ev_stop, c->ctx.stream), "hipEventRecord");
     hip_check(hipEventSynchronize(c->ctx.ev_stop), "hipEventSynchronize");
     hip_check(hipEventElapsedTime(ms, c->ctx.ev_start, c->ctx.ev_stop), "hipEventElapsedTime");

@@ -1,6 +1,7 @@
 // extern "C" boundary, part 3: one entry point per FHEController composite method.
 #include "../../include/fhelin.h"
 #include <algorithm>
+#include <functional>
 #include "capi_internal.h"
 
 using namespace fhelin;
@@ -102,53 +103,97 @@ void force_rows(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx) {
 }
 // Deferred heavy operations: everything pending, in dependency order; per round the ready operations of one kind, one
 // parameter set and one input shape go through ONE batched call.
-void flush_heavy(fhelin_ctx* c) {
+// A batched call that throws fails ONLY its own group (and, transitively, the operations that read its results); every other ready
+// group is still evaluated.  The failure stays with the operation: reading its handle reports it (force), fhelin_sync reports the
+// first one of the flush; reading an unrelated result succeeds.
+static void fail_op(LazyHeavy& h, int code, const std::string& msg) {
+    h.done = h.failed = true;
+    h.err_code = code;
+    h.err_msg = msg;
+    h.in.reset();
+    h.in_heavy.reset();
+    h.in2.reset();
+    h.in2_heavy.reset();
+}
+void flush_heavy(fhelin_ctx* c, bool report) {
     std::vector<std::shared_ptr<LazyHeavy>> pend;
     pend.swap(c->pending_heavy);
-    try {
-        for (;;) {
-            std::vector<LazyHeavy*> ready;
-            bool waiting = false;
-            for (auto& sp : pend) {
-                LazyHeavy& h = *sp;
-                if (h.done) continue;
-                if (sp.use_count() == 1) {   // every handle to the result is gone and nothing pending reads it: never evaluated
-                    h.done = h.failed = true;
-                    h.in.reset();
-                    h.in_heavy.reset();
-                    h.in2.reset();
-                    h.in2_heavy.reset();
-                    continue;
-                }
-                if (h.in_heavy && h.in_heavy->done) {
-                    if (h.in_heavy->failed || !h.in_heavy->result) throw Error(FHELIN_ERR_STATE, "a deferred operation's input failed earlier");
-                    h.in = h.in_heavy->result;
-                    h.in_heavy.reset();
-                }
-                if (h.in2_heavy && h.in2_heavy->done) {
-                    if (h.in2_heavy->failed || !h.in2_heavy->result) throw Error(FHELIN_ERR_STATE, "a deferred operation's input failed earlier");
-                    h.in2 = h.in2_heavy->result;
-                    h.in2_heavy.reset();
-                }
-                if (h.in && (h.kind != LazyHeavy::Add || h.in2)) ready.push_back(&h);
-                else waiting = true;
+    int first_code = 0;
+    std::string first_msg;
+    auto note_failure = [&](int code, const std::string& msg) {
+        if (!first_code) {
+            first_code = code;
+            first_msg = msg;
+        }
+    };
+    // run one batched call over `grp`; a throw fails exactly these operations
+    auto guarded = [&](const std::vector<LazyHeavy*>& grp, const std::function<void()>& run) {
+        try {
+            run();
+        } catch (const Error& e) {
+            for (LazyHeavy* g : grp) fail_op(*g, e.code, e.what());
+            note_failure(e.code, e.what());
+        } catch (const std::exception& e) {
+            for (LazyHeavy* g : grp) fail_op(*g, FHELIN_ERR_INTERNAL, e.what());
+            note_failure(FHELIN_ERR_INTERNAL, e.what());
+        }
+    };
+    for (;;) {
+        std::vector<LazyHeavy*> ready;
+        bool waiting = false;
+        for (auto& sp : pend) {
+            LazyHeavy& h = *sp;
+            if (h.done) continue;
+            if (sp.use_count() == 1) {   // every handle to the result is gone and nothing pending reads it: never evaluated
+                fail_op(h, FHELIN_ERR_STATE, "never evaluated: no handle to the result was left");
+                continue;
             }
-            if (ready.empty()) {
-                if (waiting) throw Error(FHELIN_ERR_INTERNAL, "deferred heavy operations: dependency cycle");
-                break;
-            }
-            std::vector<char> taken(ready.size(), 0);
-            {   // every ready addition of the round in ONE batched call (Evaluator::add_batch aligns levels per group of rows)
-                CtVec as, bs;
-                std::vector<LazyHeavy*> adds;
-                for (size_t k = 0; k < ready.size(); ++k)
-                    if (ready[k]->kind == LazyHeavy::Add) {
-                        adds.push_back(ready[k]);
-                        as.push_back(ready[k]->in);
-                        bs.push_back(ready[k]->in2);
-                        taken[k] = 1;
+            bool dep_failed = false;
+            std::string why;
+            for (auto* dep : {&h.in_heavy, &h.in2_heavy})
+                if (*dep && (*dep)->done) {
+                    if ((*dep)->failed || !(*dep)->result) {
+                        dep_failed = true;
+                        why = (*dep)->err_msg;
+                    } else {
+                        (dep == &h.in_heavy ? h.in : h.in2) = (*dep)->result;
+                        dep->reset();
                     }
-                if (!adds.empty()) {
+                }
+            if (dep_failed) {
+                fail_op(h, FHELIN_ERR_STATE, "a deferred operation this one reads failed earlier: " + why);
+                continue;
+            }
+            if (h.in && (h.kind != LazyHeavy::Add || h.in2)) ready.push_back(&h);
+            else waiting = true;
+        }
+        if (ready.empty()) {
+            if (waiting) {   // cannot happen (an operation only ever reads earlier ones); fail what is left rather than spin
+                for (auto& sp : pend)
+                    if (!sp->done) fail_op(*sp, FHELIN_ERR_INTERNAL, "deferred heavy operations: dependency cycle");
+                note_failure(FHELIN_ERR_INTERNAL, "deferred heavy operations: dependency cycle");
+            }
+            break;
+        }
+        std::vector<char> taken(ready.size(), 0);
+        {   // every ready addition of the round in ONE batched call (Evaluator::add_batch aligns levels per group of rows); additions whose
+            // operands cannot be added (component counts differ) fail on their own, before the batch
+            CtVec as, bs;
+            std::vector<LazyHeavy*> adds;
+            for (size_t k = 0; k < ready.size(); ++k)
+                if (ready[k]->kind == LazyHeavy::Add) {
+                    taken[k] = 1;
+                    if (ready[k]->in->npoly != ready[k]->in2->npoly) {
+                        fail_op(*ready[k], FHELIN_ERR_STATE, "add: component count mismatch");
+                        note_failure(FHELIN_ERR_STATE, "add: component count mismatch");
+                        continue;
+                    }
+                    adds.push_back(ready[k]);
+                    as.push_back(ready[k]->in);
+                    bs.push_back(ready[k]->in2);
+                }
+            if (!adds.empty())
+                guarded(adds, [&] {
                     CtVec out = adds.size() == 1 ? CtVec{c->ev.add(as[0], bs[0])} : c->ev.add_batch(as, bs);
                     for (size_t k = 0; k < adds.size(); ++k) {
                         adds[k]->result = out[k];
@@ -156,22 +201,23 @@ void flush_heavy(fhelin_ctx* c) {
                         adds[k]->in.reset();
                         adds[k]->in2.reset();
                     }
+                });
+        }
+        for (size_t first = 0; first < ready.size(); ++first) {
+            if (taken[first]) continue;
+            LazyHeavy& f = *ready[first];
+            std::vector<LazyHeavy*> grp;
+            for (size_t k = first; k < ready.size(); ++k) {
+                LazyHeavy& g = *ready[k];
+                const bool same = !taken[k] && g.kind == f.kind && g.in->ell == f.in->ell && g.in->deg == f.in->deg &&
+                                  g.in->npoly == f.in->npoly &&
+                                  (f.kind == LazyHeavy::Boot ? g.drop == f.drop : (g.a == f.a && g.b == f.b && g.coeffs == f.coeffs));
+                if (same) {
+                    grp.push_back(&g);
+                    taken[k] = 1;
                 }
             }
-            for (size_t first = 0; first < ready.size(); ++first) {
-                if (taken[first]) continue;
-                LazyHeavy& f = *ready[first];
-                std::vector<LazyHeavy*> grp;
-                for (size_t k = first; k < ready.size(); ++k) {
-                    LazyHeavy& g = *ready[k];
-                    const bool same = !taken[k] && g.kind == f.kind && g.in->ell == f.in->ell && g.in->deg == f.in->deg &&
-                                      g.in->npoly == f.in->npoly &&
-                                      (f.kind == LazyHeavy::Boot ? g.drop == f.drop : (g.a == f.a && g.b == f.b && g.coeffs == f.coeffs));
-                    if (same) {
-                        grp.push_back(&g);
-                        taken[k] = 1;
-                    }
-                }
+            guarded(grp, [&] {
                 CtVec in;
                 for (LazyHeavy* g : grp) in.push_back(g->in);
                 CtVec out = f.kind == LazyHeavy::Boot ? c->boot.bootstrap_batch(in, f.drop) : c->ev.eval_chebyshev_many(in, f.coeffs, f.a, f.b);
@@ -180,19 +226,10 @@ void flush_heavy(fhelin_ctx* c) {
                     grp[k]->done = true;
                     grp[k]->in.reset();
                 }
-            }
+            });
         }
-    } catch (...) {
-        for (auto& sp : pend)
-            if (!sp->done) {
-                sp->done = sp->failed = true;
-                sp->in.reset();
-                sp->in_heavy.reset();
-                sp->in2.reset();
-                sp->in2_heavy.reset();
-            }
-        throw;
     }
+    if (report && first_code) throw Error(first_code, "a deferred operation failed: " + first_msg);
 }
 // a handle to a deferred heavy operation on `a` (itself possibly deferred)
 static fhelin_ct* defer_heavy(fhelin_ctx* c, const fhelin_ct* a, const std::shared_ptr<LazyHeavy>& op) {
@@ -200,6 +237,10 @@ static fhelin_ct* defer_heavy(fhelin_ctx* c, const fhelin_ct* a, const std::shar
         op->in_heavy = a->heavy;
     } else {
         op->in = ct_in(c, a);
+        // what can be checked now is checked now: the offending call reports it, not a later read
+        if (op->in->npoly != 2) throw Error(FHELIN_ERR_STATE, "bootstrap / polynomial evaluation: the ciphertext must have 2 components (relinearise first)");
+        if (op->kind == LazyHeavy::Cheb && op->in->ell - (op->in->deg >= 2 ? 1 : 0) < 2)
+            throw Error(FHELIN_ERR_STATE, "polynomial evaluation: no limb left for a multiplication");
     }
     c->pending_heavy.push_back(op);
     auto* h = new fhelin_ct;
@@ -215,6 +256,7 @@ fhelin_ct* defer_add(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b) {
     else op->in = ct_in(c, a);
     if (!b->p && b->heavy && !b->heavy->done) op->in2_heavy = b->heavy;
     else op->in2 = ct_in(c, b);
+    if (op->in && op->in2 && op->in->npoly != op->in2->npoly) throw Error(FHELIN_ERR_STATE, "add: component count mismatch");
     c->pending_heavy.push_back(op);
     auto* h = new fhelin_ct;
     h->heavy = op;
@@ -673,6 +715,7 @@ int fhelin_eval_chebyshev(fhelin_ctx* c, const fhelin_ct* x, const double* coeff
     NEED(c && x && coeffs && out);
     FHELIN_TRY
     const std::vector<double> cf(coeffs, coeffs + n);
+    if (n < 2) throw Error(FHELIN_ERR_ARG, "eval_chebyshev: need degree >= 1");
     if (defer_ok(c)) {
         auto op = std::make_shared<LazyHeavy>();
         op->kind = LazyHeavy::Cheb;

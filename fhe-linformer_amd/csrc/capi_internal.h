@@ -84,6 +84,8 @@ struct LazyHeavy {
     int drop = 0;                           // Boot: limbs left out under a level plan
     CtPtr result;
     bool done = false, failed = false;
+    int err_code = 0;                       // failed: what the batched call that evaluated it threw (reported when the handle is read)
+    std::string err_msg;
 };
 }
 // opaque handle behind include/fhelin.h's `fhelin_ctx`
@@ -154,14 +156,17 @@ std::vector<int> rows_for_read(LazyRows& g, const std::vector<int>& idx);
 // inputs[i]), src/main.cpp:237-239): everything that is left is evaluated in one batched call instead of row by row.
 void force_group(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx);
 // evaluate every pending deferred heavy operation, batched (capi_composite.cpp)
-void flush_heavy(fhelin_ctx* c);
+// report: throw the first failure of this flush (fhelin_sync / fhelin_ctx_trim: "evaluate everything pending"); a read of ONE result
+// (force) does not - it reports that result's own failure, if any, and leaves the others' to their readers
+void flush_heavy(fhelin_ctx* c, bool report = false);
 fhelin_ct* defer_add(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b);
 bool defer_allowed(fhelin_ctx* c);
 inline void force(fhelin_ctx* c, const fhelin_ct* h) {
     if (!h->p && h->heavy) {
         if (!h->heavy->done) flush_heavy(c);
         if (h->heavy->failed || !h->heavy->result)
-            throw Error(FHELIN_ERR_STATE, "a deferred bootstrap / polynomial evaluation this value depends on failed earlier");
+            throw Error(h->heavy->err_code ? h->heavy->err_code : FHELIN_ERR_STATE,
+                        "deferred operation failed: " + (h->heavy->err_msg.empty() ? std::string("no result") : h->heavy->err_msg));
         h->p = h->heavy->result;
         h->heavy.reset();
         return;
