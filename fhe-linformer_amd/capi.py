@@ -96,6 +96,7 @@ def load_library():
         "fhelin_dev_download": (i32, [vp, vp, vp, C.c_size_t]),
         "fhelin_ntt": (i32, [vp, vp, i32, i32, i32, i32]),
         "fhelin_stats": (i32, [vp, u64p, i32, i32]),
+        "fhelin_debug_pool_selftest": (i32, [C.c_uint64, i32, C.c_uint64, u64p, i32]),
         "fhelin_keygen": (i32, [vp]),
         "fhelin_gen_relin_key": (i32, [vp]),
         "fhelin_gen_rotation_keys": (i32, [vp, C.POINTER(i32), i32]),

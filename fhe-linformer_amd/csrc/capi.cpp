@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include "context.h"
+#include <map>
 #include "capi_internal.h"
 
 using namespace fhelin;
@@ -330,6 +331,105 @@ int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset) {
     }
     if (reset) s = OpStats();
     return FHELIN_OK;
+}
+
+
+// ---- host-side self-test of the device arena's logic (no GPU: a mock backend hands out address ranges of a pretend device) -----------
+namespace {
+size_t g_mock_cap = 0, g_mock_used = 0, g_mock_cursor = 0;
+std::map<uintptr_t, size_t> g_mock_blocks;
+void* mock_malloc(size_t bytes) {
+    if (g_mock_used + bytes > g_mock_cap) return nullptr;
+    g_mock_used += bytes;
+    const uintptr_t p = (uintptr_t(1) << 40) + g_mock_cursor;     // never dereferenced
+    g_mock_cursor += bytes + (size_t(1) << 21);
+    g_mock_blocks[p] = bytes;
+    return reinterpret_cast<void*>(p);
+}
+void mock_free(void* p) {
+    auto it = g_mock_blocks.find(reinterpret_cast<uintptr_t>(p));
+    if (it == g_mock_blocks.end()) throw fhelin::Error(FHELIN_ERR_INTERNAL, "mock backend: free of unknown slab");
+    g_mock_used -= it->second;
+    g_mock_blocks.erase(it);
+}
+}  // namespace
+int fhelin_debug_pool_selftest(uint64_t seed, int32_t n_ops, uint64_t device_bytes, uint64_t* out, int32_t cap) {
+    if (!out || cap < 6 || n_ops < 1) return capi_fail(FHELIN_ERR_ARG, "pool selftest: need room for 6 results");
+    FHELIN_TRY
+    g_mock_cap = device_bytes;
+    g_mock_used = g_mock_cursor = 0;
+    g_mock_blocks.clear();
+    DevicePool::Backend be;
+    be.malloc_fn = mock_malloc;
+    be.free_fn = mock_free;
+    {
+        DevicePool pool(be);
+        std::map<uintptr_t, size_t> live;       // what the test believes is allocated: address -> bytes asked
+        std::vector<uintptr_t> order;
+        u64 x = seed * 0x9E3779B97F4A7C15ull + 1;
+        auto rnd = [&]() {
+            x ^= x << 13;
+            x ^= x >> 7;
+            x ^= x << 17;
+            return x;
+        };
+        size_t want_live = 0, peak_live = 0, oom = 0;
+        for (int op = 0; op < n_ops; ++op) {
+            const bool do_alloc = live.empty() || (rnd() % 100) < 55;
+            if (do_alloc) {
+                // the engine's mix: limb vectors (512 KiB), ciphertexts (tens of MiB), batch blocks (GBs), odd small tables
+                size_t bytes;
+                switch (rnd() % 6) {
+                    case 0: bytes = 256 + rnd() % 8192; break;
+                    case 1: bytes = (size_t(512) << 10) * (1 + rnd() % 8); break;
+                    case 2: bytes = (size_t(1) << 20) * (2 + rnd() % 56); break;
+                    case 3: bytes = (size_t(1) << 20) * (64 + rnd() % 400); break;
+                    case 4: bytes = (size_t(1) << 20) * (147); break;
+                    default: bytes = (size_t(1) << 20) * (1024 + rnd() % 5000); break;
+                }
+                void* p = nullptr;
+                try {
+                    p = pool.alloc(bytes);
+                } catch (const Error&) {
+                    ++oom;          // the pretend device is full: legitimate when what is live plus this request exceeds it
+                    if (want_live + bytes + (size_t(64) << 20) < device_bytes / 2) throw Error(FHELIN_ERR_INTERNAL, "pool selftest: out of memory at less than half the device");
+                    continue;
+                }
+                const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+                auto nx = live.lower_bound(a);
+                if (nx != live.end() && a + bytes > nx->first) throw Error(FHELIN_ERR_INTERNAL, "pool selftest: block overlaps its successor");
+                if (nx != live.begin()) {
+                    auto pv = std::prev(nx);
+                    if (pv->first + pv->second > a) throw Error(FHELIN_ERR_INTERNAL, "pool selftest: block overlaps its predecessor");
+                }
+                bool inside = false;
+                for (const auto& b : g_mock_blocks) inside = inside || (a >= b.first && a + bytes <= b.first + b.second);
+                if (!inside) throw Error(FHELIN_ERR_INTERNAL, "pool selftest: block outside every slab");
+                live[a] = bytes;
+                order.push_back(a);
+                want_live += bytes;
+                peak_live = std::max(peak_live, want_live);
+            } else {
+                const size_t k = rnd() % order.size();
+                const uintptr_t a = order[k];
+                order[k] = order.back();
+                order.pop_back();
+                want_live -= live[a];
+                live.erase(a);
+                pool.free(reinterpret_cast<void*>(a));
+            }
+        }
+        out[0] = peak_live;
+        out[1] = pool.reserved_peak;
+        out[2] = pool.malloc_calls;
+        out[3] = oom;
+        for (uintptr_t a : order) pool.free(reinterpret_cast<void*>(a));
+        // everything free: every slab is ONE free range again (coalescing), and a trim hands all of it back
+        out[4] = pool.free_ranges() == pool.slabs() && pool.bytes_live() == 0 ? 1 : 0;
+        pool.trim();
+        out[5] = pool.bytes_reserved() == 0 && g_mock_used == 0 ? 1 : 0;
+    }
+    FHELIN_CATCH
 }
 
 }  // extern "C"

@@ -13,60 +13,142 @@ void hip_check(hipError_t e, const char* what) {
 }
 
 // ---------------------------------------------------------------- DevicePool
+void* DevicePool::raw_malloc(size_t bytes) {
+    if (backend_.malloc_fn) return backend_.malloc_fn(bytes);
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();  // the failure is handled by the caller; do not leave it for the next launch check
+        return nullptr;
+    }
+    return p;
+}
+void DevicePool::raw_free(void* p) {
+    if (backend_.free_fn) backend_.free_fn(p);
+    else (void)hipFree(p);
+}
 DevicePool::~DevicePool() {
-    for (auto& lane : idle_)
-        for (auto& kv : lane) {
-            if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
-            (void)hipFree(kv.second.p);
-        }
+    for (auto& ln : lane_) {
+        for (auto& pk : ln.parked)
+            if (pk.ev) (void)hipEventDestroy(pk.ev);
+        for (auto& sl : ln.slabs)
+            if (sl.base) raw_free(sl.base);
+    }
     for (hipEvent_t e : spare_events_) (void)hipEventDestroy(e);
-    for (auto& kv : live_) (void)hipFree(kv.first);
+}
+size_t DevicePool::slabs() const {
+    size_t n = 0;
+    for (const auto& ln : lane_)
+        for (const auto& sl : ln.slabs) n += sl.base != nullptr;
+    return n;
+}
+size_t DevicePool::free_ranges() const {
+    size_t n = 0;
+    for (const auto& ln : lane_) n += ln.by_size.size();
+    return n;
+}
+void DevicePool::erase_size_entry(Lane& ln, int slab, size_t off, size_t len) {
+    auto r = ln.by_size.equal_range(len);
+    for (auto it = r.first; it != r.second; ++it)
+        if (it->second.first == slab && it->second.second == off) {
+            ln.by_size.erase(it);
+            return;
+        }
+    throw Error(FHELIN_ERR_INTERNAL, "DevicePool: free list out of step");
+}
+// a range goes back into its slab's free list, merged with the free ranges it touches
+void DevicePool::insert_free(Lane& ln, int slab, size_t off, size_t len) {
+    Slab& sl = ln.slabs[slab];
+    auto nxt = sl.free_at.lower_bound(off);
+    if (nxt != sl.free_at.begin()) {
+        auto prv = std::prev(nxt);
+        if (prv->first + prv->second == off) {
+            off = prv->first;
+            len += prv->second;
+            erase_size_entry(ln, slab, prv->first, prv->second);
+            sl.free_at.erase(prv);
+        }
+    }
+    if (nxt != sl.free_at.end() && off + len == nxt->first) {
+        len += nxt->second;
+        erase_size_entry(ln, slab, nxt->first, nxt->second);
+        sl.free_at.erase(nxt);
+    }
+    sl.free_at[off] = len;
+    ln.by_size.emplace(len, std::make_pair(slab, off));
+}
+// one more slab for this lane, large enough for `bytes`: geometric growth, so that a small context stays small and a large one
+// reaches the slab size in a few steps
+bool DevicePool::grow(Lane& ln, size_t bytes) {
+    size_t want = std::max(bytes, std::min(SLAB_MAX, std::max(SLAB_MIN, reserved_)));
+    want = (want + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    void* p = raw_malloc(want);
+    if (!p && want > bytes) {   // not that much left: exactly what is asked for
+        want = (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+        p = raw_malloc(want);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (!p) return false;
+    malloc_calls += 1;
+    malloc_bytes += want;
+    malloc_ns += (u64)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
+    reserved_ += want;
+    if (reserved_ > reserved_peak) reserved_peak = reserved_;
+    int idx = -1;
+    for (size_t i = 0; i < ln.slabs.size(); ++i)
+        if (!ln.slabs[i].base) idx = (int)i;      // a slot a trim has emptied
+    if (idx < 0) {
+        ln.slabs.emplace_back();
+        idx = (int)ln.slabs.size() - 1;
+    }
+    Slab& sl = ln.slabs[idx];
+    sl.base = static_cast<char*>(p);
+    sl.size = want;
+    sl.used = 0;
+    sl.free_at.clear();
+    insert_free(ln, idx, 0, want);
+    return true;
 }
 void* DevicePool::alloc(size_t bytes) {
     if (bytes == 0) bytes = 256;
-    bytes = (bytes + 255) & ~size_t(255);
-    // size classes 2^k x {1, 1.25, 1.5, 1.75} above 1 MiB: batches of slightly different row counts share blocks instead
-    // of each parking its own exact size in the idle lists (<= 25 % slack)
-    if (bytes > (size_t(1) << 20)) {
-        size_t p2 = size_t(1) << 20;
-        while (p2 * 2 <= bytes) p2 *= 2;
-        const size_t step = p2 / 4;
-        bytes = (bytes + step - 1) / step * step;
-    }
-    auto& idle = idle_[cur_lane];
-    // best fit: the smallest idle block of this lane that holds the request and wastes at most a quarter of itself again (a block
-    // keeps its own size: it goes back to the idle list as what it is).  Exact-size matching alone lets the pool hoard blocks of
-    // every size a pass has ever asked for - with many samples per pass that is what runs the device out of memory, and every
-    // out-of-memory costs a device-wide synchronisation (trim).
-    auto it = idle.lower_bound(bytes);
-    if (it != idle.end() && it->first > bytes + bytes / 4) it = idle.end();
-    void* p = nullptr;
-    if (it != idle.end()) {
-        bytes = it->first;
-        p = it->second.p;
-        if (it->second.ev) {
-            // last used by work on another lane's stream: this lane's stream goes behind it (no host wait)
-            hip_check(hipStreamWaitEvent(lane_stream[cur_lane], it->second.ev, 0), "hipStreamWaitEvent(pool reuse)");
-            spare_events_.push_back(it->second.ev);
+    // 256-byte granules for small blocks, 4 KiB above 64 KiB (fewer distinct fragment sizes)
+    const size_t gran = bytes > (size_t(64) << 10) ? 4096 : 256;
+    bytes = (bytes + gran - 1) & ~(gran - 1);
+    Lane& ln = lane_[cur_lane];
+    // ranges that were freed under another lane: this lane's stream goes behind that use (no host wait), then they are ordinary
+    // free memory of this lane
+    if (!ln.parked.empty()) {
+        for (auto& pk : ln.parked) {
+            if (pk.ev) {
+                hip_check(hipStreamWaitEvent(lane_stream[cur_lane], pk.ev, 0), "hipStreamWaitEvent(pool reuse)");
+                spare_events_.push_back(pk.ev);
+            }
+            insert_free(ln, pk.slab, pk.off, pk.len);
         }
-        idle.erase(it);
-    } else {
-        timespec t0, t1;
-        clock_gettime(CLOCK_MONOTONIC, &t0);
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();  // the failure is handled here; do not leave it for the next launch check
-            trim();
-            hip_check(hipMalloc(&p, bytes), "hipMalloc");
-        }
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        malloc_calls += 1;
-        malloc_bytes += bytes;
-        malloc_ns += (u64)((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec));
-        reserved_ += bytes;
-        if (reserved_ > reserved_peak) reserved_peak = reserved_;
+        ln.parked.clear();
     }
-    live_[p] = Live{bytes, cur_lane};
+    auto it = ln.by_size.lower_bound(bytes);
+    if (it == ln.by_size.end()) {
+        if (!grow(ln, bytes)) {
+            trim();                                            // out of memory: give back what holds nothing, then once more
+            if (!grow(ln, bytes)) throw Error(FHELIN_ERR_HIP, "hipMalloc: out of device memory (" + std::to_string(bytes >> 20) + " MiB asked, " +
+                                                                  std::to_string(reserved_ >> 20) + " MiB held, " + std::to_string(live_bytes_ >> 20) + " MiB in use)");
+        }
+        it = ln.by_size.lower_bound(bytes);
+    }
+    const int slab = it->second.first;
+    const size_t off = it->second.second, len = it->first;
+    Slab& sl = ln.slabs[slab];
+    ln.by_size.erase(it);
+    sl.free_at.erase(off);
+    if (len > bytes) {
+        sl.free_at[off + bytes] = len - bytes;
+        ln.by_size.emplace(len - bytes, std::make_pair(slab, off + bytes));
+    }
+    sl.used += bytes;
+    void* p = sl.base + off;
+    live_[p] = Live{bytes, cur_lane, slab, off};
     live_bytes_ += bytes;
     if (live_bytes_ > live_peak) live_peak = live_bytes_;
     return p;
@@ -75,9 +157,14 @@ void DevicePool::free(void* p) {
     if (!p) return;
     auto it = live_.find(p);
     if (it == live_.end()) throw Error(FHELIN_ERR_STATE, "DevicePool::free of unknown pointer");
-    hipEvent_t ev = nullptr;
-    if (have_streams && it->second.lane != cur_lane) {
+    const Live lv = it->second;
+    live_.erase(it);
+    live_bytes_ -= lv.bytes;
+    Lane& ln = lane_[lv.lane];
+    ln.slabs[lv.slab].used -= lv.bytes;
+    if (have_streams && lv.lane != cur_lane) {
         // freed under another lane than the one that owns it: whatever that lane's stream has queued so far may still read it
+        hipEvent_t ev = nullptr;
         if (!spare_events_.empty()) {
             ev = spare_events_.back();
             spare_events_.pop_back();
@@ -86,21 +173,28 @@ void DevicePool::free(void* p) {
         }
         hip_check(hipEventRecord(ev, lane_stream[cur_lane]), "hipEventRecord(pool free)");
         foreign_frees += 1;
+        ln.parked.push_back(Parked{lv.slab, lv.off, lv.bytes, ev});
+        return;
     }
-    idle_[it->second.lane].emplace(it->second.bytes, Idle{p, ev});  // back to the lane (stream) that owns it
-    live_bytes_ -= it->second.bytes;
-    live_.erase(it);
+    insert_free(ln, lv.slab, lv.off, lv.bytes);
 }
 void DevicePool::trim() {
     trims += 1;
-    (void)hipDeviceSynchronize();
-    for (auto& lane : idle_) {
-        for (auto& kv : lane) {
-            if (kv.second.ev) spare_events_.push_back(kv.second.ev);
-            (void)hipFree(kv.second.p);
-            reserved_ -= kv.first;
+    if (!backend_.malloc_fn) (void)hipDeviceSynchronize();
+    for (auto& ln : lane_) {
+        for (auto& pk : ln.parked) {            // the device is idle: parked ranges are plain free memory
+            if (pk.ev) spare_events_.push_back(pk.ev);
+            insert_free(ln, pk.slab, pk.off, pk.len);
         }
-        lane.clear();
+        ln.parked.clear();
+        for (size_t i = 0; i < ln.slabs.size(); ++i) {
+            Slab& sl = ln.slabs[i];
+            if (!sl.base || sl.used != 0) continue;
+            erase_size_entry(ln, (int)i, 0, sl.size);   // an unused slab is one free range
+            raw_free(sl.base);
+            reserved_ -= sl.size;
+            sl = Slab();
+        }
     }
 }
 

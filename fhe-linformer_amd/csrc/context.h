@@ -43,35 +43,66 @@ struct Error : std::runtime_error {
 
 void hip_check(hipError_t e, const char* what);
 
-// Size-bucketed caching allocator.  Work is stream-ordered, so a freed block can be handed out again immediately —
-// to the SAME stream.  With several lanes (streams) every block belongs to the lane that allocated it and only
-// that lane's idle list gets it back.  A block that is freed while ANOTHER lane is current (a worker lane's result
-// consumed and released on the main stream, or the reverse) may still be read by work queued on that other lane's
-// stream: the free records an event there and the owner lane's stream waits for it before the block's next use.
+// Device memory arena (sized for the 288 GB of an MI355X: the key set, the resident inputs and the intermediates of a batched pass
+// share it).  Memory comes from the driver in SLABS (few, large hipMalloc calls: geometric growth up to 8 GiB a slab, or the
+// request itself when that is larger) and is handed out by BEST FIT from an address-ordered free list with coalescing: a freed
+// block merges with its free neighbours, so the ciphertext blocks of one stage (say 6 GB of unwrapped rows) are carved up again by
+// the next one, whatever its sizes.  (Rounds 1-3 cached freed blocks by exact size class: with many samples per pass the idle
+// lists held 1.6 x the bytes in use and the device ran out of memory - every time at the price of a device-wide synchronisation.)
+// Work is stream-ordered, so a freed block can be handed out again immediately - to the SAME stream.  With several lanes (streams)
+// every lane has its own slabs and free list; a block that is freed while ANOTHER lane is current (a worker lane's result consumed
+// and released on the main stream, or the reverse) may still be read by work queued on that other lane's stream: the free records
+// an event there, and the owner lane's stream waits for it before the range goes back into the owner's free list.
+// The backend (hipMalloc / hipFree) is replaceable: the allocator's logic is unit-tested on the host (fhelin_debug_pool_selftest).
 class DevicePool {
 public:
     static constexpr int MAX_LANES = 5;  // lane 0 = main stream
+    static constexpr size_t SLAB_MAX = size_t(8) << 30, SLAB_MIN = size_t(32) << 20;
+    struct Backend {
+        void* (*malloc_fn)(size_t) = nullptr;   // null: hipMalloc / hipFree
+        void (*free_fn)(void*) = nullptr;
+    };
+    DevicePool() = default;
+    explicit DevicePool(const Backend& b) : backend_(b) {}
     ~DevicePool();
     void* alloc(size_t bytes);
     void free(void* p);
-    void trim();
+    void trim();                                // hand slabs that hold nothing back to the driver (synchronises the device first)
     size_t bytes_reserved() const { return reserved_; }
+    size_t bytes_live() const { return live_bytes_; }
+    size_t slabs() const;
+    size_t free_ranges() const;
     int cur_lane = 0;
     hipStream_t lane_stream[MAX_LANES] = {};   // set by the Context: the stream each lane launches on (lane 0 = main stream)
     bool have_streams = false;
-    // growth diagnostics (fhelin_stats slots 9..11): blocks obtained from hipMalloc, their bytes, host time spent inside hipMalloc
+    // growth diagnostics (fhelin_stats slots 9..11): slabs obtained from hipMalloc, their bytes, host time spent inside hipMalloc
     u64 malloc_calls = 0, malloc_bytes = 0, malloc_ns = 0;
     u64 foreign_frees = 0;
-    u64 trims = 0;                              // out-of-memory events: everything idle handed back (a device-wide synchronisation each)
+    u64 trims = 0;                              // out-of-memory events: empty slabs handed back (a device-wide synchronisation each)
     size_t live_peak = 0, reserved_peak = 0;    // high-water marks: bytes in use, bytes held from the driver
 private:
-    size_t live_bytes_ = 0;
-    struct Live { size_t bytes; int lane; };
-    struct Idle { void* p; hipEvent_t ev; };   // ev: last use on a foreign lane's stream (null: none)
+    struct Slab {
+        char* base = nullptr;
+        size_t size = 0, used = 0;
+        std::map<size_t, size_t> free_at;       // offset -> length of the free ranges, address-ordered
+    };
+    struct Live { size_t bytes; int lane; int slab; size_t off; };
+    struct Parked { int slab; size_t off, len; hipEvent_t ev; };   // freed under a foreign lane: waits for the event
+    struct Lane {
+        std::vector<Slab> slabs;
+        std::multimap<size_t, std::pair<int, size_t>> by_size;      // length -> (slab, offset): best fit
+        std::vector<Parked> parked;
+    };
+    Backend backend_;
+    Lane lane_[MAX_LANES];
     std::unordered_map<void*, Live> live_;
-    std::multimap<size_t, Idle> idle_[MAX_LANES];
     std::vector<hipEvent_t> spare_events_;
-    size_t reserved_ = 0;
+    size_t reserved_ = 0, live_bytes_ = 0;
+    void insert_free(Lane& ln, int slab, size_t off, size_t len);
+    void erase_size_entry(Lane& ln, int slab, size_t off, size_t len);
+    bool grow(Lane& ln, size_t bytes);
+    void* raw_malloc(size_t bytes);
+    void raw_free(void* p);
 };
 
 // Per-level constants of hybrid key switching / rescale, resident on the device.

@@ -129,6 +129,11 @@ int fhelin_ntt(fhelin_ctx* c, uint64_t* d_data, int32_t nvec, int32_t limb_first
  * cap >= 16: [12] bytes the pool holds from the driver now, [13] / [14] high-water marks of bytes in use / held since the last
  * reset, [15] out-of-memory events (everything idle handed back: a device-wide synchronisation each) */
 int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset);
+/* host-side self-test of the device memory arena (slabs, best fit, coalescing) against a pretend device of device_bytes: n_ops random
+ * allocations / frees in the engine's size mix; checks that blocks never overlap, lie inside a slab, that freeing everything leaves one
+ * free range per slab and that a trim returns every slab.  out (cap >= 6): [0] peak bytes in use, [1] peak bytes held, [2] slabs
+ * obtained, [3] out-of-memory events, [4] coalesced-to-one-range-per-slab (1/0), [5] trim-returned-everything (1/0).  No GPU needed. */
+int fhelin_debug_pool_selftest(uint64_t seed, int32_t n_ops, uint64_t device_bytes, uint64_t* out, int32_t cap);
 
 
 /* ---- keys (client side; sampling on the host, polynomial arithmetic on the GPU) ---------------- */

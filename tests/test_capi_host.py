@@ -136,3 +136,19 @@ def test_level_plan_bookkeeping_on_a_host_context(fa):
     assert e.lib.fhelin_level_plan_seek(e.h, 1) == 4         # a recording runs from its first source
     assert e.level_plan_end() == []                          # nothing was recorded: an empty plan replaces the old one
     e.close()
+
+
+def test_device_arena_logic_on_a_pretend_device(fa):
+    """csrc/context.cpp DevicePool (slabs from the driver, best fit, address-ordered free list with coalescing) against a mock backend:
+    blocks never overlap and lie inside a slab, the pool follows the bytes in use closely (the exact-size caching pool it replaces
+    held 1.6 x), freeing everything leaves one free range per slab, and a trim hands every slab back."""
+    import ctypes as C
+    lib = fa.load_library()
+    for seed, dev in ((1, 288 << 30), (2, 288 << 30), (3, 16 << 30)):
+        out = np.zeros(6, dtype=np.uint64)
+        rc = lib.fhelin_debug_pool_selftest(seed, 6000, dev, out.ctypes.data_as(C.POINTER(C.c_uint64)), 6)
+        assert rc == 0, lib.fhelin_last_error()
+        peak_live, peak_held, slabs, oom, coalesced, trimmed = (int(v) for v in out)
+        assert coalesced == 1 and trimmed == 1
+        assert peak_held <= dev and slabs >= 1
+        assert peak_held <= 1.25 * peak_live + (8 << 30), (peak_held / 2**30, peak_live / 2**30)
