@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--pass-width", type=int, default=4, help="with --batch: at most this many samples travel in ONE pass (a pass keeps ~17 GB of "
                     "intermediates per sample at N=2^16 next to ~50 GB of keys: 4 fit 288 GB with room for the resident inputs, 8 do not); "
                     "a rank's share of a step runs as ceil(share / width) passes")
+    ap.add_argument("--lanes", type=int, default=1, help="with --batch: a pass runs as this many sub-batches on as many lanes (HIP streams) of the ONE "
+                    "context, concurrently on the GPU (linformer.LanedBatchedController); 1: one launch set for the whole pass")
     ap.add_argument("--batch-loop", action="store_true", help="with --batch: a rank runs its samples one after another instead (A/B)")
     ap.add_argument("--resident-gb", type=float, default=75.0, help="with --batch: device memory for the resident input sets of the "
                     "timed region; steps cycle through the sets that fit (every pass still does all of its work)")
@@ -59,7 +61,9 @@ def parse():
                     "unwrap loops split over the ranks (all-gather of ciphertext rows over RCCL/xGMI per row loop)")
     ap.add_argument("--no-ops", action="store_true", help="skip the short leaf-op section of a forward run")
     ap.add_argument("--no-level-plan", action="store_true", help="run every pass at the levels the driver asks for (no recorded level plan)")
-    ap.add_argument("--inflight", type=int, default=2, help="after the timed region (one sample in flight: `value`), also measure the "
+    ap.add_argument("--throughput-batch", type=int, default=4, help="after the timed region (one sample per pass: `value`), also measure passes that "
+                    "carry this many samples through the SAME engine (one key set: linformer.BatchedController); 0/1: skip")
+    ap.add_argument("--inflight", type=int, default=0, help="after the timed region (one sample in flight: `value`), also measure the "
                     "throughput with this many samples in flight on the GPU, one engine (context, stream, host thread) each; 0/1: skip")
     ap.add_argument("--forward-only", action="store_true", help="profiling runs: only the timed forward passes (no eager comparison, "
                     "no NTT / op sections, no CPU leg); prints a reduced line without `roofline`")
@@ -452,7 +456,8 @@ def main():
         while batched and per_rank % n_pass:
             n_pass += 1
         width = per_rank // n_pass if batched else 1
-        bctl = lf.BatchedController(eng, width) if batched else None
+        laned = batched and args.lanes > 1 and width % args.lanes == 0
+        bctl = (lf.LanedBatchedController(eng, width, args.lanes) if laned else lf.BatchedController(eng, width)) if batched else None
         n_sets = args.warmup + args.steps                    # distinct input sets (one set = a rank's samples of one step)
         if batched:
             n_sets = max(1, min(n_sets, int(args.resident_gb / (4.5 * per_rank * (eng.N / 65536.0)))))
@@ -487,7 +492,11 @@ def main():
             for lo in range(0, len(encs), width):
                 if use_plan:
                     eng.level_plan_begin("apply", first_source=n_client_sources * width)
+                if laned:
+                    bctl.begin()
                 outs.extend(lf.forward_encrypted(bctl, w, lf.batch_inputs(encs[lo:lo + width]), None, args.variant))
+                if laned:
+                    bctl.end()
             return outs
 
         eng.sync()
@@ -633,21 +642,69 @@ def main():
                                   "value": round(elapsed * 1e3 / (n_timed * world), 2), "unit": "ms/sample", "n_gpus": world,
                                   "steps": args.steps, "warmup": args.warmup, "log_n": args.log_n, "n_q": eng.n_q, "n_p": eng.n_p, "variant": args.variant,
                                   "host_issue_ms_per_sample": round(host_enqueue * 1e3 / n_timed, 2), "ops_per_sample": stats, "device_pool": pool_now,
-                                  "samples_per_pass": width, "passes_per_step": n_pass if batched else per_rank, "distinct_input_sets": n_sets,
+                                  "samples_per_pass": width, "passes_per_step": n_pass if batched else per_rank, "lanes": args.lanes if (batched and laned) else 1, "distinct_input_sets": n_sets,
                                   "logit_err_vs_circuit_oracle": round(err, 5), "level_plan": bool(plan)}))
             eng.close()
             if dist:
                 dist.destroy_process_group()
             return
         fwd = {"elapsed": elapsed, "stats": stats, "logit_err_vs_circuit_oracle": err, "logit_err_mean": err_sum / max(1, len(logits)),
-               "batched": batched, "n_sets": n_sets, "pool": pool_now, "width": width, "n_pass": n_pass if batched else per_rank, "host_enqueue_ms": host_enqueue * 1e3 / max(1, n_timed), "pred": int(np.argmax(logits[-1])),
+               "batched": batched, "n_sets": n_sets, "pool": pool_now, "width": width, "lanes": args.lanes if (batched and laned) else 1, "n_pass": n_pass if batched else per_rank, "host_enqueue_ms": host_enqueue * 1e3 / max(1, n_timed), "pred": int(np.argmax(logits[-1])),
                "samples_checked": len(logits), "eager_ms": eager_ms, "client_ms": client_ms, "unplanned_ms": unplanned_ms, "literal_ms": literal_ms,
                "client_first_ms": client_first_ms, "client_pool": client_pool,
                "plan": plan, "n_client_sources": n_client_sources}
         for _, enc in samples:
             del enc
         samples = None
-        # ---- secondary figure: K samples in flight on the one GPU (throughput; `value` above stays the one-sample-at-a-time pass)
+        # ---- secondary figure: B samples per pass through the SAME engine (BASELINE config 4's per-GPU unit; `value` above stays one sample per pass)
+        fwd["tb"] = None
+        Bt = args.throughput_batch
+        if Bt > 1 and world == 1 and not row_mode and not batched:
+            eng.trim()
+            tctl = lf.BatchedController(eng, Bt)
+            xs = [pf.synthetic_tokens(S, 9100 + i) for i in range(Bt)]
+            if use_plan:
+                eng.set_level_plan(plan)
+            encs_t = []
+            for x in xs:
+                if use_plan:
+                    eng.level_plan_begin("apply")
+                encs_t.append(lf.ingest_sample(ctl0, w, x))
+            if use_plan:
+                eng.set_level_plan(lf.batched_level_plan(plan, Bt, n_client_sources))
+
+            def tpass():
+                if use_plan:
+                    eng.level_plan_begin("apply", first_source=n_client_sources * Bt)
+                return lf.forward_encrypted(tctl, w, lf.batch_inputs(encs_t), None, args.variant)
+            outs_t = tpass()
+            lg_t = [lf.logits_from_slots(eng.decrypt(o)) for o in outs_t]
+            eng.sync()
+            eng.stats(reset=True)
+            t1 = time.perf_counter()
+            n_tp = 2
+            for _ in range(n_tp):
+                for o in tpass():
+                    eng.decrypt(o)
+            eng.sync()
+            tb_ms = (time.perf_counter() - t1) * 1e3 / (n_tp * Bt)
+            st_t = eng.stats()
+            err_t = 0.0
+            for x, lg in zip(xs, lg_t):
+                ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, *pf.client_inputs(w, x), None, args.variant))
+                err_t = max(err_t, float(np.max(np.abs(lg - ref))))
+            assert err_t < 2e-2, f"batched pass: encrypted logits differ from the circuit oracle ({err_t})"
+            fwd["tb"] = {"samples_per_pass": Bt, "ms_per_sample": round(tb_ms, 2), "passes_timed": n_tp, "logit_err_vs_circuit_oracle": round(err_t, 5),
+                         "device_pool_in_use_peak_GB": round(st_t["pool_live_peak_bytes"] / 1e9, 1),
+                         "device_pool_held_GB": round(st_t["pool_reserved_bytes"] / 1e9, 1),
+                         "out_of_memory_trims": st_t["pool_trims"],
+                         "note": "ONE engine, one key set, one plaintext cache: every call of the driver carries the rows of all samples of the pass "
+                                 "(linformer.BatchedController); each sample ends in the residues of its own single pass (tests/test_batched_forward_gpu.py); "
+                                 "per-sample latency is the whole pass.  `value` is the one-sample-per-pass figure."}
+            if use_plan:
+                eng.set_level_plan(plan)
+            del encs_t, outs_t
+        # ---- K samples in flight on the one GPU, one engine EACH (replicated keys; off by default since round 4: the batched pass above shares one key set)
         fwd["inflight"] = None
         if args.inflight > 1 and world == 1 and not row_mode:
             fwd["inflight"] = inflight_section(fa, lf, pf, np, eng, ctl, w, S, args, use_plan, n_client_sources, plan)
@@ -721,6 +778,7 @@ def main():
                            "parallelism": (f"ONE sample per step, rows of its matmul / unwrap loops over {world} ranks, keys replicated"
                                            if row_mode else f"independent samples x{world}, keys replicated (one key seed)"),
                            "samples_per_pass": fwd["width"],
+                           "lanes_per_pass": fwd["lanes"],
                            "passes_per_step_per_gpu": fwd["n_pass"],
                            "samples_per_pass_note": ("ONE pass of the driver carries this many samples through one engine (linformer.BatchedController: one key set, "
                                                      "one plaintext cache, one launch set; every sample ends in the residues of its own single pass, "
@@ -758,6 +816,8 @@ def main():
                                "deferred_rows=off,level_plan=off (every call of the reference's driver evaluated in full where it is made, at the driver's own levels)": round(fwd["literal_ms"], 2),
                                "how": "value: the timed region (steps x passes, max over ranks); the other cells: 2 passes each after one untimed "
                                       "pass, same build, same process, after the timed region"},
+                           "ms_per_sample_with_4_samples_per_pass": (fwd["tb"] or {}).get("ms_per_sample") if (fwd["tb"] or {}).get("samples_per_pass") == 4 else None,
+                           "throughput_with_several_samples_per_pass": fwd["tb"],
                            "throughput_with_samples_in_flight": fwd["inflight"],
                            "client_ingest_ms_per_sample": round(fwd["client_ms"], 2),
                            "client_ingest_note": "fhelin_client_ingest: positional embedding, the two Linformer projections, packing, encoding and encryption of the sample's "

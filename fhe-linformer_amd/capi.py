@@ -87,6 +87,9 @@ def load_library():
         "fhelin_level_plan_get": (i32, [vp, C.POINTER(i32), i32, C.POINTER(i32)]),
         "fhelin_level_plan_set": (i32, [vp, C.POINTER(i32), i32]),
         "fhelin_sync": (i32, [vp]),
+        "fhelin_ctx_set_lane": (i32, [vp, i32]),
+        "fhelin_ctx_lanes_fork": (i32, [vp]),
+        "fhelin_ctx_lanes_join": (i32, [vp]),
         "fhelin_ctx_trim": (i32, [vp]),
         "fhelin_timer_start": (i32, [vp]),
         "fhelin_timer_stop": (i32, [vp, f32p]),
@@ -340,6 +343,16 @@ class Engine:
 
     def sync(self):
         self._ck(self.lib.fhelin_sync(self.h))
+
+    def set_lane(self, k):
+        """subsequent calls launch on lane k's stream (0 = the main stream) and allocate from its arena"""
+        self._ck(self.lib.fhelin_ctx_set_lane(self.h, int(k)))
+
+    def lanes_fork(self):
+        self._ck(self.lib.fhelin_ctx_lanes_fork(self.h))
+
+    def lanes_join(self):
+        self._ck(self.lib.fhelin_ctx_lanes_join(self.h))
 
     def trim(self):
         """release the device memory the caching pool holds but does not use"""

@@ -212,9 +212,9 @@ int fhelin_sync(fhelin_ctx* c) {
     FHELIN_TRY
     // deferred bootstraps / polynomial evaluations count as issued work; the first failure among them is this call's error
     // (everything that could be evaluated has been: the device is synchronised either way)
-    if (!c->pending_heavy.empty()) {
+    if (c->any_pending()) {
         try {
-            flush_heavy(c, true);
+            flush_heavy_all(c, true);
         } catch (...) {
             c->ctx.sync();
             throw;
@@ -224,11 +224,40 @@ int fhelin_sync(fhelin_ctx* c) {
     FHELIN_CATCH
 }
 
+int fhelin_ctx_set_lane(fhelin_ctx* c, int32_t lane) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    FHELIN_TRY
+    c->ctx.require_device();
+    if (lane < 0 || lane > c->ctx.n_lanes) throw Error(FHELIN_ERR_ARG, "set_lane: the context has lanes 0.." + std::to_string(c->ctx.n_lanes));
+    c->user_lane = lane;
+    c->ctx.stream = lane == 0 ? c->ctx.main_stream : c->ctx.lane_stream[lane];
+    c->ctx.pool.cur_lane = lane;
+    FHELIN_CATCH
+}
+int fhelin_ctx_lanes_fork(fhelin_ctx* c) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    FHELIN_TRY
+    c->ctx.require_device();
+    if (c->user_lane != 0) throw Error(FHELIN_ERR_STATE, "lanes_fork: call it under lane 0");
+    if (!c->pending_heavy[0].empty()) flush_heavy(c);     // what the lanes are about to read exists
+    c->ctx.fork_lanes();
+    FHELIN_CATCH
+}
+int fhelin_ctx_lanes_join(fhelin_ctx* c) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    FHELIN_TRY
+    c->ctx.require_device();
+    if (c->user_lane != 0) throw Error(FHELIN_ERR_STATE, "lanes_join: call it under lane 0");
+    if (c->any_pending()) flush_heavy_all(c);
+    c->ctx.join_lanes();
+    FHELIN_CATCH
+}
+
 int fhelin_ctx_trim(fhelin_ctx* c) {
     if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
     FHELIN_TRY
     c->ctx.require_device();
-    if (!c->pending_heavy.empty()) flush_heavy(c, true);
+    if (c->any_pending()) flush_heavy_all(c, true);
     c->ctx.sync();
     c->ctx.pool.trim();
     FHELIN_CATCH
@@ -246,7 +275,7 @@ int fhelin_timer_stop(fhelin_ctx* c, float* ms) {
     if (!c || !ms) return capi_fail(FHELIN_ERR_ARG, "null argument");
     FHELIN_TRY
     c->ctx.require_device();
-    if (!c->pending_heavy.empty()) flush_heavy(c);   // deferred operations issued inside the timed region belong to it
+    if (c->any_pending()) flush_heavy_all(c);   // deferred operations issued inside the timed region belong to it
     hip_check(hipEventRecord(c->ctx.ev_stop, c->ctx.stream), "hipEventRecord");
     hip_check(hipEventSynchronize(c->ctx.ev_stop), "hipEventSynchronize");
     hip_check(hipEventElapsedTime(ms, c->ctx.ev_start, c->ctx.ev_stop), "hipEventElapsedTime");

@@ -117,7 +117,7 @@ static void fail_op(LazyHeavy& h, int code, const std::string& msg) {
 }
 void flush_heavy(fhelin_ctx* c, bool report) {
     std::vector<std::shared_ptr<LazyHeavy>> pend;
-    pend.swap(c->pending_heavy);
+    pend.swap(c->pending_heavy[c->ctx.pool.cur_lane]);
     int first_code = 0;
     std::string first_msg;
     auto note_failure = [&](int code, const std::string& msg) {
@@ -242,7 +242,8 @@ static fhelin_ct* defer_heavy(fhelin_ctx* c, const fhelin_ct* a, const std::shar
         if (op->kind == LazyHeavy::Cheb && op->in->ell - (op->in->deg >= 2 ? 1 : 0) < 2)
             throw Error(FHELIN_ERR_STATE, "polynomial evaluation: no limb left for a multiplication");
     }
-    c->pending_heavy.push_back(op);
+    op->lane = c->ctx.pool.cur_lane;
+    c->pending_heavy[op->lane].push_back(op);
     auto* h = new fhelin_ct;
     h->heavy = op;
     h->owner = c;
@@ -257,14 +258,48 @@ fhelin_ct* defer_add(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b) {
     if (!b->p && b->heavy && !b->heavy->done) op->in2_heavy = b->heavy;
     else op->in2 = ct_in(c, b);
     if (op->in && op->in2 && op->in->npoly != op->in2->npoly) throw Error(FHELIN_ERR_STATE, "add: component count mismatch");
-    c->pending_heavy.push_back(op);
+    op->lane = c->ctx.pool.cur_lane;
+    c->pending_heavy[op->lane].push_back(op);
     auto* h = new fhelin_ct;
     h->heavy = op;
     h->owner = c;
     return h;
 }
-bool defer_allowed(fhelin_ctx* c) { return c->lazy_heavy && c->plan.mode != 1 && c->ctx.stream == c->ctx.main_stream; }
-static bool defer_ok(fhelin_ctx* c) { return c->lazy_heavy && c->plan.mode != 1 && c->ctx.stream == c->ctx.main_stream; }
+// deferral on the context's main stream or on a lane the CALLER selected (fhelin_ctx_set_lane) - not inside the library's own lane scopes
+bool defer_allowed(fhelin_ctx* c) {
+    return c->lazy_heavy && c->plan.mode != 1 && c->ctx.pool.cur_lane == c->user_lane &&
+           c->ctx.stream == (c->user_lane ? c->ctx.lane_stream[c->user_lane] : c->ctx.main_stream);
+}
+static bool defer_ok(fhelin_ctx* c) { return defer_allowed(c); }
+void flush_heavy_all(fhelin_ctx* c, bool report) {
+    const int cur = c->ctx.pool.cur_lane;
+    hipStream_t cur_stream = c->ctx.stream;
+    int code = 0;
+    std::string msg;
+    for (int k = 0; k < DevicePool::MAX_LANES; ++k) {
+        if (c->pending_heavy[k].empty()) continue;
+        c->ctx.stream = k == 0 ? c->ctx.main_stream : c->ctx.lane_stream[k];
+        c->ctx.pool.cur_lane = k;
+        try {
+            flush_heavy(c, report);
+        } catch (const Error& e) {
+            if (!code) {
+                code = e.code;
+                msg = e.what();
+            }
+        }
+    }
+    c->ctx.stream = cur_stream;
+    c->ctx.pool.cur_lane = cur;
+    if (code) throw Error(code, msg);
+}
+void wait_for_lane(fhelin_ctx* c, int lane) {
+    Context& x = c->ctx;
+    if (lane == x.pool.cur_lane) return;
+    hipStream_t src = lane == 0 ? x.main_stream : x.lane_stream[lane];
+    hip_check(hipEventRecord(x.fork_event, src), "hipEventRecord(lane hand-over)");
+    hip_check(hipStreamWaitEvent(x.stream, x.fork_event, 0), "hipStreamWaitEvent(lane hand-over)");
+}
 
 void force_many(fhelin_ctx* c, const fhelin_ct* const* v, int n) {
     for (int i = 0; i < n; ++i)

@@ -86,6 +86,7 @@ struct LazyHeavy {
     bool done = false, failed = false;
     int err_code = 0;                       // failed: what the batched call that evaluated it threw (reported when the handle is read)
     std::string err_msg;
+    int lane = 0;                           // the lane (stream) the call was made under: it is evaluated there (fhelin_ctx_set_lane)
 };
 }
 // opaque handle behind include/fhelin.h's `fhelin_ctx`
@@ -97,7 +98,14 @@ struct fhelin_ctx {
     fhelin::Bootstrapper boot;
     bool lazy_rows = true;      // FHELIN_LAZY_ROWS
     bool lazy_heavy = true;     // FHELIN_LAZY_HEAVY
-    std::vector<std::shared_ptr<fhelin::LazyHeavy>> pending_heavy;
+    // deferred operations, per lane: a lane's pending operations are evaluated on that lane's stream (fhelin_ctx_set_lane)
+    std::vector<std::shared_ptr<fhelin::LazyHeavy>> pending_heavy[fhelin::DevicePool::MAX_LANES];
+    bool any_pending() const {
+        for (const auto& v : pending_heavy)
+            if (!v.empty()) return true;
+        return false;
+    }
+    int user_lane = 0;          // fhelin_ctx_set_lane: 0 = the context's main stream
     fhelin::LevelPlan plan;
     explicit fhelin_ctx(const fhelin::Params& p);
 };
@@ -158,12 +166,33 @@ void force_group(fhelin_ctx* c, LazyRows& g, const std::vector<int>& idx);
 // evaluate every pending deferred heavy operation, batched (capi_composite.cpp)
 // report: throw the first failure of this flush (fhelin_sync / fhelin_ctx_trim: "evaluate everything pending"); a read of ONE result
 // (force) does not - it reports that result's own failure, if any, and leaves the others' to their readers
-void flush_heavy(fhelin_ctx* c, bool report = false);
+void flush_heavy(fhelin_ctx* c, bool report = false);          // the CURRENT lane's pending operations
+void flush_heavy_all(fhelin_ctx* c, bool report = false);      // every lane's, each on its own stream
+// a value produced under lane `lane` is about to be read under the current one: order the current stream behind that lane's work
+void wait_for_lane(fhelin_ctx* c, int lane);
 fhelin_ct* defer_add(fhelin_ctx* c, const fhelin_ct* a, const fhelin_ct* b);
 bool defer_allowed(fhelin_ctx* c);
 inline void force(fhelin_ctx* c, const fhelin_ct* h) {
     if (!h->p && h->heavy) {
-        if (!h->heavy->done) flush_heavy(c);
+        if (!h->heavy->done) {
+            const int cur = c->ctx.pool.cur_lane, own = h->heavy->lane;
+            if (own == cur) {
+                flush_heavy(c);
+            } else {                 // issued under another lane: evaluated there, then this lane's stream goes behind it
+                c->ctx.stream = own == 0 ? c->ctx.main_stream : c->ctx.lane_stream[own];
+                c->ctx.pool.cur_lane = own;
+                try {
+                    flush_heavy(c);
+                } catch (...) {
+                    c->ctx.stream = cur == 0 ? c->ctx.main_stream : c->ctx.lane_stream[cur];
+                    c->ctx.pool.cur_lane = cur;
+                    throw;
+                }
+                c->ctx.stream = cur == 0 ? c->ctx.main_stream : c->ctx.lane_stream[cur];
+                c->ctx.pool.cur_lane = cur;
+                wait_for_lane(c, own);
+            }
+        }
         if (h->heavy->failed || !h->heavy->result)
             throw Error(h->heavy->err_code ? h->heavy->err_code : FHELIN_ERR_STATE,
                         "deferred operation failed: " + (h->heavy->err_msg.empty() ? std::string("no result") : h->heavy->err_msg));

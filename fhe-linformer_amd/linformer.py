@@ -322,6 +322,69 @@ class BatchedController:
     eval_tanh_function = GpuController.eval_tanh_function
 
 
+class LanedBatchedController:
+    """B samples through ONE engine as `lanes` sub-batches that run CONCURRENTLY on the GPU (include/fhelin.h fhelin_ctx_set_lane): every
+    call of the driver is made once per sub-batch, each under its own lane (HIP stream + memory arena) of the one context, from the
+    one host thread.  Same keys, same plaintext cache, same level plan as `BatchedController` - and the same residues per sample
+    (scheduling only) - but while one lane's launch drains, the other lane's fills the CUs: what two engines "in flight" gained in
+    round 3 at the price of a second key set.  Sub-batch k holds samples [k B/lanes, (k+1) B/lanes).
+    Use: ctl.begin() (lanes wait for the inputs) ... forward_encrypted(ctl, ...) ... ctl.end() (main stream waits for the lanes)."""
+
+    _ONCE = ("level", "encode", "read_plain_input", "read_plain_repeated_input", "read_plain_expanded_input")
+
+    def __init__(self, eng, B, lanes=2):
+        assert B % lanes == 0 and lanes >= 1
+        self.e, self.B, self.lanes, self.h = eng, B, lanes, B // lanes
+        self.sub = [BatchedController(eng, self.h) for _ in range(lanes)]
+        self.num_slots = SLOTS
+
+    @property
+    def n_boot(self):
+        return self.sub[0].n_boot
+
+    def begin(self):
+        self.e.set_lane(0)
+        self.e.lanes_fork()
+
+    def end(self):
+        self.e.set_lane(0)
+        self.e.lanes_join()
+
+    def _split(self, x, k):
+        if isinstance(x, Batch):
+            return Batch(x[k * self.h:(k + 1) * self.h])
+        if isinstance(x, (list, tuple)):
+            return [self._split(v, k) for v in x]
+        return x
+
+    def _merge(self, parts):
+        r0 = parts[0]
+        if isinstance(r0, Batch):
+            return Batch(h for p in parts for h in p)
+        if isinstance(r0, list):
+            return [self._merge([p[i] for p in parts]) for i in range(len(r0))]
+        return r0
+
+    def __getattr__(self, name):
+        if name in LanedBatchedController._ONCE:          # plaintexts / levels: the same for every sample, made once
+            def once(*a, **kw):
+                self.e.set_lane(1)
+                return getattr(self.sub[0], name)(*[self._split(v, 0) for v in a], **kw)
+            return once
+
+        def call(*a, **kw):
+            parts = []
+            for k in range(self.lanes):
+                self.e.set_lane(k + 1)
+                parts.append(getattr(self.sub[k], name)(*[self._split(v, k) for v in a], **kw))
+            return self._merge(parts)
+        return call
+
+    def decrypt(self, c):
+        self.e.set_lane(0)
+        return [self.e.decrypt(h, SLOTS) for h in c]
+
+
 def batched_level_plan(plan, B, n_client):
     """the level plan of a batched pass from the plan recorded on ONE sample (Engine.level_plan_end): the sources of a batched pass
     are the B samples' client encryptions (sample-major, n_client each) and then, call by call, B sources per source of the single pass"""

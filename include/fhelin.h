@@ -105,6 +105,17 @@ int fhelin_level_plan_end(fhelin_ctx* c, int32_t* n_sources);        /* record: 
 int fhelin_level_plan_get(fhelin_ctx* c, int32_t* target, int32_t cap, int32_t* n);   /* *n = length; fills min(cap, *n) */
 int fhelin_level_plan_set(fhelin_ctx* c, const int32_t* target, int32_t n);
 int fhelin_sync(fhelin_ctx* c);
+/* Lanes: a context owns a few extra HIP streams ("lanes" 1..n, FHELIN_LANES, default 2) besides its main stream (lane 0), each with
+ * its own arena of device memory.  After fhelin_ctx_set_lane(c, k) every call launches on lane k and allocates there, until the next
+ * set_lane; deferred operations (fhelin_bootstrap, ...) issued under a lane are evaluated on that lane.  Independent work - the two
+ * halves of a batch of samples, src/main.cpp:145-475 once per sample - issued alternately under two lanes runs CONCURRENTLY on the
+ * GPU from ONE host thread and ONE context (one key set, one plaintext cache): the tail of one lane's launch is filled by the
+ * other's.  lanes_fork: lanes 1..n wait for everything the main stream has been given so far (the inputs); lanes_join: the main
+ * stream waits for every lane (before decrypting / exporting under lane 0).  A value must be consumed under the lane that produced it,
+ * or after a join; results are bit-identical to lane 0 (scheduling only). */
+int fhelin_ctx_set_lane(fhelin_ctx* c, int32_t lane);
+int fhelin_ctx_lanes_fork(fhelin_ctx* c);
+int fhelin_ctx_lanes_join(fhelin_ctx* c);
 /* give the device memory the context's caching pool holds but does not use back to the driver (another context / process
  * on the same GPU can then have it); synchronises first */
 int fhelin_ctx_trim(fhelin_ctx* c);

@@ -32,6 +32,16 @@ class SlotEngine:
     def _note(self, name, n):
         self.calls.append((name, n))
 
+    def set_lane(self, k):
+        self.lane_log = getattr(self, "lane_log", [])
+        self.lane_log.append(k)
+
+    def lanes_fork(self):
+        pass
+
+    def lanes_join(self):
+        pass
+
     def encode(self, v, level=0, slots=0):
         return self.sim.encode(v)
 
@@ -146,6 +156,31 @@ def test_batched_driver_gives_every_sample_its_own_single_pass(variant, S_tok, B
     # the row loops saw every sample's rows in ONE call (S tokens -> B * S rows)
     St = S_tok + 1
     assert ("matmul_pt", B * St) in eng.calls and ("matmulCRlarge", B * St) in eng.calls and ("matmul_pt", B * 32) in eng.calls
+
+
+def test_laned_driver_splits_and_merges_the_sub_batches():
+    """LanedBatchedController: every driver call once per sub-batch under its own lane, results merged in sample order"""
+    from fhe_linformer_amd import linformer as lf
+    B, S_tok = 4, 129
+    w = pf.synthetic_model(1234)
+    samples = [pf.client_inputs(w, pf.synthetic_tokens(S_tok, 500 + 3 * x)) for x in range(B)]
+    eng = SlotEngine()
+    ctl = lf.LanedBatchedController(eng, B, 2)
+    encs = []
+    for (x_in, X_E, X_F) in samples:
+        rows = [X_E[i] for i in range(32)] + [X_F[i] for i in range(32)] + [x_in[i] for i in range(x_in.shape[0])]
+        cts = [_H(lf.expanded(r)) for r in rows]
+        encs.append({"inputs_E": cts[:32], "inputs_F": cts[32:64], "inputs": cts[64:]})
+    ctl.begin()
+    out = lf.forward_encrypted(ctl, w, lf.batch_inputs(encs))
+    ctl.end()
+    assert isinstance(out, lf.Batch) and len(out) == B
+    got = [lf.logits_from_slots(v) for v in ctl.decrypt(out)]
+    for x, smp in enumerate(samples):
+        want = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, *smp))
+        assert np.allclose(got[x], want, rtol=0, atol=1e-9), x
+    assert set(eng.lane_log) == {0, 1, 2} and eng.lane_log[0] == 0 and eng.lane_log[-1] == 0
+    assert ("matmul_pt", 2 * (S_tok + 1)) in eng.calls          # a sub-batch of two samples per call
 
 
 def test_batched_level_plan_from_a_single_sample_plan():

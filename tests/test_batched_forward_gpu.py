@@ -4,7 +4,8 @@
 never meet) with every value B ciphertexts wide: the row loops of all samples concatenated into the batched entry points, the
 single-ciphertext chains B rows wide, the bootstraps in batches of 2B / 5B / B.  Rows of a batched key switch are independent, so
 sample x must end in EXACTLY the residues its own single pass gives:
-  * B = 3 batched == three single passes on the same input ciphertexts (the server-side fresh encryptions - the encrypted zero,
+  * B = 4 batched - in one launch set (BatchedController) and as two sub-batches on two lanes of the context that run concurrently
+    (LanedBatchedController) - == four single passes on the same input ciphertexts (the server-side fresh encryptions - the encrypted zero,
     src/main.cpp:220, and the encrypted mask, :472 - replayed), final ciphertext and six traced intermediates, N=2^15;
   * B = 2 batched, one of the two samples against the CPU residue oracle (oracle/residue_controller.py) - the check of
     tests/test_forward_residue_gpu.py made on a sample that travelled in a batch."""
@@ -36,7 +37,7 @@ def _same(a, b, what):
 def test_batched_pass_gives_the_residues_of_the_single_passes(fa, variant, S):
     from fhe_linformer_amd import linformer as lf
     from oracle import plain_forward as pf, circuit_sim as cs
-    B = 3
+    B = 4
     w = pf.synthetic_model(1234)
     samples = [pf.client_inputs(w, pf.synthetic_tokens(S, 4321 + 13 * x)) for x in range(B)]
     eng = _engine(fa, "reference")
@@ -90,6 +91,28 @@ def test_batched_pass_gives_the_residues_of_the_single_passes(fa, variant, S):
         # (level adjustments of B additions made in one call share their rescales' bookkeeping: the counter may differ by a few)
         assert abs(st_batch["rescale"] - st_single["rescale"]) <= 0.01 * st_single["rescale"]
         assert st_batch["limb_ntt"] <= st_single["limb_ntt"]      # (the single passes also encoded + encrypted their zero and mask)
+        # the same batch as two sub-batches on two lanes (streams) of the one context: scheduling only, the same residues
+        class ReplayingLanes(lf.LanedBatchedController):
+            def __init__(self, e, B):
+                super().__init__(e, B, 2)
+                self.k = 0
+
+            def encrypt(self, v, level=0):
+                b = lf.Batch(fresh[x][self.k] for x in range(self.B))
+                self.k += 1
+                return b
+
+        lctl, ltr = ReplayingLanes(eng, B), {}
+        lctl.begin()
+        lout = lf.forward_encrypted(lctl, w, lf.batch_inputs(encs), ltr, variant)
+        lctl.end()
+        eng.sync()
+        st_lane = eng.stats(reset=True)
+        for x in range(B):
+            for k in TRACED:
+                _same(ltr[k][x], traces[x][k], (variant, "lanes", x, k))
+            _same(lout[x], outs[x], (variant, "lanes", x, "out"))
+        assert st_lane["keyswitch"] == st_single["keyswitch"] and st_lane["bootstrap"] == st_single["bootstrap"]
         # ... and it is the forward pass of every sample
         for x in range(B):
             lg = lf.logits_from_slots(eng.decrypt(bout[x]))
