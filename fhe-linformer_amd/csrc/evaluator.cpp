@@ -1401,22 +1401,22 @@ bool Evaluator::dot_plain_window(const std::vector<CtPtr>& cur, const std::vecto
 std::vector<CtPtr> Evaluator::add_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 1); }
 std::vector<CtPtr> Evaluator::sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b) { return add_sub_batch(a, b, 2); }
 
-std::vector<CtPtr> Evaluator::add_sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b, int op) {
-    if (a.size() != b.size()) throw Error(FHELIN_ERR_ARG, "add_batch: operand count mismatch");
-    std::vector<CtPtr> x(a.size()), y(a.size()), out(a.size());
-    // FLEXIBLEAUTO alignment.  The common case of a row loop - a degree-1 operand with more limbs meets a degree-1 operand with
-    // fewer (the driver's residual additions output[i] + inputs[i], src/main.cpp:237-239) - goes through ONE batched integer
-    // multiply + rescale per (target limbs, target scale) instead of one per pair (adjust_deg1_batch: the residues of adjust());
-    // everything else through match() as before
-    std::vector<char> aligned(a.size(), 0);
+// FLEXIBLEAUTO alignment of many operand pairs at once: x[i], y[i] = what match(a[i], b[i]) gives.  The common case of a row loop or
+// of a round of a polynomial evaluation - a degree-1 operand with more limbs meets a degree-1 operand with fewer - goes through ONE
+// batched integer multiply + rescale per (target limbs, target scale) instead of one per pair (adjust_deg1_batch: the residues of
+// adjust(); the same ciphertext brought to the same target for several pairs is adjusted once); everything else through match().
+void Evaluator::match_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b, std::vector<CtPtr>& x, std::vector<CtPtr>& y) {
+    const size_t n = a.size();
+    x.assign(n, CtPtr());
+    y.assign(n, CtPtr());
+    std::vector<char> aligned(n, 0);
     for (int side = 0; side < 2; ++side) {
         // side 0: b is brought down to a; side 1: a is brought down to b
         std::map<std::pair<int, long long>, std::vector<size_t>> groups;   // (target ell, bits of the target scale) -> pairs
-        for (size_t i = 0; i < a.size(); ++i) {
+        for (size_t i = 0; i < n; ++i) {
             if (aligned[i]) continue;
             const CtPtr& lo = side == 0 ? a[i] : b[i];
             const CtPtr& hi = side == 0 ? b[i] : a[i];
-            if (a[i]->npoly != b[i]->npoly) throw Error(FHELIN_ERR_STATE, "add: component count mismatch");
             if (lo->deg == 1 && hi->deg == 1 && lo->ell < hi->ell) {
                 long long bits;
                 const double sd = (double)lo->scale;
@@ -1432,21 +1432,36 @@ std::vector<CtPtr> Evaluator::add_sub_batch(const std::vector<CtPtr>& a, const s
             for (size_t i : g.second) same = same && (side == 0 ? a[i] : b[i])->scale == sc;
             if (!same) continue;
             std::vector<CtPtr> hi;
-            for (size_t i : g.second) hi.push_back(side == 0 ? b[i] : a[i]);
+            std::map<const Ciphertext*, size_t> slot;                       // distinct ciphertexts to adjust
+            std::vector<size_t> which(g.second.size());
+            for (size_t k = 0; k < g.second.size(); ++k) {
+                const CtPtr& h = side == 0 ? b[g.second[k]] : a[g.second[k]];
+                auto it = slot.find(h.get());
+                if (it == slot.end()) {
+                    it = slot.emplace(h.get(), hi.size()).first;
+                    hi.push_back(h);
+                }
+                which[k] = it->second;
+            }
             std::vector<CtPtr> adj = adjust_deg1_batch(hi, g.first.first, sc);
             for (size_t k = 0; k < g.second.size(); ++k) {
                 const size_t i = g.second[k];
-                x[i] = side == 0 ? a[i] : adj[k];
-                y[i] = side == 0 ? adj[k] : b[i];
+                x[i] = side == 0 ? a[i] : adj[which[k]];
+                y[i] = side == 0 ? adj[which[k]] : b[i];
                 aligned[i] = 1;
             }
         }
     }
-    for (size_t i = 0; i < a.size(); ++i) {
-        if (aligned[i]) continue;
+    for (size_t i = 0; i < n; ++i)
+        if (!aligned[i]) match(a[i], b[i], x[i], y[i]);
+}
+
+std::vector<CtPtr> Evaluator::add_sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b, int op) {
+    if (a.size() != b.size()) throw Error(FHELIN_ERR_ARG, "add_batch: operand count mismatch");
+    std::vector<CtPtr> x, y, out(a.size());
+    for (size_t i = 0; i < a.size(); ++i)
         if (a[i]->npoly != b[i]->npoly) throw Error(FHELIN_ERR_STATE, "add: component count mismatch");
-        match(a[i], b[i], x[i], y[i]);
-    }
+    match_batch(a, b, x, y);   // the driver's residual additions output[i] + inputs[i] (src/main.cpp:237-239): one batched adjustment
     for_runs(x.size(), [&](size_t p, size_t q) { return x[p]->npoly == x[q]->npoly && x[p]->ell == x[q]->ell; },
              [&](size_t lo, size_t hi) {
                  const CtPtr& f = x[lo];
@@ -1485,8 +1500,12 @@ std::vector<CtPtr> Evaluator::mult_batch(const std::vector<CtPtr>& a, const std:
         }
     std::vector<CtPtr> resc = in.empty() ? std::vector<CtPtr>() : rescale_batch(in);
     auto ready = [&](const CtPtr& c) { return c->deg >= 2 ? resc[slot[c.get()]] : c; };
-    std::vector<CtPtr> x(n), y(n), out(n);
-    for (size_t i = 0; i < n; ++i) match(ready(a[i]), ready(b[i]), x[i], y[i]);
+    std::vector<CtPtr> x, y, out(n), ra(n), rb(n);
+    for (size_t i = 0; i < n; ++i) {
+        ra[i] = ready(a[i]);
+        rb[i] = ready(b[i]);
+    }
+    match_batch(ra, rb, x, y);   // the level adjustments of all pairs of a round together (one batched rescale per target level)
     std::vector<char> done(n, 0);
     for (size_t first = 0; first < n; ++first) {
         if (done[first]) continue;

@@ -270,6 +270,7 @@ private:
     CtRow cheb_recurse(const std::vector<double>& c, const std::vector<CtRow>& T, const std::map<int, CtRow>& G, int baby);
     std::vector<CtPtr> add_sub_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b, int op);
     void match(const CtPtr& a, const CtPtr& b, CtPtr& ao, CtPtr& bo);
+    void match_batch(const std::vector<CtPtr>& a, const std::vector<CtPtr>& b, std::vector<CtPtr>& x, std::vector<CtPtr>& y);
 };
 
 }  // namespace fhelin

@@ -167,6 +167,44 @@ static void align_deg1(Evaluator& ev, std::vector<CtPtr>& v, int from) {
     std::vector<CtPtr> r = ev.adjust_deg1_batch(std::vector<CtPtr>(v.begin() + from, v.end()), ell, sf);
     for (size_t i = from; i < v.size(); ++i) v[i] = r[i - from];
 }
+// the same for several such sets (one per input of a batched evaluation): each set to ITS OWN common level - and the sets that end
+// at one level (all of them, for the inputs of one driver call) through one batched rescale and one batched adjustment.  A set's
+// members hold the residues align_deg1 gives for that set alone.
+static void align_deg1_cols(Evaluator& ev, std::vector<std::vector<CtPtr>>& cols, int from) {
+    if (cols.size() == 1) {
+        align_deg1(ev, cols[0], from);
+        return;
+    }
+    {
+        std::vector<CtPtr> need;
+        std::vector<std::pair<size_t, size_t>> pos;
+        for (size_t c = 0; c < cols.size(); ++c)
+            for (size_t i = from; i < cols[c].size(); ++i)
+                if (cols[c][i]->deg >= 2) {
+                    need.push_back(cols[c][i]);
+                    pos.push_back({c, i});
+                }
+        if (!need.empty()) {
+            const std::vector<CtPtr> r = ev.rescale_batch(need);
+            for (size_t k = 0; k < pos.size(); ++k) cols[pos[k].first][pos[k].second] = r[k];
+        }
+    }
+    std::map<int, std::vector<size_t>> by_ell;
+    for (size_t c = 0; c < cols.size(); ++c) {
+        int ell = 1 << 30;
+        for (size_t i = from; i < cols[c].size(); ++i) ell = std::min(ell, cols[c][i]->ell);
+        by_ell[ell].push_back(c);
+    }
+    for (const auto& g : by_ell) {
+        const long double sf = ev.ctx().sf_real[ev.ctx().L + 1 - g.first];
+        std::vector<CtPtr> all;
+        for (size_t c : g.second) all.insert(all.end(), cols[c].begin() + from, cols[c].end());
+        const std::vector<CtPtr> r = ev.adjust_deg1_batch(all, g.first, sf);
+        size_t p = 0;
+        for (size_t c : g.second)
+            for (size_t i = from; i < cols[c].size(); ++i) cols[c][i] = r[p++];
+    }
+}
 
 CtPtr Evaluator::eval_poly(const CtPtr& x, const std::vector<double>& coeffs) { return eval_poly_many(std::vector<CtPtr>{x}, coeffs)[0]; }
 
@@ -179,7 +217,14 @@ std::vector<CtPtr> Evaluator::eval_poly_many(const std::vector<CtPtr>& xs, const
     const size_t X = xs.size();
     if (!X) return {};
     std::vector<CtRow> pw(n + 1, CtRow(X));
-    for (size_t x = 0; x < X; ++x) pw[1][x] = xs[x]->deg >= 2 ? rescale(xs[x]) : xs[x];
+    {
+        std::vector<CtPtr> need;
+        for (size_t x = 0; x < X; ++x)
+            if (xs[x]->deg >= 2) need.push_back(xs[x]);
+        const std::vector<CtPtr> r = need.empty() ? std::vector<CtPtr>() : rescale_batch(need);
+        size_t p = 0;
+        for (size_t x = 0; x < X; ++x) pw[1][x] = xs[x]->deg >= 2 ? r[p++] : xs[x];
+    }
     for (int h = 1; h < n; h *= 2) {
         const int i_hi = std::min(2 * h, n);
         CtRow lhs, rhs;
@@ -195,12 +240,11 @@ std::vector<CtPtr> Evaluator::eval_poly_many(const std::vector<CtPtr>& xs, const
     }
     std::vector<CtPtr> out(X);
     const std::vector<double> cf(coeffs.begin() + 1, coeffs.begin() + n + 1);
-    for (size_t x = 0; x < X; ++x) {
-        std::vector<CtPtr> col(n + 1);
-        for (int i = 1; i <= n; ++i) col[i] = pw[i][x];
-        align_deg1(*this, col, 1);
-        out[x] = lincomb(std::vector<CtPtr>(col.begin() + 1, col.begin() + n + 1), cf, coeffs[0]);
-    }
+    std::vector<std::vector<CtPtr>> cols(X, std::vector<CtPtr>(n + 1));
+    for (size_t x = 0; x < X; ++x)
+        for (int i = 1; i <= n; ++i) cols[x][i] = pw[i][x];
+    align_deg1_cols(*this, cols, 1);
+    for (size_t x = 0; x < X; ++x) out[x] = lincomb(std::vector<CtPtr>(cols[x].begin() + 1, cols[x].begin() + n + 1), cf, coeffs[0]);
     return out;
 }
 
@@ -362,7 +406,17 @@ std::vector<CtPtr> Evaluator::eval_chebyshev_many(const std::vector<CtPtr>& xs, 
             u[i] = mult_real(xs[i], 2.0 / (b - a));
             u[i] = add_real(u[i], -(a + b) / (b - a));
         }
-        if (u[i]->deg >= 2) u[i] = rescale(u[i]);
+    }
+    {
+        std::vector<CtPtr> need;
+        for (size_t i = 0; i < rows; ++i)
+            if (u[i]->deg >= 2) need.push_back(u[i]);
+        if (!need.empty()) {
+            const std::vector<CtPtr> r = rescale_batch(need);   // (a single one goes through rescale() itself)
+            size_t p = 0;
+            for (size_t i = 0; i < rows; ++i)
+                if (u[i]->deg >= 2) u[i] = r[p++];
+        }
     }
     int l = 0;
     while ((1 << (2 * l)) < n + 1) ++l;  // baby = 2^ceil(log2(n+1)/2)
@@ -449,11 +503,13 @@ std::vector<CtPtr> Evaluator::eval_chebyshev_many(const std::vector<CtPtr>& xs, 
     }
     // per input: bring the baby powers to one common (level, degree 1)
     std::vector<CtRow> babies(baby, CtRow(rows));  // index 0 unused
-    for (size_t i = 0; i < rows; ++i) {
-        std::vector<CtPtr> col(baby);
-        for (int k = 1; k < baby; ++k) col[k] = T[k][i];
-        align_deg1(*this, col, 1);
-        for (int k = 1; k < baby; ++k) babies[k][i] = col[k];
+    {
+        std::vector<std::vector<CtPtr>> cols(rows, std::vector<CtPtr>(baby));
+        for (size_t i = 0; i < rows; ++i)
+            for (int k = 1; k < baby; ++k) cols[i][k] = T[k][i];
+        align_deg1_cols(*this, cols, 1);
+        for (size_t i = 0; i < rows; ++i)
+            for (int k = 1; k < baby; ++k) babies[k][i] = cols[i][k];
     }
     return cheb_recurse(c, babies, G, baby);
 }
