@@ -1,10 +1,14 @@
 #include "context.h"
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sys/random.h>
 #include <time.h>
+#include <cxxabi.h>
+#include <dlfcn.h>
+#include <execinfo.h>
 
 namespace fhelin {
 
@@ -309,6 +313,7 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
         if (const char* e = std::getenv("FHELIN_FUSE_GATHER")) fuse_gather = std::atoi(e) != 0;
         if (const char* e = std::getenv("FHELIN_FUSE_LIFT")) fuse_lift = std::atoi(e) != 0;
         if (const char* e = std::getenv("FHELIN_LDS_DIGITS")) lds_digits = std::atoi(e) != 0;
+        if (const char* e = std::getenv("FHELIN_NTT_TRACE")) trace_small_ntt = std::atoi(e);
     }
     hip_check(hipEventCreate(&ev_start), "hipEventCreate");
     stage_words = (size_t)2 << p.log_n;
@@ -482,6 +487,13 @@ void Context::upload_async(u64* dst, const u64* src, size_t words) {
 }
 
 Context::~Context() {
+    if (trace_small_ntt && !small_ntt_sites.empty()) {
+        std::vector<std::pair<std::string, std::pair<u64, u64>>> v(small_ntt_sites.begin(), small_ntt_sites.end());
+        std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second.first > b.second.first; });
+        fprintf(stderr, "[fhelin] transforms of <= %d limb vectors by call stack (launch pairs, limb vectors):\n", trace_small_ntt);
+        for (size_t i = 0; i < v.size() && i < 40; ++i)
+            fprintf(stderr, "  %8llu %9llu  %s\n", (unsigned long long)v[i].second.first, (unsigned long long)v[i].second.second, v[i].first.c_str());
+    }
     if (has_device) {
         (void)hipSetDevice(prm.device);
         (void)hipDeviceSynchronize();
@@ -515,6 +527,28 @@ void Context::sync() {
             lane_hold[k].clear();
         }
     }
+}
+
+void Context::note_small_ntt(int nvec) {
+    void* fr[12];
+    const int n = backtrace(fr, 12);
+    std::string key;
+    for (int i = 2; i < n && i < 9; ++i) {
+        Dl_info info;
+        std::string name = "?";
+        if (dladdr(fr[i], &info) && info.dli_sname) {
+            int st = 0;
+            char* d = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &st);
+            name = (st == 0 && d) ? d : info.dli_sname;
+            if (d) std::free(d);
+            const size_t par = name.find('(');
+            if (par != std::string::npos) name.resize(par);
+        }
+        key += (i > 2 ? " < " : "") + name;
+    }
+    auto& e = small_ntt_sites[key];
+    e.first += 1;
+    e.second += (u64)nvec;
 }
 
 void Context::release_holds(int lane, u64 up_to_seq) {

@@ -240,8 +240,14 @@ struct Context {
     // K1 launch + accounting (active = vectors actually transformed, for tables with skipped entries)
     void ntt(const LimbBatch& b, bool inverse, int active = -1) {
         stats.limb_ntt += (u64)(active >= 0 ? active : b.nvec);
+        if (trace_small_ntt && b.nvec <= trace_small_ntt) note_small_ntt(b.nvec);
         launch_ntt(dt, b, inverse, stream);
     }
+    // FHELIN_NTT_TRACE=<n>: transforms of at most n limb vectors (launches that cannot fill the GPU) are counted by call stack and the
+    // table is printed when the context goes away (a development aid: which caller still issues single-ciphertext launches)
+    int trace_small_ntt = 0;
+    std::map<std::string, std::pair<u64, u64>> small_ntt_sites;   // call stack -> (launches, limb vectors)
+    void note_small_ntt(int nvec);
     void ntt_moddown(const LimbBatch& b, const NttModDown& md) {
         stats.limb_ntt += (u64)b.nvec;
         launch_ntt_moddown(dt, b, md, stream);

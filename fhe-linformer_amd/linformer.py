@@ -234,6 +234,11 @@ class BatchedController:
     # leaf ops
     def add(self, a, b):
         if isinstance(b, Batch):
+            # one fhelin_add per handle, as the single pass makes them: the C ABI defers EvalAdd(ct, ct) and runs everything pending as ONE
+            # batched level adjustment + addition when a result is first read - the driver's loop over the S residual additions
+            # (src/main.cpp:237-239) times B samples in one go, instead of S calls of B pairs
+            if self.e.lazy_heavy:
+                return Batch(self.e.add(x, y) for x, y in zip(a, b))
             return Batch(self.e.add_batch(list(a), list(b)))
         return Batch(self.e.add_plain_batch(list(a), b))
 

@@ -54,6 +54,9 @@ class SlotEngine:
     def add_batch(self, a, b):
         return [_H(x.v + y.v) for x, y in zip(a, b)]
 
+    def add(self, a, b):
+        return _H(a.v + b.v)
+
     def add_plain_batch(self, a, p):
         return [_H(x.v + p) for x in a]
 
