@@ -661,7 +661,8 @@ def main():
         Bt = args.throughput_batch
         if Bt > 1 and world == 1 and not row_mode and not batched:
             eng.trim()
-            tctl = lf.BatchedController(eng, Bt)
+            t_lanes = 2 if Bt % 2 == 0 else 1                 # two sub-batches on two lanes (streams) of the one context
+            tctl = lf.LanedBatchedController(eng, Bt, t_lanes) if t_lanes > 1 else lf.BatchedController(eng, Bt)
             xs = [pf.synthetic_tokens(S, 9100 + i) for i in range(Bt)]
             if use_plan:
                 eng.set_level_plan(plan)
@@ -676,7 +677,12 @@ def main():
             def tpass():
                 if use_plan:
                     eng.level_plan_begin("apply", first_source=n_client_sources * Bt)
-                return lf.forward_encrypted(tctl, w, lf.batch_inputs(encs_t), None, args.variant)
+                if t_lanes > 1:
+                    tctl.begin()
+                r = lf.forward_encrypted(tctl, w, lf.batch_inputs(encs_t), None, args.variant)
+                if t_lanes > 1:
+                    tctl.end()
+                return r
             outs_t = tpass()
             lg_t = [lf.logits_from_slots(eng.decrypt(o)) for o in outs_t]
             eng.sync()
@@ -694,12 +700,12 @@ def main():
                 ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, *pf.client_inputs(w, x), None, args.variant))
                 err_t = max(err_t, float(np.max(np.abs(lg - ref))))
             assert err_t < 2e-2, f"batched pass: encrypted logits differ from the circuit oracle ({err_t})"
-            fwd["tb"] = {"samples_per_pass": Bt, "ms_per_sample": round(tb_ms, 2), "passes_timed": n_tp, "logit_err_vs_circuit_oracle": round(err_t, 5),
+            fwd["tb"] = {"samples_per_pass": Bt, "lanes": t_lanes, "ms_per_sample": round(tb_ms, 2), "passes_timed": n_tp, "logit_err_vs_circuit_oracle": round(err_t, 5),
                          "device_pool_in_use_peak_GB": round(st_t["pool_live_peak_bytes"] / 1e9, 1),
                          "device_pool_held_GB": round(st_t["pool_reserved_bytes"] / 1e9, 1),
                          "out_of_memory_trims": st_t["pool_trims"],
                          "note": "ONE engine, one key set, one plaintext cache: every call of the driver carries the rows of all samples of the pass "
-                                 "(linformer.BatchedController); each sample ends in the residues of its own single pass (tests/test_batched_forward_gpu.py); "
+                                 "(linformer.BatchedController), as two sub-batches on two HIP streams of the one context (LanedBatchedController); each sample ends in the residues of its own single pass (tests/test_batched_forward_gpu.py); "
                                  "per-sample latency is the whole pass.  `value` is the one-sample-per-pass figure."}
             if use_plan:
                 eng.set_level_plan(plan)
