@@ -148,6 +148,10 @@ struct KsShape {
     // c0 parts, gathered in place of a separate gather-and-sum pass); rotation r reads gsrc + r * rot_input_stride
     const u64* gsrc = nullptr;
     size_t gsrc_stride = 0;   // per batch row
+    // basis-conversion kernels: targets per block (set by the launchers).  Every chunk of targets re-reads the conversion's source limbs,
+    // so a launch that fills the GPU anyway (many rows) takes ALL targets in one block - sources read once - and only small launches
+    // are cut into chunks of 16 for parallelism
+    int tch = 16;
 };
 // K6: cc [ell][N] coefficient form, c_ntt [ell][N] NTT form -> ext [beta][ell+k][N]
 //     (own-digit slots stay unused — K7 reads c_ntt there; the others get the fast-basis-extended values, coefficient form)

@@ -11,6 +11,7 @@
 // independent of evaluation order.  Limb-major arrays, one thread per coefficient column, per-limb constants
 // through scalar loads; no MFMA (u64 modular integers).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kernels.h"
 #include "kernels_elem.h"
 
@@ -48,7 +49,7 @@ __device__ __forceinline__ void modup_body(const DeviceTables& t, const KsShape&
         }
     }
     u64* dst = ext + (size_t)j * nt * N + n;
-    const int t0 = blockIdx.z * TCH, t1 = min(nt, t0 + TCH);
+    const int t0 = blockIdx.z * sh.tch, t1 = min(nt, t0 + sh.tch);
     for (int tt = t0; tt < t1; ++tt) {
         if (tt >= lo && tt < lo + cnt) continue;  // own-digit slots: the inner product reads c (NTT form) directly
         const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
@@ -346,7 +347,7 @@ __device__ __forceinline__ void moddown_body(const DeviceTables& t, const KsShap
         }
     }
     u64* dst = conv + (size_t)c * sh.ell * N + n;
-    const int t0 = blockIdx.z * TCH, t1 = min(sh.ell, t0 + TCH);
+    const int t0 = blockIdx.z * sh.tch, t1 = min(sh.ell, t0 + sh.tch);
     for (int tt = t0; tt < t1; ++tt) {
         const Barrett br = load_barrett(t, tt);
         u64 slo = 0, shi = 0;
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(256) void moddown_rescale_conv_kernel(DeviceTables 
         }
     }
     u64* dst = conv + ((size_t)bi * 2 + c) * e1 * N + n;
-    const int t0 = blockIdx.z * TCH, t1 = min(e1, t0 + TCH);
+    const int t0 = blockIdx.z * sh.tch, t1 = min(e1, t0 + sh.tch);
     for (int tt = t0; tt < t1; ++tt) {
         const Barrett br = load_barrett(t, tt);
         u64 slo = 0, shi = 0;
@@ -597,9 +598,22 @@ void launch_affine_acc(const DeviceTables& t, const KsShape& sh, u64* accQ, cons
     hipLaunchKernelGGL(affine_acc_kernel, dim3((1u << t.log_n) / 512, (unsigned)(sh.batch * 2 * sh.ell)), dim3(256), 0, s, t, sh, accQ, d, sub, cst,
                        has_cst, f, pmod);
 }
-void launch_moddown_rescale_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* top, const u64* hatinv,
+// targets per block of a conversion launch with `planes` (coefficient tile x row x ...) blocks per chunk: all targets in one block when
+// the launch fills the GPU that way (the sources are then read once), chunks of TCH otherwise.  FHELIN_CONV_CHUNKS=1: always chunks (A/B).
+static int conv_tch(unsigned planes, int targets) {
+    static const int force = [] {
+        const char* e = std::getenv("FHELIN_CONV_CHUNKS");
+        return e ? std::atoi(e) : 0;
+    }();
+    if (force || planes < 2048u) return TCH;
+    return targets > TCH ? targets : TCH;
+}
+void launch_moddown_rescale_conv(const DeviceTables& t, const KsShape& sh_in, u64* conv, const u64* accP, const u64* top, const u64* hatinv,
                                  const u64* hatmod, const u64* mmod, hipStream_t s) {
-    dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * 2), (unsigned)((sh.ell - 1 + TCH - 1) / TCH));
+    KsShape sh = sh_in;
+    const unsigned nx = (1u << t.log_n) / 256;
+    sh.tch = conv_tch(nx * (unsigned)(sh.batch * 2), sh.ell - 1);
+    dim3 g(nx, (unsigned)(sh.batch * 2), (unsigned)((sh.ell - 1 + sh.tch - 1) / sh.tch));
     hipLaunchKernelGGL(moddown_rescale_conv_kernel, g, dim3(256), 0, s, t, sh, conv, accP, top, hatinv, hatmod, mmod);
 }
 void launch_moddown_rescale_finish(const DeviceTables& t, const KsShape& sh, u64* out, const u64* accQ, const u64* conv, const u64* minv,
@@ -608,9 +622,12 @@ void launch_moddown_rescale_finish(const DeviceTables& t, const KsShape& sh, u64
     hipLaunchKernelGGL(moddown_rescale_finish_kernel, g, dim3(256), 0, s, t, sh, out, accQ, conv, minv);
 }
 
-void launch_modup_conv(const DeviceTables& t, const KsShape& sh, u64* ext, const u64* cc, const u64* c_ntt, const u64* hatinv,
+void launch_modup_conv(const DeviceTables& t, const KsShape& sh_in, u64* ext, const u64* cc, const u64* c_ntt, const u64* hatinv,
                        const u64* hatmod, hipStream_t s) {
-    dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * sh.beta), (unsigned)((sh.ell + sh.k + TCH - 1) / TCH));
+    KsShape sh = sh_in;
+    const unsigned nx = (1u << t.log_n) / 256;
+    sh.tch = conv_tch(nx * (unsigned)(sh.batch * sh.beta), sh.ell + sh.k);
+    dim3 g(nx, (unsigned)(sh.batch * sh.beta), (unsigned)((sh.ell + sh.k + sh.tch - 1) / sh.tch));
 #define FHELIN_MODUP_CASE(A) case A: hipLaunchKernelGGL((modup_conv_kernel<A>), g, dim3(256), 0, s, t, sh, ext, cc, c_ntt, hatinv, hatmod); break;
     switch (sh.alpha) {
         FHELIN_MODUP_CASE(1) FHELIN_MODUP_CASE(2) FHELIN_MODUP_CASE(3) FHELIN_MODUP_CASE(4)
@@ -636,9 +653,12 @@ void launch_gather_sum(const DeviceTables& t, const KsShape& sh, u64* out, const
     dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * sh.ell));
     hipLaunchKernelGGL(gather_sum_kernel, g, dim3(256), 0, s, t, sh, out, in, in_stride);
 }
-void launch_moddown_conv(const DeviceTables& t, const KsShape& sh, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
+void launch_moddown_conv(const DeviceTables& t, const KsShape& sh_in, u64* conv, const u64* accP, const u64* phatinv, const u64* phatmod,
                          hipStream_t s) {
-    dim3 g((1u << t.log_n) / 256, (unsigned)(2 * sh.batch), (unsigned)((sh.ell + TCH - 1) / TCH));
+    KsShape sh = sh_in;
+    const unsigned nx = (1u << t.log_n) / 256;
+    sh.tch = conv_tch(nx * (unsigned)(2 * sh.batch), sh.ell);
+    dim3 g(nx, (unsigned)(2 * sh.batch), (unsigned)((sh.ell + sh.tch - 1) / sh.tch));
 #define FHELIN_MODDOWN_CASE(K) case K: hipLaunchKernelGGL((moddown_conv_kernel<K>), g, dim3(256), 0, s, t, sh, conv, accP, phatinv, phatmod); break;
     switch (sh.k) {
         FHELIN_MODDOWN_CASE(1) FHELIN_MODDOWN_CASE(2) FHELIN_MODDOWN_CASE(3) FHELIN_MODDOWN_CASE(4)

@@ -183,3 +183,41 @@ def test_cpp_driver_records_a_level_plan_and_later_runs_apply_it(tmp_path):
     ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, x_in, X_E, X_F, {}, "main"))
     assert np.max(np.abs(lg1 - ref)) < 2e-2 and np.max(np.abs(lg2 - ref)) < 2e-2
     assert int(np.argmax(lg2)) == int(np.argmax(ref))
+
+
+def test_batch_of_samples_through_the_cpp_batch_controller(tmp_path):
+    """include/FHEControllerBatch.h: B samples through ONE FHEController in one pass of the same C++ driver template
+    (tests/shim/shim_forward.cpp batch=2; sample x reads input_b<x> / tokens_b<x>): every sample's traced intermediates and logits
+    against its own clear-text circuit - the C++ twin of tests/test_batched_forward_gpu.py, at the boundary the reference binds."""
+    from fhe_linformer_amd import linformer as lf
+    from oracle import plain_forward as pf, circuit_sim as cs
+    assert os.path.exists(FWD), "tests/shim/shim_forward missing: run __graft_entry__.build()"
+    B, S = 2, 129
+    w = pf.synthetic_model(1234)
+    samples = [pf.client_inputs(w, pf.synthetic_tokens(S, 4321 + 17 * x)) for x in range(B)]
+    root = str(tmp_path)
+    _write_model(root, w, *samples[0])                       # weights + the plain single-sample layout (unused by the batch run)
+    for x, (x_in, X_E, X_F) in enumerate(samples):
+        os.makedirs(os.path.join(root, f"input_b{x}"), exist_ok=True)
+        os.makedirs(os.path.join(root, f"tokens_b{x}"), exist_ok=True)
+        for i in range(32):
+            _write(os.path.join(root, f"input_b{x}", f"XE_{i}.txt"), X_E[i])
+            _write(os.path.join(root, f"input_b{x}", f"XF_{i}.txt"), X_F[i])
+        for i in range(1, x_in.shape[0]):
+            _write(os.path.join(root, f"tokens_b{x}", f"input_{i - 1}.txt"), x_in[i])
+    out = _run([FWD, root, "main", "generate", f"batch={B}"], os.path.join(root, "build"))
+    assert f"forward pass of {B} samples" in out
+    tol = {"scores": 5e-8, "exp": 5e-8, "self_attention": 5e-8, "affine1_0": 5e-8, "encoder_out": 1e-4, "pooled": 5e-3}
+    logits = []
+    for x, smp in enumerate(samples):
+        st = {}
+        ref = lf.forward(cs.SlotSimController(), w, *smp, st, "main")
+        for k, t in tol.items():
+            err = np.max(np.abs(_read(os.path.join(root, "out", f"b{x}", k + ".out")) - st[k]))
+            assert err < t, (x, k, err)
+        lg, lr = lf.logits_from_slots(_read(os.path.join(root, "out", f"b{x}", "logits.out"))), lf.logits_from_slots(ref)
+        assert np.max(np.abs(lg - lr)) < 2e-2 and int(np.argmax(lg)) == int(np.argmax(lr)), x
+        logits.append(lg)
+    assert np.max(np.abs(logits[0] - logits[1])) > 1e-6      # two different samples
+    meta = open(os.path.join(root, "out", "meta.out")).read().strip().split(",")
+    assert int(meta[0]) == 8                                 # the driver's 8 bootstrap CALLS, each B ciphertexts wide
