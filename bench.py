@@ -74,6 +74,8 @@ def parse():
                     "only) or src/main_2.cpp (attention for every token; BASELINE config 5 names it with --log-n 17 --n-q 30)")
     ap.add_argument("--n-q", type=int, default=28)
     ap.add_argument("--n-p", type=int, default=0, help="special limbs (0: OpenFHE's rule ceil(widest digit bits / 60) = 7 for 28 limbs)")
+    ap.add_argument("--special-bits", type=int, default=60, help="size of the special primes of hybrid key switching (60 = OpenFHE's, the reference's; "
+                    "an experiment knob: primes below 2^53 take the fully lazy NTT path in both directions)")
     ap.add_argument("--ntt-batch", type=int, default=8, help="ciphertexts per NTT step per GPU")
     ap.add_argument("--ntt-steps", type=int, default=30)
     ap.add_argument("--micro", action="store_true", help="instruction-rate probes instead of the benchmark")
@@ -420,7 +422,7 @@ def main():
     if args.workload == "ops":
         n_p = 6
     # replicated keys: the SAME deterministic key seed on every rank (a deployment ships one client's key set to all GPUs)
-    eng = fa.Engine("bench", device=local_rank, seed=args.key_seed, log_n=args.log_n, n_q=n_q, n_p=n_p)
+    eng = fa.Engine("bench", device=local_rank, seed=args.key_seed, log_n=args.log_n, n_q=n_q, n_p=n_p, special_bits=args.special_bits)
     cores = host_cpus()
     orc.set_threads(cores)
     line = {}
@@ -640,7 +642,7 @@ def main():
             if rank == 0:
                 print(json.dumps({"metric": "encrypted Linformer-d128 forward ms/sample (profiling run)",
                                   "value": round(elapsed * 1e3 / (n_timed * world), 2), "unit": "ms/sample", "n_gpus": world,
-                                  "steps": args.steps, "warmup": args.warmup, "log_n": args.log_n, "n_q": eng.n_q, "n_p": eng.n_p, "variant": args.variant,
+                                  "steps": args.steps, "warmup": args.warmup, "log_n": args.log_n, "n_q": eng.n_q, "n_p": eng.n_p, "special_bits": args.special_bits, "variant": args.variant,
                                   "host_issue_ms_per_sample": round(host_enqueue * 1e3 / n_timed, 2), "ops_per_sample": stats, "device_pool": pool_now,
                                   "samples_per_pass": width, "passes_per_step": n_pass if batched else per_rank, "lanes": args.lanes if (batched and laned) else 1, "distinct_input_sets": n_sets,
                                   "logit_err_vs_circuit_oracle": round(err, 5), "level_plan": bool(plan)}))
