@@ -27,6 +27,8 @@
 // Measured (profiles/): 1.95 M limb-NTT/s at N=2^16, bound by VALU issue slots (88 % busy; 15 VALU
 // instructions per lazy butterfly, 9 of them 32x32 multiplies), 2.07x algorithmic HBM traffic (two passes + twiddles).
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdlib>
 #include "kernels.h"
 
 namespace fhelin {
@@ -54,6 +56,7 @@ struct NttArgs {
     size_t src_group2_stride;
     const u64* lift_qlm;      // rescale: first-pass input = centred lift of src[vec / limb_count] (LimbBatch::lift_qlm)
     int lift_limb;
+    int vec0;                 // first vector of this launch: a large transform runs as chunks of vectors, both passes per chunk (launch_ntt_impl)
 };
 
 __device__ __forceinline__ size_t src_offset(const NttArgs& a, int vec, int log_n) {
@@ -323,7 +326,7 @@ template <int A, bool INVERSE, bool LIFT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ntt_cols_kernel(NttArgs a) {
     constexpr int LOGTILES = A - 4;
     __shared__ u64 lds[LDS_WORDS];
-    const int vec = blockIdx.x >> LOGTILES;
+    const int vec = a.vec0 + (blockIdx.x >> LOGTILES);
     const int tile = blockIdx.x & ((1 << LOGTILES) - 1);
     const int limb = limb_of(a, vec);
     if (limb < 0) return;
@@ -439,9 +442,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void n
         const int nper = a.nvec / a.period;
         const int rep = lid % nper, r = lid / nper;
         tile = r & ((1 << logtiles) - 1);
-        vec = rep * a.period + (r >> logtiles);
+        vec = a.vec0 + rep * a.period + (r >> logtiles);
     } else {
-        vec = lid >> logtiles;
+        vec = a.vec0 + (lid >> logtiles);
         tile = lid & ((1 << logtiles) - 1);
     }
     const int limb = limb_of(a, vec);
@@ -497,34 +500,65 @@ static void launch_ntt_impl(const DeviceTables& t, const LimbBatch& b, bool inve
     const int per = b.limb_tab ? b.tab_len : a.limb_count;
     a.period = (per > 0 && per < b.nvec && b.nvec % per == 0) ? per : 0;
     const int A = t.log_n - 8;
-    const int blocks = b.nvec << (t.log_n - 12);
-    auto cols = [&]() {
-        switch (A) {
-            case 4: launch_cols<4>(a, inverse, blocks, s); break;
-            case 5: launch_cols<5>(a, inverse, blocks, s); break;
-            case 6: launch_cols<6>(a, inverse, blocks, s); break;
-            case 7: launch_cols<7>(a, inverse, blocks, s); break;
-            case 8: launch_cols<8>(a, inverse, blocks, s); break;
-            case 9: launch_cols<9>(a, inverse, blocks, s); break;
-            default: break;
+    a.vec0 = 0;
+    // FHELIN_NTT_CHUNK_MB=<m> (experiment, default off): a large transform as CHUNKS of about m MiB of vectors, both tile passes per chunk,
+    // so that the intermediate a chunk's first pass writes is still in the 256 MiB Infinity Cache when its second pass reads it.
+    // Measured in round 4 (profiles/r04_q_*): SLOWER - 274 -> 284 / 293 / 316 ms per pass at 96 / 64 / 32 MiB, micro-benchmark 1.97 -> 1.69 M
+    // limb-NTT/s: the extra launch boundaries (every launch drains before the next starts) cost more than HBM round trips of the
+    // intermediate do, i.e. the tile passes are not waiting on HBM.  Chunks are multiples of the twiddle period (vectors v and
+    // v + period share a limb) so that the block order of the row pass keeps working inside a chunk.
+    static const int chunk_mb = [] {
+        const char* e = std::getenv("FHELIN_NTT_CHUNK_MB");
+        return e ? std::atoi(e) : 0;
+    }();
+    int chunk = b.nvec;
+    if (chunk_mb > 0 && !md) {
+        const size_t vec_bytes = (size_t)8 << t.log_n;
+        const int want = (int)std::max<size_t>(1, ((size_t)chunk_mb << 20) / vec_bytes);
+        if (b.nvec > want + want / 2) {
+            const int per = a.period > 0 ? a.period : 1;
+            chunk = std::max(per, want / per * per);
         }
-    };
-    // the first pass may read out of place; the second always works in place on `data`
-    if (!inverse) {
-        cols();
-        a.src = a.data;
-        a.src_group = 0;
-        a.src_group2 = 0;
-        if (md)
-            hipLaunchKernelGGL((ntt_rows_kernel<false, true>), dim3(blocks), dim3(256), 0, s, a, *md);
-        else
-            hipLaunchKernelGGL((ntt_rows_kernel<false, false>), dim3(blocks), dim3(256), 0, s, a, NttModDown());
-    } else {
-        hipLaunchKernelGGL((ntt_rows_kernel<true, false>), dim3(blocks), dim3(256), 0, s, a, NttModDown());
-        a.src = a.data;
-        a.src_group = 0;
-        a.src_group2 = 0;
-        cols();
+    }
+    const int nvec_all = b.nvec, period_all = a.period;
+    const u64* src_all = a.src;
+    const int sg = a.src_group, sg2 = a.src_group2;
+    for (int v0 = 0; v0 < nvec_all; v0 += chunk) {
+        a.vec0 = v0;
+        a.nvec = std::min(chunk, nvec_all - v0);
+        a.period = (period_all > 0 && a.nvec % period_all == 0 && a.nvec > period_all) ? period_all : 0;
+        a.src = src_all;
+        a.src_group = sg;
+        a.src_group2 = sg2;
+        const int blocks = a.nvec << (t.log_n - 12);
+        auto cols = [&]() {
+            switch (A) {
+                case 4: launch_cols<4>(a, inverse, blocks, s); break;
+                case 5: launch_cols<5>(a, inverse, blocks, s); break;
+                case 6: launch_cols<6>(a, inverse, blocks, s); break;
+                case 7: launch_cols<7>(a, inverse, blocks, s); break;
+                case 8: launch_cols<8>(a, inverse, blocks, s); break;
+                case 9: launch_cols<9>(a, inverse, blocks, s); break;
+                default: break;
+            }
+        };
+        // the first pass may read out of place; the second always works in place on `data`
+        if (!inverse) {
+            cols();
+            a.src = a.data;
+            a.src_group = 0;
+            a.src_group2 = 0;
+            if (md)
+                hipLaunchKernelGGL((ntt_rows_kernel<false, true>), dim3(blocks), dim3(256), 0, s, a, *md);
+            else
+                hipLaunchKernelGGL((ntt_rows_kernel<false, false>), dim3(blocks), dim3(256), 0, s, a, NttModDown());
+        } else {
+            hipLaunchKernelGGL((ntt_rows_kernel<true, false>), dim3(blocks), dim3(256), 0, s, a, NttModDown());
+            a.src = a.data;
+            a.src_group = 0;
+            a.src_group2 = 0;
+            cols();
+        }
     }
 }
 
