@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+# logits: measured 2.5e-3 (round 1) ... 8.6e-3 (round 3, maximum over the bench's 20 samples); 1.2e-2 so that a further doubling fails
+LOGIT_TOL = 1.2e-2
 
 
 @pytest.mark.parametrize("variant,preset,n_q,S", [
@@ -43,11 +45,15 @@ def test_encrypted_forward_matches_plaintext_circuit(fa, variant, preset, n_q, S
         # above the widest digit) hybrid key switching leaves ~2^-37 relative noise per rotation, ~2e-8 after the thousands
         # of rotations up to `self_attention`; after bootstrapping its 2.5e-5 precision dominates
         tol = {"scores": 5e-8, "exp": 5e-8, "self_attention": 5e-8, "affine1_0": 5e-8, "encoder_out": 1e-4, "pooled": 5e-3}
+        errs = {}
         for k, t in tol.items():
-            err = np.max(np.abs(eng.decrypt(tr[k]) - st[k]))
+            errs[k] = err = np.max(np.abs(eng.decrypt(tr[k]) - st[k]))
             assert err < t, (k, err)
         lg, lr = lf.logits_from_slots(eng.decrypt(out)), lf.logits_from_slots(ref)
-        assert np.max(np.abs(lg - lr)) < 2e-2
+        errs["logits"] = np.max(np.abs(lg - lr))
+        # measured values next to their tolerances (pytest -s; a recorded run: profiles/r04_s_forward_test_errors.txt)
+        print(f"{variant} {preset} S={S}: " + ", ".join(f"{k} {v:.2e} (< {tol.get(k, LOGIT_TOL):.0e})" for k, v in errs.items()))
+        assert errs["logits"] < LOGIT_TOL
         assert int(np.argmax(lg)) == int(np.argmax(lr))
         assert out.info()["ell"] >= 2
     finally:
@@ -93,7 +99,7 @@ def test_forward_under_a_recorded_level_plan(fa, variant, preset):
         lg2, ref2, ntt_plan, _ = one("apply", 4323)
         assert ntt_plan < 0.97 * ntt_plain, (ntt_plan, ntt_plain)   # main: -23 %, main_2 (every token attends): about -10 %
         for lg, ref in ((lg0, ref0), (lg1, ref1), (lg2, ref2)):
-            assert np.max(np.abs(lg - ref)) < 2e-2
+            assert np.max(np.abs(lg - ref)) < LOGIT_TOL
             top2 = np.sort(ref)[-2:]
             if top2[1] - top2[0] > 4e-2:
                 assert int(np.argmax(lg)) == int(np.argmax(ref))
