@@ -16,6 +16,7 @@ Composite::Composite(Evaluator& ev, Client& cl) : ev_(ev), cl_(cl) {
     merge_rot_ = env_flag("FHELIN_MERGE_ROT");
     if (const char* e = std::getenv("FHELIN_ROW_LANES")) row_lanes_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_CHEB_ROUNDS")) ev_.cheb_rounds = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FHELIN_CHEB_LEAF_CLASSES")) ev_.cheb_leaf_classes = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_DOT_GROUPS")) ev_.dot_groups = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_DOUBLE_HOIST")) ev_.double_hoist = std::atoi(e) != 0;
     if (const char* e = std::getenv("FHELIN_FUSE_RELARGE")) fuse_relarge = std::atoi(e) != 0;

@@ -92,6 +92,7 @@ public:
     u64 gather_copies[8] = {};   // ciphertext copies made by make_contiguous, per call site (diagnostics)
     bool dot_groups = true;    // inner sums of all giant steps of a linear stage in one pass (dot_plain_groups); FHELIN_DOT_GROUPS=0: one pass each
     bool cheb_leaf_at_product = true;   // r-leaves of the Paterson-Stockmeyer tree born at their product's (limbs, scale); FHELIN_CHEB_LEAF_AT=0: level-adjusted afterwards
+    bool cheb_leaf_classes = true;   // a Chebyshev leaf's babies aligned to the deepest power IT uses (one level saved: OpenFHE's depth); FHELIN_CHEB_LEAF_CLASSES=0: all babies at one level
     bool cheb_rounds = true;   // Paterson-Stockmeyer products in rounds (polyeval.cpp cheb_recurse); FHELIN_CHEB_ROUNDS=0: one at a time
     int batch_limit = 32;   // rows processed per batched key switch (FHELIN_BATCH overrides; 16 / 24 / 32 / 48 / 64 re-measured at the end of round 2: DESIGN.md)
     CtPtr clone(const CtPtr& a);

@@ -295,11 +295,36 @@ int cheb_build(std::vector<ChebNode>& nodes, const std::vector<double>& c_in, in
 }
 }  // namespace
 
-Evaluator::CtRow Evaluator::cheb_recurse(const std::vector<double>& c, const std::vector<CtRow>& T, const std::map<int, CtRow>& G,
+Evaluator::CtRow Evaluator::cheb_recurse(const std::vector<double>& c, const std::vector<CtRow>& Traw, const std::map<int, CtRow>& G,
                                          int baby) {
-    const size_t rows = T[1].size();
+    const size_t rows = Traw[1].size();
     std::vector<ChebNode> nodes;
     const int root = cheb_build(nodes, c, baby);
+    // A leaf sum_{k<=d} c_k T_k only needs the babies T_1..T_d at ONE level - that of the deepest power among them, depth ceil(log2 d) -
+    // not at the level of T_(baby-1): the leaves at the bottom of the quotient chain p = q T_m + r (degree < baby / 2) then sit one level
+    // higher, and the whole evaluation takes ceil(log2(degree)) levels for the powers + 1 for the constants - OpenFHE's Paterson-Stockmeyer
+    // depth (7 for degree 119, 9 for 300; all babies at one level costs one more).  The babies are aligned per CLASS j (degrees in
+    // (2^(j-1), 2^j] use T_1..T_min(2^j, baby-1) brought to their common level), lazily, all inputs of the batch together.
+    std::map<int, std::vector<CtRow>> aligned;   // class -> [k][input], k = 1..prefix
+    auto class_of = [](int d) {
+        int j = 0;
+        while ((1 << j) < d) ++j;
+        return j;
+    };
+    auto babies_for = [&](int d) -> const std::vector<CtRow>& {
+        const int j = cheb_leaf_classes ? class_of(std::max(d, 1)) : 30;
+        const int prefix = std::min(j >= 30 ? baby - 1 : (1 << j), baby - 1);
+        auto it = aligned.find(prefix);
+        if (it != aligned.end()) return it->second;
+        std::vector<std::vector<CtPtr>> cols(rows, std::vector<CtPtr>(prefix + 1));
+        for (size_t i = 0; i < rows; ++i)
+            for (int k = 1; k <= prefix; ++k) cols[i][k] = Traw[k][i];
+        align_deg1_cols(*this, cols, 1);
+        std::vector<CtRow> out(prefix + 1, CtRow(rows));
+        for (size_t i = 0; i < rows; ++i)
+            for (int k = 1; k <= prefix; ++k) out[k][i] = cols[i][k];
+        return aligned.emplace(prefix, std::move(out)).first->second;
+    };
     // a leaf that is the r of p = q T_m + r is only ever ADDED to the product q T_m: it is evaluated when that product is known,
     // with its coefficients scaled so that it is born with the product's limbs and scale (no level adjustment = no rescale)
     std::vector<char> is_r_leaf(nodes.size(), 0);
@@ -310,6 +335,7 @@ Evaluator::CtRow Evaluator::cheb_recurse(const std::vector<double>& c, const std
             is_r_leaf[nd.r] = any && cheb_leaf_at_product ? 1 : 0;
         }
     auto leaf_terms = [&](const ChebNode& nd, size_t i) {
+        const std::vector<CtRow>& T = babies_for((int)nd.c.size() - 1);
         std::vector<CtPtr> terms;
         for (size_t k = 1; k < nd.c.size(); ++k) terms.push_back(T[k][i]);
         return terms;
@@ -322,6 +348,7 @@ Evaluator::CtRow Evaluator::cheb_recurse(const std::vector<double>& c, const std
         bool any = false;
         for (int k = 1; k <= n; ++k) any = any || nd.c[k] != 0.0;
         nd.val.resize(rows);
+        const std::vector<CtRow>& T = babies_for(any ? n : baby - 1);   // a constant leaf hangs on T_1 at the level of all babies
         for (size_t i = 0; i < rows; ++i) {
             if (!any) {  // constant polynomial: c0 as an encryption-free shift of 0 * T_1
                 nd.val[i] = mult_real(T[1][i], 0.0);
@@ -501,16 +528,8 @@ std::vector<CtPtr> Evaluator::eval_chebyshev_many(const std::vector<CtPtr>& xs, 
         for (size_t i = 0; i < rows; ++i) t[i] = add_real(t[i], -1.0);
         G[2 * m] = rescale_batch(t);
     }
-    // per input: bring the baby powers to one common (level, degree 1)
-    std::vector<CtRow> babies(baby, CtRow(rows));  // index 0 unused
-    {
-        std::vector<std::vector<CtPtr>> cols(rows, std::vector<CtPtr>(baby));
-        for (size_t i = 0; i < rows; ++i)
-            for (int k = 1; k < baby; ++k) cols[i][k] = T[k][i];
-        align_deg1_cols(*this, cols, 1);
-        for (size_t i = 0; i < rows; ++i)
-            for (int k = 1; k < baby; ++k) babies[k][i] = cols[i][k];
-    }
+    // the baby powers as they are: cheb_recurse brings the ones a leaf needs to that leaf's level
+    std::vector<CtRow> babies(T.begin(), T.begin() + baby);   // index 0 unused
     return cheb_recurse(c, babies, G, baby);
 }
 

@@ -224,6 +224,7 @@ class ResidueEvaluator:
         d = orc.mult_relin(x.d, y.d, self.keys["relin"], self.alpha, self.q, self.p, self.psi_q, self.psi_p)
         return RCt(d, x.deg + y.deg, x.scale * y.scale)
 
+    cheb_leaf_classes = True    # Evaluator::cheb_leaf_classes (FHELIN_CHEB_LEAF_CLASSES=0 restores all babies at one level)
     merged_products = False     # Evaluator::merged_products (FHELIN_MERGED_PRODUCTS=1, off by default): the power steps of a Chebyshev
                                 # evaluation / EvalMod's double angle through mult_affine_rescale
 
@@ -389,7 +390,18 @@ class ResidueEvaluator:
             t = self.add_real(self.add(t, t), -1.0)
             G[2 * m] = self.rescale(t)
             m *= 2
-        B = [None] + self.align_deg1(T[1:baby])
+        # a leaf's babies are aligned to the deepest power THE LEAF uses (polyeval.cpp cheb_recurse babies_for): degrees in
+        # (2^(j-1), 2^j] take T_1..T_min(2^j, baby-1) at their common level - one level saved against all babies at one level
+        aligned = {}
+
+        def babies_for(d):
+            j = 0
+            while (1 << j) < max(d, 1):
+                j += 1
+            prefix = min(1 << j, baby - 1) if self.cheb_leaf_classes else baby - 1
+            if prefix not in aligned:
+                aligned[prefix] = [None] + self.align_deg1(T[1:prefix + 1])
+            return aligned[prefix]
 
         def strip(p):
             k = len(p) - 1
@@ -400,9 +412,9 @@ class ResidueEvaluator:
         def leaf(p, at=None):
             """sum_{k>=1} p_k T_k + p_0 over the aligned babies; at = the product it will be added to"""
             if not any(v != 0.0 for v in p[1:]):
-                z = self.mult_real(B[1], 0.0)
+                z = self.mult_real(babies_for(baby - 1)[1], 0.0)
                 return self.add_real(z, p[0]) if p[0] != 0.0 else z
-            terms, cf = B[1:len(p)], p[1:]
+            terms, cf = babies_for(len(p) - 1)[1:len(p)], p[1:]
             if at is not None and at.deg == 2:
                 v = self.lincomb_at(terms, cf, p[0], at.scale, at.ell)
                 if v is not None:
