@@ -354,7 +354,11 @@ int fhelin_stats(fhelin_ctx* c, uint64_t* out, int32_t cap, int32_t reset) {
             out[13] = p.live_peak;
             out[14] = p.reserved_peak;
             out[15] = p.trims;
-            if (reset) p.live_peak = p.reserved_peak = p.trims = 0;
+            if (reset) {   // the marks restart from the present state
+                p.live_peak = p.bytes_live();
+                p.reserved_peak = p.bytes_reserved();
+                p.trims = 0;
+            }
         }
         if (reset) p.malloc_calls = p.malloc_bytes = p.malloc_ns = 0;
     }
