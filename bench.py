@@ -615,25 +615,37 @@ def main():
         unplanned_ms = float("nan")
         literal_ms = float("nan")
         if not args.forward_only:
-            def timed_passes(fn, n=2):
-                eng.decrypt(fn())                              # untimed: pool / plaintext caches of this variant
-                eng.sync()
+            leg_pool = {}
+
+            def timed_passes(fn, n=2, name=""):
+                for _ in range(3):                             # untimed: plaintext caches of this variant, and the device arena grown to
+                    m0 = eng.stats()["pool_malloc_calls"]      # the variant's working set (a slab from the driver costs ~60 ms)
+                    eng.decrypt(fn())
+                    eng.sync()
+                    if eng.stats()["pool_malloc_calls"] == m0:
+                        break
+                s0 = eng.stats()
                 t1 = time.perf_counter()
                 for _ in range(n):
                     eng.decrypt(fn())
                 eng.sync()
-                return (time.perf_counter() - t1) * 1e3 / n
+                ms = (time.perf_counter() - t1) * 1e3 / n
+                s1 = eng.stats()
+                leg_pool[name] = {"hipMalloc_ms": round((s1["pool_malloc_ns"] - s0["pool_malloc_ns"]) / 1e6, 1),
+                                  "out_of_memory_trims": s1["pool_trims"] - s0["pool_trims"], "held_GB": round(s1["pool_reserved_bytes"] / 1e9, 1),
+                                  "limb_ntt_per_pass": (s1["limb_ntt"] - s0["limb_ntt"]) // n}
+                return ms
             eng.set_lazy_rows(False)
-            eager_ms = timed_passes(lambda: server_pass(samples[-1][1]))
+            eager_ms = timed_passes(lambda: server_pass(samples[-1][1]), name="rows_eager_plan_on")
             eng.set_lazy_rows(True)
             # and the pass at the levels the driver asks for (no plan), on inputs encrypted at level 0 as the driver does
             if use_plan:
                 eng.level_plan_begin("off")
                 enc_full = lf.encrypt_inputs(ctl0, *pf.client_inputs(w, samples[-1][0]))
-                unplanned_ms = timed_passes(lambda: lf.forward_encrypted(ctl, w, enc_full, None, args.variant))
+                unplanned_ms = timed_passes(lambda: lf.forward_encrypted(ctl, w, enc_full, None, args.variant), name="rows_deferred_plan_off")
                 # ... with every row evaluated as well: the reference's literal operation sequence at the reference's own levels
                 eng.set_lazy_rows(False)
-                literal_ms = timed_passes(lambda: lf.forward_encrypted(ctl, w, enc_full, None, args.variant))
+                literal_ms = timed_passes(lambda: lf.forward_encrypted(ctl, w, enc_full, None, args.variant), name="literal")
                 eng.set_lazy_rows(True)
                 del enc_full
             else:
@@ -651,7 +663,7 @@ def main():
                 dist.destroy_process_group()
             return
         fwd = {"elapsed": elapsed, "stats": stats, "logit_err_vs_circuit_oracle": err, "logit_err_mean": err_sum / max(1, len(logits)),
-               "batched": batched, "n_sets": n_sets, "pool": pool_now, "width": width, "lanes": args.lanes if (batched and laned) else 1, "n_pass": n_pass if batched else per_rank, "host_enqueue_ms": host_enqueue * 1e3 / max(1, n_timed), "pred": int(np.argmax(logits[-1])),
+               "batched": batched, "n_sets": n_sets, "pool": pool_now, "leg_pool": leg_pool if not args.forward_only else {}, "width": width, "lanes": args.lanes if (batched and laned) else 1, "n_pass": n_pass if batched else per_rank, "host_enqueue_ms": host_enqueue * 1e3 / max(1, n_timed), "pred": int(np.argmax(logits[-1])),
                "samples_checked": len(logits), "eager_ms": eager_ms, "client_ms": client_ms, "unplanned_ms": unplanned_ms, "literal_ms": literal_ms,
                "client_first_ms": client_first_ms, "client_pool": client_pool,
                "plan": plan, "n_client_sources": n_client_sources}
@@ -793,6 +805,7 @@ def main():
                                                      "tests/test_batched_forward_gpu.py)" if fwd["batched"] else "one sample per pass"),
                            "distinct_input_sets_in_the_timed_region": fwd["n_sets"],
                            "device_pool": fwd["pool"],
+                           "device_pool_in_the_other_cells": fwd["leg_pool"],
                            "host_issue_ms_per_sample": round(fwd["host_enqueue_ms"], 2),
                            "logit_err_vs_circuit_oracle": round(fwd["logit_err_vs_circuit_oracle"], 5),
                            "logit_err_vs_circuit_oracle_mean": round(fwd["logit_err_mean"], 5),
