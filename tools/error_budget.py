@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-knob error budget of the forward pass: max |logit - circuit oracle| over the bench's samples for
-packed EvalMod on/off x level plan on/off, at the headline ring.  Writes one JSON line per configuration.
+packed EvalMod on/off x level plan on/off, and the default configuration with each re-association knob off in turn, at the headline ring.  Writes one JSON line per configuration.
 Usage: python tools/error_budget.py [n_samples] > profiles/rNN_error_budget.jsonl"""
 import json
 import os
@@ -11,8 +11,15 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def run(packed, plan_on, n_samples, S=129):
+KNOBS = ("FHELIN_MERGED_RESCALE", "FHELIN_DOUBLE_HOIST", "FHELIN_CHEB_LEAF_CLASSES", "FHELIN_FUSE_RELARGE", "FHELIN_BULK_UNWRAP")
+
+
+def run(packed, plan_on, n_samples, S=129, off=None):
     os.environ["FHELIN_BOOT_PACKED"] = "1" if packed else "0"
+    for k in KNOBS:                      # every re-association on, except the one under test
+        os.environ.pop(k, None)
+    if off:
+        os.environ[off] = "0"
     import fhe_linformer_amd as fa
     from fhe_linformer_amd import linformer as lf
     from oracle import plain_forward as pf, circuit_sim as cs
@@ -51,7 +58,7 @@ def run(packed, plan_on, n_samples, S=129):
             m = np.random.default_rng(s).uniform(-1, 1, 16384)
             ct = eng.encrypt(m, level=eng.n_q - 3)
             boot_errs.append(float(np.max(np.abs(eng.decrypt(eng.bootstrap(ct)) - m))))
-        return {"packed_evalmod": packed, "level_plan": plan_on, "samples": n_samples, "max_logit_err": max(errs),
+        return {"packed_evalmod": packed, "level_plan": plan_on, "knob_off": off, "samples": n_samples, "max_logit_err": max(errs),
                 "mean_logit_err": float(np.mean(errs)), "per_sample": [round(e, 6) for e in errs],
                 "single_bootstrap_max_err_4_seeds": [float("%.3g" % e) for e in boot_errs]}
     finally:
@@ -63,3 +70,6 @@ if __name__ == "__main__":
     for packed in (True, False):
         for plan_on in (True, False):
             print(json.dumps(run(packed, plan_on, n)), flush=True)
+    # which re-association costs precision: the default configuration with ONE knob off at a time
+    for off in KNOBS:
+        print(json.dumps(run(True, True, n, off=off)), flush=True)
