@@ -241,6 +241,8 @@ int fhelin_ctx_lanes_fork(fhelin_ctx* c) {
     if (c->user_lane != 0) throw Error(FHELIN_ERR_STATE, "lanes_fork: call it under lane 0");
     if (!c->pending_heavy[0].empty()) flush_heavy(c);     // what the lanes are about to read exists
     c->ctx.fork_lanes();
+    c->ctx.pool.n_user_lanes = c->ctx.n_lanes;
+    c->ctx.pool.conservative_foreign_free = true;
     FHELIN_CATCH
 }
 int fhelin_ctx_lanes_join(fhelin_ctx* c) {
@@ -250,6 +252,7 @@ int fhelin_ctx_lanes_join(fhelin_ctx* c) {
     if (c->user_lane != 0) throw Error(FHELIN_ERR_STATE, "lanes_join: call it under lane 0");
     if (c->any_pending()) flush_heavy_all(c);
     c->ctx.join_lanes();
+    c->ctx.pool.conservative_foreign_free = false;
     FHELIN_CATCH
 }
 

@@ -1,4 +1,5 @@
 #include "client.h"
+#include <time.h>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -295,14 +296,29 @@ std::shared_ptr<Encoding> encode_to_device(Context& c, const std::vector<double>
 }
 
 std::shared_ptr<Encoding> Plaintext::at(int ell, long double scale) {
+    // an encoding is made on the stream that first asks for it; a DIFFERENT lane that uses it later orders its stream behind the event
+    // recorded after the encode (no host wait: with two lanes fed by one host thread a host-side synchronisation of one lane starves the
+    // other - 2.9 s of host time per 16 samples before this, tools: FHELIN_HOST_WAITS=1)
+    auto order = [&](const std::shared_ptr<Encoding>& e) {
+        const int lane = ctx->pool.cur_lane;
+        if (e->ready && lane != e->made_lane && !(e->lanes_ordered & (1u << lane))) {
+            hip_check(hipStreamWaitEvent(ctx->stream, e->ready, 0), "hipStreamWaitEvent(encoding)");
+            e->lanes_ordered |= 1u << lane;
+        }
+    };
     for (size_t i = 0; i < cache.size(); ++i)
         if (cache[i]->ell == ell && fabsl(cache[i]->scale / scale - 1.0L) < 1e-12L) {
             if (i) std::rotate(cache.begin(), cache.begin() + i, cache.begin() + i + 1);   // most recently used first
+            order(cache[0]);
             return cache[0];
         }
     auto e = encode_to_device(*ctx, values, imag, slots, ell, scale);
-    // an encoding made on a worker lane is cached and may be read from any other stream next: finish it first
-    if (ctx->stream != ctx->main_stream) hip_check(hipStreamSynchronize(ctx->stream), "encode sync (lane)");
+    e->made_lane = ctx->pool.cur_lane;
+    e->lanes_ordered = 1u << e->made_lane;
+    if (ctx->n_lanes > 0) {
+        hip_check(hipEventCreateWithFlags(&e->ready, hipEventDisableTiming), "hipEventCreate(encoding)");
+        hip_check(hipEventRecord(e->ready, ctx->stream), "hipEventRecord(encoding)");
+    }
     cache.insert(cache.begin(), e);
     // one entry per (limb count, scale) the plaintext has been used at: bounded by the chain length in principle, capped here
     // so that a long-lived mask or bootstrap diagonal cannot pin more than MAX_ENCODINGS device copies (least recently used

@@ -33,7 +33,7 @@ void DevicePool::raw_free(void* p) {
 DevicePool::~DevicePool() {
     for (auto& ln : lane_) {
         for (auto& pk : ln.parked)
-            if (pk.ev) (void)hipEventDestroy(pk.ev);
+            for (int k = 0; k < pk.n_ev; ++k) (void)hipEventDestroy(pk.ev[k]);
         for (auto& sl : ln.slabs)
             if (sl.base) raw_free(sl.base);
     }
@@ -124,9 +124,9 @@ void* DevicePool::alloc(size_t bytes) {
     // free memory of this lane
     if (!ln.parked.empty()) {
         for (auto& pk : ln.parked) {
-            if (pk.ev) {
-                hip_check(hipStreamWaitEvent(lane_stream[cur_lane], pk.ev, 0), "hipStreamWaitEvent(pool reuse)");
-                spare_events_.push_back(pk.ev);
+            for (int k = 0; k < pk.n_ev; ++k) {
+                hip_check(hipStreamWaitEvent(lane_stream[cur_lane], pk.ev[k], 0), "hipStreamWaitEvent(pool reuse)");
+                spare_events_.push_back(pk.ev[k]);
             }
             insert_free(ln, pk.slab, pk.off, pk.len);
         }
@@ -157,7 +157,7 @@ void* DevicePool::alloc(size_t bytes) {
     if (live_bytes_ > live_peak) live_peak = live_bytes_;
     return p;
 }
-void DevicePool::free(void* p) {
+void DevicePool::free(void* p, unsigned used_by_lanes) {
     if (!p) return;
     auto it = live_.find(p);
     if (it == live_.end()) throw Error(FHELIN_ERR_STATE, "DevicePool::free of unknown pointer");
@@ -166,8 +166,21 @@ void DevicePool::free(void* p) {
     live_bytes_ -= lv.bytes;
     Lane& ln = lane_[lv.lane];
     ln.slabs[lv.slab].used -= lv.bytes;
+    // the lanes whose streams may still have work queued that reads the block, other than the owner (whose own stream order covers it)
+    unsigned wait = used_by_lanes;
     if (have_streams && lv.lane != cur_lane) {
-        // freed under another lane than the one that owns it: whatever that lane's stream has queued so far may still read it
+        wait |= 1u << cur_lane;
+        if (conservative_foreign_free)
+            for (int k = 0; k <= n_user_lanes; ++k) wait |= 1u << k;
+    }
+    wait &= ~(1u << lv.lane);
+    if (!have_streams || !wait) {
+        insert_free(ln, lv.slab, lv.off, lv.bytes);
+        return;
+    }
+    Parked pk{lv.slab, lv.off, lv.bytes, {}, 0};
+    for (int k = 0; k < MAX_LANES; ++k) {
+        if (!(wait & (1u << k)) || !lane_stream[k]) continue;
         hipEvent_t ev = nullptr;
         if (!spare_events_.empty()) {
             ev = spare_events_.back();
@@ -175,19 +188,18 @@ void DevicePool::free(void* p) {
         } else {
             hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate(pool)");
         }
-        hip_check(hipEventRecord(ev, lane_stream[cur_lane]), "hipEventRecord(pool free)");
-        foreign_frees += 1;
-        ln.parked.push_back(Parked{lv.slab, lv.off, lv.bytes, ev});
-        return;
+        hip_check(hipEventRecord(ev, lane_stream[k]), "hipEventRecord(pool free)");
+        pk.ev[pk.n_ev++] = ev;
     }
-    insert_free(ln, lv.slab, lv.off, lv.bytes);
+    foreign_frees += 1;
+    ln.parked.push_back(pk);
 }
 void DevicePool::trim() {
     trims += 1;
     if (!backend_.malloc_fn) (void)hipDeviceSynchronize();
     for (auto& ln : lane_) {
         for (auto& pk : ln.parked) {            // the device is idle: parked ranges are plain free memory
-            if (pk.ev) spare_events_.push_back(pk.ev);
+            for (int k = 0; k < pk.n_ev; ++k) spare_events_.push_back(pk.ev[k]);
             insert_free(ln, pk.slab, pk.off, pk.len);
         }
         ln.parked.clear();
@@ -314,6 +326,7 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
         if (const char* e = std::getenv("FHELIN_FUSE_LIFT")) fuse_lift = std::atoi(e) != 0;
         if (const char* e = std::getenv("FHELIN_LDS_DIGITS")) lds_digits = std::atoi(e) != 0;
         if (const char* e = std::getenv("FHELIN_NTT_TRACE")) trace_small_ntt = std::atoi(e);
+        if (const char* e = std::getenv("FHELIN_HOST_WAITS")) trace_waits = std::atoi(e) != 0;
     }
     hip_check(hipEventCreate(&ev_start), "hipEventCreate");
     stage_words = (size_t)2 << p.log_n;
@@ -321,6 +334,8 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
         hip_check(hipHostMalloc(reinterpret_cast<void**>(&stage_buf[i]), stage_words * sizeof(u64), hipHostMallocDefault), "hipHostMalloc(stage)");
         hip_check(hipEventCreateWithFlags(&stage_ev[i], hipEventDisableTiming), "hipEventCreate(stage)");
     }
+    hip_check(hipHostMalloc(reinterpret_cast<void**>(&small_buf), (size_t)SMALL_SLOTS * SMALL_WORDS * sizeof(u64), hipHostMallocDefault), "hipHostMalloc(stage, small)");
+    for (int i = 0; i < SMALL_SLOTS; ++i) hip_check(hipEventCreateWithFlags(&small_ev[i], hipEventDisableTiming), "hipEventCreate(stage, small)");
     hip_check(hipEventCreate(&ev_stop), "hipEventCreate");
     has_device = true;
 
@@ -476,10 +491,37 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
 }
 
 void Context::upload_async(u64* dst, const u64* src, size_t words) {
+    if (words <= SMALL_WORDS && small_buf) {
+        const int i = small_next;
+        small_next = (small_next + 1) % SMALL_SLOTS;
+        if (small_used[i]) {
+            timespec a, b;
+            if (trace_waits) clock_gettime(CLOCK_MONOTONIC, &a);
+            hip_check(hipEventSynchronize(small_ev[i]), "hipEventSynchronize(stage, small)");
+            if (trace_waits) {
+                clock_gettime(CLOCK_MONOTONIC, &b);
+                note_wait("upload ring (small)", (u64)((b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec)));
+            }
+        }
+        u64* slot = small_buf + (size_t)i * SMALL_WORDS;
+        std::memcpy(slot, src, words * sizeof(u64));
+        hip_check(hipMemcpyAsync(dst, slot, words * sizeof(u64), hipMemcpyHostToDevice, stream), "hipMemcpyAsync(stage, small)");
+        hip_check(hipEventRecord(small_ev[i], stream), "hipEventRecord(stage, small)");
+        small_used[i] = true;
+        return;
+    }
     if (words > stage_words) throw Error(FHELIN_ERR_INTERNAL, "upload_async: block larger than a staging slot");
     const int i = stage_next;
     stage_next = (stage_next + 1) % STAGE_SLOTS;
-    if (stage_used[i]) hip_check(hipEventSynchronize(stage_ev[i]), "hipEventSynchronize(stage)");
+    if (stage_used[i]) {
+        timespec a, b;
+        if (trace_waits) clock_gettime(CLOCK_MONOTONIC, &a);
+        hip_check(hipEventSynchronize(stage_ev[i]), "hipEventSynchronize(stage)");
+        if (trace_waits) {
+            clock_gettime(CLOCK_MONOTONIC, &b);
+            note_wait("upload ring (large)", (u64)((b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec)));
+        }
+    }
     std::memcpy(stage_buf[i], src, words * sizeof(u64));
     hip_check(hipMemcpyAsync(dst, stage_buf[i], words * sizeof(u64), hipMemcpyHostToDevice, stream), "hipMemcpyAsync(stage)");
     hip_check(hipEventRecord(stage_ev[i], stream), "hipEventRecord(stage)");
@@ -487,6 +529,10 @@ void Context::upload_async(u64* dst, const u64* src, size_t words) {
 }
 
 Context::~Context() {
+    if (trace_waits) {
+        fprintf(stderr, "[fhelin] host time blocked inside the library, by site (waits, ms):\n");
+        for (const auto& e : wait_sites) fprintf(stderr, "  %8llu %10.1f  %s\n", (unsigned long long)e.second.first, e.second.second / 1e6, e.first.c_str());
+    }
     if (trace_small_ntt && !small_ntt_sites.empty()) {
         std::vector<std::pair<std::string, std::pair<u64, u64>>> v(small_ntt_sites.begin(), small_ntt_sites.end());
         std::sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.second.first > b.second.first; });
@@ -507,6 +553,9 @@ Context::~Context() {
             if (stage_ev[i]) (void)hipEventDestroy(stage_ev[i]);
             if (stage_buf[i]) (void)hipHostFree(stage_buf[i]);
         }
+        for (int i = 0; i < SMALL_SLOTS; ++i)
+            if (small_ev[i]) (void)hipEventDestroy(small_ev[i]);
+        if (small_buf) (void)hipHostFree(small_buf);
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
         if (own_stream && main_stream) (void)hipStreamDestroy(main_stream);

@@ -66,7 +66,13 @@ public:
     explicit DevicePool(const Backend& b) : backend_(b) {}
     ~DevicePool();
     void* alloc(size_t bytes);
-    void free(void* p);
+    // used_by_lanes: lanes (bit k) whose queued work may still read the block besides the current one (a plaintext encoding shared by
+    // the lanes of a pass): the owner lane reuses the range only behind all of them
+    void free(void* p, unsigned used_by_lanes = 0);
+    // between fhelin_ctx_lanes_fork and _join the caller's lanes run side by side and a handle may be dropped (a host language's garbage
+    // collection) while ANY lane is current: a free under a foreign lane then waits for every lane, not only the current one
+    bool conservative_foreign_free = false;
+    int n_user_lanes = 0;
     void trim();                                // hand slabs that hold nothing back to the driver (synchronises the device first)
     size_t bytes_reserved() const { return reserved_; }
     size_t bytes_live() const { return live_bytes_; }
@@ -87,7 +93,7 @@ private:
         std::map<size_t, size_t> free_at;       // offset -> length of the free ranges, address-ordered
     };
     struct Live { size_t bytes; int lane; int slab; size_t off; };
-    struct Parked { int slab; size_t off, len; hipEvent_t ev; };   // freed under a foreign lane: waits for the event
+    struct Parked { int slab; size_t off, len; hipEvent_t ev[MAX_LANES]; int n_ev; };   // freed while other lanes may read it: waits for their events
     struct Lane {
         std::vector<Slab> slabs;
         std::multimap<size_t, std::pair<int, size_t>> by_size;      // length -> (slab, offset): best fit
@@ -186,12 +192,21 @@ struct Context {
     // Pinned staging ring for host->device uploads on the hot path (plaintext encodings, encryption randomness):
     // the copy is queued on the current stream and the host does NOT wait for the stream to drain.  A slot is reused
     // only after the event recorded behind its copy has completed.
-    static constexpr int STAGE_SLOTS = 8;
+    static constexpr int STAGE_SLOTS = 64;   // 64 x 2N words pinned (64 MiB at N=2^16): with 8 the host ran at most eight plaintext encodings ahead of the GPU
     u64* stage_buf[STAGE_SLOTS] = {};
     hipEvent_t stage_ev[STAGE_SLOTS] = {};
     bool stage_used[STAGE_SLOTS] = {};
     int stage_next = 0;
     size_t stage_words = 0;
+    // small payloads (the scalar tables of a linear combination: a few KB, hundreds per pass) have a ring of their own with MANY slots:
+    // with the eight large slots alone the host could run at most eight uploads ahead of the GPU - harmless on one stream, but a host
+    // that waits for lane 1's old upload cannot feed lane 2 (fhelin_ctx_set_lane)
+    static constexpr int SMALL_SLOTS = 256;
+    static constexpr size_t SMALL_WORDS = 8192;      // 64 KiB
+    u64* small_buf = nullptr;                        // SMALL_SLOTS x SMALL_WORDS, pinned
+    hipEvent_t small_ev[SMALL_SLOTS] = {};
+    bool small_used[SMALL_SLOTS] = {};
+    int small_next = 0;
     void upload_async(u64* dst, const u64* src, size_t words);  // words <= 2N
 
     // ModDown / rescale constants (level independent)
@@ -245,6 +260,14 @@ struct Context {
     }
     // FHELIN_NTT_TRACE=<n>: transforms of at most n limb vectors (launches that cannot fill the GPU) are counted by call stack and the
     // table is printed when the context goes away (a development aid: which caller still issues single-ciphertext launches)
+    // FHELIN_HOST_WAITS=1: host time spent blocked inside the library, by site (printed when the context goes away)
+    bool trace_waits = false;
+    std::map<std::string, std::pair<u64, u64>> wait_sites;   // site -> (calls that waited, nanoseconds)
+    void note_wait(const char* site, u64 ns) {
+        auto& e = wait_sites[site];
+        e.first += 1;
+        e.second += ns;
+    }
     int trace_small_ntt = 0;
     std::map<std::string, std::pair<u64, u64>> small_ntt_sites;   // call stack -> (launches, limb vectors)
     void note_small_ntt(int nvec);

@@ -18,8 +18,9 @@ Ciphertext::~Ciphertext() {
     }
 }
 Encoding::~Encoding() {
+    if (ready) (void)hipEventDestroy(ready);
     if (d && ctx) {
-        try { ctx->pool.free(d); } catch (...) {}
+        try { ctx->pool.free(d, lanes_ordered); } catch (...) {}   // every lane that used it may still have reads queued
     }
 }
 EvalKey::~EvalKey() {

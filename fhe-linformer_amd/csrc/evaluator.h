@@ -45,6 +45,11 @@ struct Encoding {
     u64* d = nullptr;  // [ell][N] NTT form
     int ell = 0;
     long double scale = 0;
+    // made under lane `made_lane` (stream order covers its later uses there); another lane's stream waits for `ready` before its first
+    // use (Plaintext::at) - a device-side wait, the host never blocks
+    hipEvent_t ready = nullptr;
+    int made_lane = 0;
+    unsigned lanes_ordered = 0;   // bit k: lane k's stream is already ordered behind `ready`
     ~Encoding();
 };
 
