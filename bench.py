@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--pass-width", type=int, default=4, help="with --batch: at most this many samples travel in ONE pass (a pass keeps ~17 GB of "
                     "intermediates per sample at N=2^16 next to ~50 GB of keys: 4 fit 288 GB with room for the resident inputs, 8 do not); "
                     "a rank's share of a step runs as ceil(share / width) passes")
-    ap.add_argument("--lanes", type=int, default=1, help="with --batch: a pass runs as this many sub-batches on as many lanes (HIP streams) of the ONE "
+    ap.add_argument("--lanes", type=int, default=2, help="with --batch: a pass runs as this many sub-batches on as many lanes (HIP streams) of the ONE "
                     "context, concurrently on the GPU (linformer.LanedBatchedController); 1: one launch set for the whole pass")
     ap.add_argument("--batch-loop", action="store_true", help="with --batch: a rank runs its samples one after another instead (A/B)")
     ap.add_argument("--resident-gb", type=float, default=75.0, help="with --batch: device memory for the resident input sets of the "
