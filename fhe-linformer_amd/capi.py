@@ -451,6 +451,9 @@ class Engine:
             tok = np.ascontiguousarray(tokens, dtype=np.int32)
             tab = f(table)
             S, vocab = tok.shape[0], tab.shape[0]
+        if pos.shape[0] < S or pos.shape[1] != 128 or E_w.shape != F_w.shape or E_w.shape[0] != 32 or E_w.shape[1] < S + 1 or cls.size != 128 \
+                or E_b.size != 32 or F_b.size != 32:
+            raise FhelinError(1, "client_ingest: pos needs >= S rows of 128, E_w / F_w [32][>= S + 1], E_b / F_b [32], cls [128]")
         n = 64 + S + 1
         outs = self._outs(n)
         proj = np.empty((S + 1 + 64, 128)) if want_proj else None

@@ -580,8 +580,26 @@ std::vector<CtPtr> Client::ingest_sample(const double* emb, const int* tokens, c
     if (S < 1 || S1 > w_cols || (!emb && !(tokens && table && vocab > 0))) throw Error(FHELIN_ERR_ARG, "ingest: bad token count / inputs");
     if (level < 0 || level > c_.L || (int)drop.size() != n_vec) throw Error(FHELIN_ERR_ARG, "ingest: level out of range");
     hipStream_t s = c_.stream;
+    // every temporary of the sample - the embeddings, x_in, the projections, the expanded packing: the client's PLAINTEXT - is wiped
+    // before its block goes back to the recycled pool, and freed on every path out of this function (an exception included)
+    struct Temps {
+        Context& c;
+        hipStream_t s;
+        std::vector<std::pair<void*, size_t>> blocks;
+        void* get(size_t bytes) {
+            void* d = c.pool.alloc(bytes);
+            blocks.emplace_back(d, bytes);
+            return d;
+        }
+        ~Temps() {
+            for (auto& b : blocks) {
+                (void)hipMemsetAsync(b.first, 0, b.second, s);
+                try { c.pool.free(b.first); } catch (...) {}
+            }
+        }
+    } tmp{c_, s, {}};
     auto up = [&](const void* h, size_t bytes) {
-        void* d = c_.pool.alloc(bytes);
+        void* d = tmp.get(bytes);
         hip_check(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s), "ingest upload");
         return d;
     };
@@ -597,11 +615,11 @@ std::vector<CtPtr> Client::ingest_sample(const double* emb, const int* tokens, c
     double* d_Fw = (double*)up(F_w, (size_t)32 * w_cols * 8);
     double* d_Eb = (double*)up(E_b, 32 * 8);
     double* d_Fb = (double*)up(F_b, 32 * 8);
-    double* x_in = (double*)c_.pool.alloc((size_t)S1 * 128 * 8);
-    double* proj = (double*)c_.pool.alloc((size_t)64 * 128 * 8);
+    double* x_in = (double*)tmp.get((size_t)S1 * 128 * 8);
+    double* proj = (double*)tmp.get((size_t)64 * 128 * 8);
     launch_ingest_xin(x_in, d_emb, d_tok, d_tab, d_cls, d_pos, S, s);
     launch_ingest_project(proj, x_in, d_Ew, d_Eb, d_Fw, d_Fb, w_cols, S1, s);
-    double* dv = (double*)c_.pool.alloc((size_t)n_vec * slots * 16);
+    double* dv = (double*)tmp.get((size_t)n_vec * slots * 16);
     launch_ingest_expand(dv, proj, x_in, S1, slots, s);
     hip_check(hipGetLastError(), "ingest kernels");
     if (proj_out) {   // test hook: x_in rows then the 64 projected rows, as computed on the device
@@ -628,11 +646,10 @@ std::vector<CtPtr> Client::ingest_sample(const double* emb, const int* tokens, c
             int hi = j;
             while (hi < n_vec && hi - j < 32 && !seen[hi] && std::min(c_.L, level + std::max(0, drop[hi])) == lvl) ++hi;
             const int n = hi - j;
-            u64* enc = c_.dalloc<u64>((size_t)n * pn);
+            u64* enc = (u64*)tmp.get((size_t)n * pn * sizeof(u64));   // the encoded plaintext: wiped and freed with the other temporaries
             encode_complex_on_device(c_, enc, dv + (size_t)j * slots * 2, n, slots, ell, scale);
             std::vector<CtPtr> part;
             encrypt_encoded(enc, pn, n, ell, scale, slots, part);
-            c_.pool.free(enc);
             for (int k = 0; k < n; ++k) {
                 out[j + k] = part[k];
                 seen[j + k] = 1;
@@ -640,10 +657,7 @@ std::vector<CtPtr> Client::ingest_sample(const double* emb, const int* tokens, c
             j = hi;
         }
     }
-    for (void* p : {(void*)d_emb, (void*)d_tok, (void*)d_tab, (void*)d_cls, (void*)d_pos, (void*)d_Ew, (void*)d_Fw, (void*)d_Eb, (void*)d_Fb,
-                    (void*)x_in, (void*)proj, (void*)dv})
-        if (p) c_.pool.free(p);
-    return out;
+    return out;   // ~Temps wipes and frees
 }
 
 CtPtr Client::phase(const CtPtr& ct, int nl) {

@@ -289,13 +289,19 @@ CtVec Composite::matmul_ct_each(const CtVec& rows, const CtVec& ws, int slots, i
     return rotsum_batch(prod, slots, padding);
 }
 
+static bool same_plain_set(const std::vector<std::vector<double>>& kept, const std::vector<PtPtr>& now) {
+    if (kept.size() != now.size()) return false;
+    for (size_t i = 0; i < now.size(); ++i)
+        if (kept[i] != now[i]->values) return false;
+    return true;
+}
 static uint64_t hash_plain(const PtPtr& w, uint64_t h) {   // FNV-1a over the slot values and the level
     for (double v : w->values) {
         uint64_t bits;
         std::memcpy(&bits, &v, sizeof bits);
         h = (h ^ bits) * 1099511628211ull;
     }
-    return (h ^ (uint64_t)w->values.size() ^ ((uint64_t)w->level << 32)) * 1099511628211ull;
+    return (h ^ (uint64_t)w->values.size() ^ ((uint64_t)w->level << 32) ^ ((uint64_t)w->slots << 48)) * 1099511628211ull;
 }
 
 // W''_t (t = 0..3): block b (128 slots) of W''_t is block b of W_j with j = (b - t) mod 4 — see matmulRElarge.
@@ -308,7 +314,7 @@ std::vector<PtPtr> Composite::relarge_weights(const std::vector<PtPtr>& weights,
     char key[96];
     snprintf(key, sizeof key, "relarge:%016llx:%d", (unsigned long long)h, rotated ? 1 : 0);
     auto it = relarge_cache_.find(key);
-    if (it != relarge_cache_.end()) return it->second;
+    if (it != relarge_cache_.end() && same_plain_set(relarge_src_[key], weights)) return it->second;   // a hash hit is CHECKED against the values
     const int ns = num_slots();
     std::vector<PtPtr> out;
     for (int t = 0; t < 4; ++t) {
@@ -321,8 +327,14 @@ std::vector<PtPtr> Composite::relarge_weights(const std::vector<PtPtr>& weights,
         }
         out.push_back(encode_vec(v, weights[0]->level));
     }
-    if (relarge_cache_.size() > 16) relarge_cache_.clear();   // bounded: a driver uses one or two weight sets
+    if (relarge_cache_.size() > 16) {   // bounded: a driver uses one or two weight sets
+        relarge_cache_.clear();
+        relarge_src_.clear();
+    }
     relarge_cache_[key] = out;
+    std::vector<std::vector<double>> src;
+    for (const PtPtr& w : weights) src.push_back(w->values);
+    relarge_src_[key] = src;
     return out;
 }
 
@@ -419,7 +431,7 @@ PtPtr Composite::relarge_tiled_bias(const PtPtr& bias, int q) {
     char key[96];
     snprintf(key, sizeof key, "relarge_bias:%016llx:%d", (unsigned long long)hash_plain(bias, 1469598103934665603ull), q);
     auto it = relarge_cache_.find(key);
-    if (it != relarge_cache_.end()) return it->second[0];
+    if (it != relarge_cache_.end() && same_plain_set(relarge_src_[key], std::vector<PtPtr>{bias})) return it->second[0];
     std::vector<double> v(ns, 0.0);
     for (int i = 0; i < q; ++i)
         for (int s = 0; s < ns; ++s) {
@@ -427,8 +439,12 @@ PtPtr Composite::relarge_tiled_bias(const PtPtr& bias, int q) {
             if (b != 0.0) v[(s + 512 * i) % ns] += b;       // rot(bias, -512 i): slot s lands at s + 512 i
         }
     PtPtr tiled = encode_vec(v, bias->level);
-    if (relarge_cache_.size() > 16) relarge_cache_.clear();
+    if (relarge_cache_.size() > 16) {
+        relarge_cache_.clear();
+        relarge_src_.clear();
+    }
     relarge_cache_[key] = {tiled};
+    relarge_src_[key] = {bias->values};
     return tiled;
 }
 

@@ -111,6 +111,7 @@ private:
     std::map<std::string, PtPtr> mask_cache_;
     // matmulRElarge: the four 128x128 weight blocks re-arranged block-wise (W''_t, t = 0..3), cached per weight set
     std::map<std::string, std::vector<PtPtr>> relarge_cache_;
+    std::map<std::string, std::vector<std::vector<double>>> relarge_src_;   // the slot values an entry was made from: a hash hit is compared with them
     std::vector<PtPtr> relarge_weights(const std::vector<PtPtr>& weights, bool rotated);
     bool relarge_shared(const CtVec& inputs, const std::vector<PtPtr>& weights);
     CtVec relarge_u(const CtVec& inputs, const std::vector<PtPtr>& weights);        // the shared form's first step: U per row

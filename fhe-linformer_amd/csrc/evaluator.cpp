@@ -329,8 +329,17 @@ Evaluator::FoldedKey Evaluator::folded_key(const PtPtr& p, int index, long doubl
     const u64 g = c_.galois_element(index);
     auto kit = rot_keys.find(g);
     if (kit == rot_keys.end()) throw Error(FHELIN_ERR_KEY, "no rotation key for index " + std::to_string(index) + " (EvalRotateKeyGen list)");
-    for (const FoldedKey& f : folded_keys)
-        if (f.pt.get() == p.get() && f.key.get() == kit->second.get() && f.index == index && fabsl(f.scale / scale - 1.0L) < 1e-12L) return f;
+    for (size_t i = 0; i < folded_keys.size(); ++i) {
+        const FoldedKey& f = folded_keys[i];
+        if (f.pt.get() == p.get() && f.key.get() == kit->second.get() && f.index == index && fabsl(f.scale / scale - 1.0L) < 1e-12L) {
+            FoldedKey hit = f;
+            if (i + 1 != folded_keys.size()) {   // least recently used goes first when the cache is full
+                folded_keys.erase(folded_keys.begin() + i);
+                folded_keys.push_back(hit);
+            }
+            return hit;
+        }
+    }
     FoldedKey f;
     f.pt = p;
     f.key = kit->second;
