@@ -54,6 +54,8 @@ def parse():
                     "a rank's share of a step runs as ceil(share / width) passes")
     ap.add_argument("--lanes", type=int, default=2, help="with --batch: a pass runs as this many sub-batches on as many lanes (HIP streams) of the ONE "
                     "context, concurrently on the GPU (linformer.LanedBatchedController); 1: one launch set for the whole pass")
+    ap.add_argument("--dataflow", action="store_true", help="one sample per pass: the independent branches of the driver's circuit on different lanes "
+                    "of the context (linformer.DataflowController; measured at no gain in round 4, DESIGN.md 6d: off by default)")
     ap.add_argument("--batch-loop", action="store_true", help="with --batch: a rank runs its samples one after another instead (A/B)")
     ap.add_argument("--resident-gb", type=float, default=75.0, help="with --batch: device memory for the resident input sets of the "
                     "timed region; steps cycle through the sets that fit (every pass still does all of its work)")
@@ -483,9 +485,16 @@ def main():
 
         bplan = lf.batched_level_plan(plan, width, n_client_sources) if (use_plan and batched) else []
 
+        flow = lf.DataflowController(ctl) if (not row_mode and args.dataflow and os.environ.get("FHELIN_LANES", "2") != "0") else None
+
         def server_pass(enc):
             if use_plan:
                 eng.level_plan_begin("apply", first_source=n_client_sources)
+            if flow is not None and eng.lazy_rows_on:
+                flow.begin()
+                r = lf.forward_encrypted(flow, w, enc, None, args.variant)
+                flow.end()
+                return r
             return lf.forward_encrypted(ctl, w, enc, None, args.variant)
 
         def server_pass_batched(encs):

@@ -88,6 +88,9 @@ def load_library():
         "fhelin_level_plan_set": (i32, [vp, C.POINTER(i32), i32]),
         "fhelin_sync": (i32, [vp]),
         "fhelin_ctx_set_lane": (i32, [vp, i32]),
+        "fhelin_ctx_lane_wait": (i32, [vp, i32]),
+        "fhelin_ctx_lane_mark": (i32, [vp]),
+        "fhelin_ctx_lane_wait_mark": (i32, [vp, i32]),
         "fhelin_ctx_lanes_fork": (i32, [vp]),
         "fhelin_ctx_lanes_join": (i32, [vp]),
         "fhelin_ctx_trim": (i32, [vp]),
@@ -276,7 +279,8 @@ class Engine:
         a, d = C.c_int32(), C.c_int32()
         self._ck(self.lib.fhelin_ctx_info(self.h, None, C.byref(a), C.byref(d)))
         self.alpha, self.has_device = a.value, bool(d.value)
-        self.lazy_heavy = os.environ.get("FHELIN_LAZY_HEAVY", "1") != "0"   # the library reads the same knob (capi.cpp)
+        self.lazy_heavy = os.environ.get("FHELIN_LAZY_HEAVY", "1") != "0"
+        self.lazy_rows_on = os.environ.get("FHELIN_LAZY_ROWS", "1") != "0"   # the library reads the same knob (capi.cpp)
 
     def _ck(self, rc):
         if rc != 0:
@@ -285,6 +289,7 @@ class Engine:
     def set_lazy_rows(self, on):
         """deferred evaluation of the rows of matmul_pt / unwrapExpanded (default on)"""
         self._ck(self.lib.fhelin_ctx_set_lazy_rows(self.h, 1 if on else 0))
+        self.lazy_rows_on = bool(on)
 
     # level plan (include/fhelin.h fhelin_level_plan_*): record one pass of a straight-line driver, apply to later ones
     def force(self, cts):
@@ -347,6 +352,16 @@ class Engine:
     def set_lane(self, k):
         """subsequent calls launch on lane k's stream (0 = the main stream) and allocate from its arena"""
         self._ck(self.lib.fhelin_ctx_set_lane(self.h, int(k)))
+
+    def lane_wait(self, from_lane):
+        """the current lane's stream waits for everything issued under from_lane so far"""
+        self._ck(self.lib.fhelin_ctx_lane_wait(self.h, int(from_lane)))
+
+    def lane_mark(self):
+        self._ck(self.lib.fhelin_ctx_lane_mark(self.h))
+
+    def lane_wait_mark(self, from_lane):
+        self._ck(self.lib.fhelin_ctx_lane_wait_mark(self.h, int(from_lane)))
 
     def lanes_fork(self):
         self._ck(self.lib.fhelin_ctx_lanes_fork(self.h))

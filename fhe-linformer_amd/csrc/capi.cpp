@@ -110,6 +110,9 @@ void fhelin_ctx_destroy(fhelin_ctx* c) {
         for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %llu", (unsigned long long)c->ev.gather_copies[i]);
         std::fprintf(stderr, "\n");
     }
+    if (c)
+        for (hipEvent_t e : c->lane_mark)
+            if (e) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -234,6 +237,52 @@ int fhelin_ctx_set_lane(fhelin_ctx* c, int32_t lane) {
     c->ctx.pool.cur_lane = lane;
     FHELIN_CATCH
 }
+int fhelin_ctx_lane_wait(fhelin_ctx* c, int32_t from_lane) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    FHELIN_TRY
+    c->ctx.require_device();
+    if (from_lane < 0 || from_lane > c->ctx.n_lanes) throw Error(FHELIN_ERR_ARG, "lane_wait: no such lane");
+    if (from_lane != c->ctx.pool.cur_lane) {
+        // what was DEFERRED under that lane is issued there first, then this lane's stream goes behind everything queued on it
+        if (!c->pending_heavy[from_lane].empty()) {
+            const int cur = c->ctx.pool.cur_lane;
+            hipStream_t cur_stream = c->ctx.stream;
+            c->ctx.stream = from_lane == 0 ? c->ctx.main_stream : c->ctx.lane_stream[from_lane];
+            c->ctx.pool.cur_lane = from_lane;
+            try {
+                flush_heavy(c);
+            } catch (...) {
+                c->ctx.stream = cur_stream;
+                c->ctx.pool.cur_lane = cur;
+                throw;
+            }
+            c->ctx.stream = cur_stream;
+            c->ctx.pool.cur_lane = cur;
+        }
+        wait_for_lane(c, from_lane);
+    }
+    FHELIN_CATCH
+}
+int fhelin_ctx_lane_mark(fhelin_ctx* c) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    FHELIN_TRY
+    c->ctx.require_device();
+    const int k = c->ctx.pool.cur_lane;
+    if (!c->lane_mark[k]) hip_check(hipEventCreateWithFlags(&c->lane_mark[k], hipEventDisableTiming), "hipEventCreate(lane mark)");
+    if (!c->pending_heavy[k].empty()) flush_heavy(c);
+    hip_check(hipEventRecord(c->lane_mark[k], c->ctx.stream), "hipEventRecord(lane mark)");
+    c->lane_marked[k] = true;
+    FHELIN_CATCH
+}
+int fhelin_ctx_lane_wait_mark(fhelin_ctx* c, int32_t from_lane) {
+    if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
+    FHELIN_TRY
+    c->ctx.require_device();
+    if (from_lane < 0 || from_lane > c->ctx.n_lanes) throw Error(FHELIN_ERR_ARG, "lane_wait_mark: no such lane");
+    if (from_lane != c->ctx.pool.cur_lane && c->lane_marked[from_lane])
+        hip_check(hipStreamWaitEvent(c->ctx.stream, c->lane_mark[from_lane], 0), "hipStreamWaitEvent(lane mark)");
+    FHELIN_CATCH
+}
 int fhelin_ctx_lanes_fork(fhelin_ctx* c) {
     if (!c) return capi_fail(FHELIN_ERR_ARG, "null context");
     FHELIN_TRY
@@ -243,6 +292,7 @@ int fhelin_ctx_lanes_fork(fhelin_ctx* c) {
     c->ctx.fork_lanes();
     c->ctx.pool.n_user_lanes = c->ctx.n_lanes;
     c->ctx.pool.conservative_foreign_free = true;
+    for (bool& m : c->lane_marked) m = false;
     FHELIN_CATCH
 }
 int fhelin_ctx_lanes_join(fhelin_ctx* c) {

@@ -106,6 +106,8 @@ struct fhelin_ctx {
         return false;
     }
     int user_lane = 0;          // fhelin_ctx_set_lane: 0 = the context's main stream
+    hipEvent_t lane_mark[fhelin::DevicePool::MAX_LANES] = {};   // fhelin_ctx_lane_mark: a point in a lane's stream others can wait for
+    bool lane_marked[fhelin::DevicePool::MAX_LANES] = {};
     fhelin::LevelPlan plan;
     explicit fhelin_ctx(const fhelin::Params& p);
 };

@@ -168,6 +168,104 @@ class GpuController:
         return self._cheb(("tanh", mult), lambda x: math.tanh(x / mult), c, lo, hi, degree)
 
 
+class DataflowController:
+    """ONE sample, its independent branches on different lanes.  The reference's driver is a straight-line program, but not a chain: the
+    value projection (src/main.cpp:212-213: 32 rows of 7-step trees, large launches) does not depend on the scores chain that the driver
+    writes in front of it (:196-207: single-ciphertext steps, each a handful of launches that cannot fill the GPU).  This wrapper puts
+    every call on the lane (HIP stream + memory arena of the one context, include/fhelin.h fhelin_ctx_set_lane) of the ciphertexts it
+    reads: a call whose inputs carry no lane yet - fresh encryptions, rows nobody has evaluated - starts a new branch on the next lane; a
+    call that reads values of two branches runs on the first one's lane after fhelin_ctx_lane_wait on the other.  The host issues both
+    branches back to back (3.4 us per launch, it never waits for the GPU), the GPU runs them side by side.  No knowledge of the driver: the
+    rule is data flow.  Scheduling only - the residues of the plain single pass (tests/test_batched_forward_gpu.py).
+    Use: ctl.begin() ... forward_encrypted(ctl, ...) ... ctl.end()."""
+
+    # calls whose outputs are deferred rows when they return more than one (capi_composite.cpp): evaluated later, under the lane that reads them
+    _DEFERRED = ("matmulRE", "matmulCR", "unwrapExpanded", "matmulRElarge")
+    BULK_ROWS = 8        # a call that reads this many ciphertexts is a row loop: its launches fill the GPU
+    _PLAIN = ("level", "encode", "read_plain_input", "read_plain_repeated_input", "read_plain_expanded_input", "decrypt")
+
+    def __init__(self, inner, lanes=2):
+        self.c, self.e, self.lanes = inner, inner.e, lanes
+        self.num_slots = inner.num_slots
+        self._next = 0
+        self.branches = 0
+
+    @property
+    def n_boot(self):
+        return self.c.n_boot
+
+    def begin(self):
+        self.e.set_lane(0)
+        self.e.lanes_fork()
+        self._next = 0
+
+    def end(self):
+        self.e.set_lane(0)
+        self.e.lanes_join()
+
+    def _cts(self, x, out):
+        if hasattr(x, "info") and hasattr(x, "export"):
+            out.append(x)
+        elif isinstance(x, (list, tuple)):
+            for v in x:
+                self._cts(v, out)
+
+    def __getattr__(self, name):
+        fn = getattr(self.c, name)
+        if name in DataflowController._PLAIN or not callable(fn):
+            if name == "decrypt":
+                def dec(c):
+                    self.e.set_lane(0)
+                    return fn(c)
+                return dec
+            if name == "level":
+                def lev(c):            # reading the level may evaluate a deferred value: under its own lane
+                    if getattr(c, "lane", None) is not None:
+                        self.e.set_lane(c.lane)
+                    return fn(c)
+                return lev
+            return fn
+
+        def call(*a, **kw):
+            ins = []
+            self._cts(a, ins)
+            lanes = []
+            for h in ins:
+                l = getattr(h, "lane", None)
+                if l is not None and l not in lanes:
+                    lanes.append(l)
+            if lanes:
+                lane = lanes[0]
+                self.e.set_lane(lane)
+            else:                                   # a new branch: nothing it reads has been computed under a lane
+                lane = 1 + self._next % self.lanes
+                self._next += 1
+                self.branches += 1
+                self.e.set_lane(lane)
+                # ... held back until the other lanes' last BULK call has drained: beside a row loop that fills the GPU by itself a
+                # second one gains nothing; beside the single-ciphertext steps that FOLLOW it there, it fills the CUs they leave idle
+                for l in range(1, self.lanes + 1):
+                    if l != lane:
+                        self.e.lane_wait_mark(l)
+            for l in lanes[1:]:
+                self.e.lane_wait(l)
+            r = fn(*a, **kw)
+            if len(ins) >= DataflowController.BULK_ROWS:
+                self.e.lane_mark()
+            outs = []
+            self._cts(r, outs)
+            deferred = name in DataflowController._DEFERRED and len(outs) > 1 and not lanes and not any(_is_ct(v) for v in a[1:2])
+            for h in outs:
+                if getattr(h, "lane", None) is None:
+                    h.lane = None if deferred else lane
+            return r
+        return call
+
+
+def _is_ct(x):
+    return hasattr(x, "info") and hasattr(x, "export")
+
+
 class Batch(list):
     """one value of the driver for each of B samples (B ciphertext handles, sample order)"""
 

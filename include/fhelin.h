@@ -112,8 +112,16 @@ int fhelin_sync(fhelin_ctx* c);
  * GPU from ONE host thread and ONE context (one key set, one plaintext cache): the tail of one lane's launch is filled by the
  * other's.  lanes_fork: lanes 1..n wait for everything the main stream has been given so far (the inputs); lanes_join: the main
  * stream waits for every lane (before decrypting / exporting under lane 0).  A value must be consumed under the lane that produced it,
- * or after a join; results are bit-identical to lane 0 (scheduling only). */
+ * after a join, or after fhelin_ctx_lane_wait(producer's lane) under the consuming lane (a value of one branch of a circuit meeting
+ * another branch's); results are bit-identical to lane 0 (scheduling only). */
 int fhelin_ctx_set_lane(fhelin_ctx* c, int32_t lane);
+int fhelin_ctx_lane_wait(fhelin_ctx* c, int32_t from_lane);   /* the current lane's stream waits for everything issued under from_lane so far */
+/* mark: remember the present point of the current lane's stream; wait_mark: the current lane waits for from_lane's last mark (not for what
+ * was issued there after it).  A scheduler that starts a new branch of a circuit on a free lane holds it back until the other lane's
+ * last BULK call (a row loop that fills the GPU by itself) has drained: the new branch then runs beside the small launches that follow
+ * it there, instead of beside the bulk call, where it would gain nothing. */
+int fhelin_ctx_lane_mark(fhelin_ctx* c);
+int fhelin_ctx_lane_wait_mark(fhelin_ctx* c, int32_t from_lane);
 int fhelin_ctx_lanes_fork(fhelin_ctx* c);
 int fhelin_ctx_lanes_join(fhelin_ctx* c);
 /* give the device memory the context's caching pool holds but does not use back to the driver (another context / process

@@ -113,6 +113,29 @@ def test_batched_pass_gives_the_residues_of_the_single_passes(fa, variant, S):
                 _same(ltr[k][x], traces[x][k], (variant, "lanes", x, k))
             _same(lout[x], outs[x], (variant, "lanes", x, "out"))
         assert st_lane["keyswitch"] == st_single["keyswitch"] and st_lane["bootstrap"] == st_single["bootstrap"]
+        # ONE sample with its independent branches on different lanes (DataflowController: the value projection beside the scores chain):
+        # scheduling only, the residues of the plain pass
+        class ReplayingFlow(lf.GpuController):
+            def __init__(self, e, x):
+                super().__init__(e)
+                self.k, self.x = 0, x
+
+            def encrypt(self, v, level=0):
+                c = fresh[self.x][self.k]
+                self.k += 1
+                return c
+
+        for x in (0, B - 1):
+            fctl, ftr = lf.DataflowController(ReplayingFlow(eng, x)), {}
+            fctl.begin()
+            fout = lf.forward_encrypted(fctl, w, encs[x], ftr, variant)
+            fctl.end()
+            eng.sync()
+            assert fctl.branches >= 2                       # at least the K and the V projection started branches of their own
+            for k in TRACED:
+                _same(ftr[k], traces[x][k], (variant, "dataflow", x, k))
+            _same(fout, outs[x], (variant, "dataflow", x, "out"))
+        eng.stats(reset=True)
         # ... and it is the forward pass of every sample
         for x in range(B):
             lg = lf.logits_from_slots(eng.decrypt(bout[x]))
