@@ -192,6 +192,9 @@ def test_bootstrap_precision_at_the_headline_ring(fa):
             out = eng.bootstrap_drop(ct, drop)
             worst[drop] = float(np.max(np.abs(eng.decrypt(out) - m)))
             assert out.info()["ell"] == eng.n_q - eng.bootstrap_describe()["depth"] - drop
+        # 15 levels: the refreshed ciphertext keeps 12 rescales of the 27-level chain; the reference counts on 10 after OpenFHE's
+        # (/root/reference/src/FHEController.cpp:27-33: "available multiplications: levelsUsedBeforeBootstrap - 2")
+        assert eng.bootstrap_describe()["depth"] == 15 and eng.n_q - 15 - 1 >= 12 - 2
         print("bootstrap max error at N=2^16, 28+7 limbs:", {k: f"{v:.2e}" for k, v in worst.items()}, "(asserted < 6.3e-5)")
         assert max(worst.values()) < 6.3e-5, worst
     finally:
