@@ -83,6 +83,7 @@ def load_library():
         "fhelin_ct_force": (i32, [vp, C.POINTER(vp), i32]),
         "fhelin_level_plan_begin": (i32, [vp, i32]),
         "fhelin_level_plan_seek": (i32, [vp, i32]),
+        "fhelin_level_plan_tell": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
         "fhelin_level_plan_end": (i32, [vp, C.POINTER(i32)]),
         "fhelin_level_plan_get": (i32, [vp, C.POINTER(i32), i32, C.POINTER(i32)]),
         "fhelin_level_plan_set": (i32, [vp, C.POINTER(i32), i32]),
@@ -304,6 +305,15 @@ class Engine:
         self._ck(self.lib.fhelin_level_plan_begin(self.h, {"off": 0, "record": 1, "apply": 2}[mode]))
         if first_source:
             self._ck(self.lib.fhelin_level_plan_seek(self.h, int(first_source)))
+
+    def level_plan_tell(self):
+        """(mode, index of the next source call): mode "off" / "record" / "apply" """
+        m, k = C.c_int32(0), C.c_int32(0)
+        self._ck(self.lib.fhelin_level_plan_tell(self.h, C.byref(m), C.byref(k)))
+        return ("off", "record", "apply")[m.value], k.value
+
+    def level_plan_seek(self, source):
+        self._ck(self.lib.fhelin_level_plan_seek(self.h, int(source)))
 
     def level_plan_end(self):
         """ends the pass (a recording pass derives the plan); returns the plan: limbs per source, -1 = as asked"""

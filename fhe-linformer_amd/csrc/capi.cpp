@@ -190,6 +190,12 @@ int fhelin_level_plan_seek(fhelin_ctx* c, int32_t source) {
     c->plan.next_ordinal = source;
     return FHELIN_OK;
 }
+int fhelin_level_plan_tell(fhelin_ctx* c, int32_t* mode, int32_t* source) {
+    NEED(c);
+    if (mode) *mode = c->plan.mode;
+    if (source) *source = c->plan.next_ordinal;
+    return FHELIN_OK;
+}
 int fhelin_level_plan_end(fhelin_ctx* c, int32_t* n_sources) {
     NEED(c);
     FHELIN_TRY

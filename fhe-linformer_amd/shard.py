@@ -95,27 +95,26 @@ class EngineTransport:
         return self.eng.ct_import(limbs, deg=deg, scale=float(meta[4]), slots=slots)
 
 
-def all_gather_rows(dist, transport, local, n_rows, world):
-    """local: {row index: ciphertext} of this rank's rows (sample_ids partition) -> list of all n_rows ciphertexts, the
-    same objects on every rank (the owner re-imports its own rows too, so that every replica continues from identical
-    bytes).  One metadata all-gather and one payload all-gather (RCCL over xGMI with nccl)."""
+def _all_gather_indexed(dist, transport, local, owned):
+    """owned[r] = the indices rank r holds (local[i] on that rank) -> {index: ciphertext} of all of them on every rank (the owner
+    re-imports its own too, so that every replica continues from identical bytes).  One size all-reduce, one metadata all-gather and
+    one payload all-gather (RCCL over xGMI with nccl)."""
     import torch
-    rank = dist.get_rank()
-    per = -(-n_rows // world)
-    ids = sample_ids(n_rows, world, rank)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = owned[rank]
+    per = max(1, max(len(o) for o in owned))
     if hasattr(transport, "force"):
-        transport.force([local[i] for i in ids])
-    packed = [transport.pack(local[i]) for i in ids]
+        transport.force([local[i] for i in mine])
+    packed = [transport.pack(local[i]) for i in mine]
     dev = _device(dist)
-    meta = torch.zeros((per, 8), dtype=torch.float64, device=dev)
     size = torch.zeros(1, dtype=torch.int64, device=dev)
-    for k, (p, m) in enumerate(packed):
-        meta[k] = torch.as_tensor(m, dtype=torch.float64)
+    for p, _ in packed:
         size[0] = max(int(size[0]), int(p.numel() if hasattr(p, "numel") else p.size))
     dist.all_reduce(size, op=dist.ReduceOp.MAX)
-    row_bytes = int(size[0])
-    buf = torch.zeros((per, row_bytes), dtype=torch.uint8, device=dev)
-    for k, (p, _) in enumerate(packed):
+    meta = torch.zeros((per, 8), dtype=torch.float64, device=dev)
+    buf = torch.zeros((per, int(size[0])), dtype=torch.uint8, device=dev)
+    for k, (p, m) in enumerate(packed):
+        meta[k] = torch.as_tensor(m, dtype=torch.float64)
         t = p if hasattr(p, "numel") else torch.from_numpy(np.ascontiguousarray(p))
         buf[k, : t.numel()] = t.to(dev)
     metas = [torch.zeros_like(meta) for _ in range(world)]
@@ -123,12 +122,26 @@ def all_gather_rows(dist, transport, local, n_rows, world):
     dist.all_gather(metas, meta)
     dist.all_gather(bufs, buf)
     _payload_ready(dev)
-    out = [None] * n_rows
+    out = {}
     for r in range(world):
-        for k, i in enumerate(sample_ids(n_rows, world, r)):
+        for k, i in enumerate(owned[r]):
             payload = bufs[r][k] if getattr(transport, "device", False) else bufs[r][k].cpu().numpy()
             out[i] = transport.unpack(payload, metas[r][k].cpu().numpy())
     return out
+
+
+def all_gather_rows(dist, transport, local, n_rows, world):
+    """local: {row index: ciphertext} of this rank's rows (sample_ids partition) -> list of all n_rows ciphertexts, the
+    same objects on every rank"""
+    got = _all_gather_indexed(dist, transport, local, [sample_ids(n_rows, world, r) for r in range(world)])
+    return [got[i] for i in range(n_rows)]
+
+
+def all_gather_owned(dist, transport, local, owners):
+    """owners[i] = the rank that holds value i (local[i] there) -> list of all values on every rank"""
+    world = dist.get_world_size()
+    got = _all_gather_indexed(dist, transport, local, [[i for i, o in enumerate(owners) if o == r] for r in range(world)])
+    return [got[i] for i in range(len(owners))]
 
 
 class _ShardedRows(list):
@@ -208,6 +221,26 @@ class _PendingRelarge(list):
         return list(other) + list(self)
 
 
+class _Chain:
+    """A ciphertext that is the result of single-ciphertext heavy calls (bootstrap, eval_gelu_function) the sharded controller has not
+    made yet.  The reference's drivers run such calls in loops over independent ciphertexts and read the results afterwards
+    (src/main.cpp:313-314: the two halves of affine-1; :354-358: GELU then bootstrap per container): the controller collects the
+    calls, and when another call reads one of the results every chain is evaluated by ONE rank - the rank that holds its input
+    (a container of generate_containers' split) or, for replicated inputs, the least loaded one - and one all-gather puts the
+    results on every rank.  `ops`: (method, args, kwargs, level-plan source index or None)."""
+    __slots__ = ("src", "ops", "owner", "value")
+
+    def __init__(self, src, ops, owner):
+        self.src, self.ops, self.owner, self.value = src, ops, owner, None
+
+
+def _resolved(fn):
+    def call(self, *a, **kw):
+        return fn(self, *[self._res(x) for x in a], **{k: self._res(v) for k, v in kw.items()})
+    call.__name__, call.__doc__ = fn.__name__, fn.__doc__
+    return call
+
+
 class RowShardedController:
     """Batch-1 latency on `world` GPUs: every rank holds the same keys and runs the same driver; the row loops of the
     reference's matmul* / unwrap* methods (src/FHEController.cpp:872,888,904,918,949,963,985,1001,1089,1115) are split
@@ -226,6 +259,10 @@ class RowShardedController:
         # counter() -> a running operation count (e.g. the engine's key switches): row_ops accumulates what this rank spent
         # evaluating the rows it owns, so that a test can check the split against an unsharded pass
         self.counter, self.row_ops = counter, 0
+        self._pending = []         # _Chain values nobody has read yet, in call order
+        self.shard_chains = True   # False: bootstrap / eval_gelu_function replicated on every rank (rounds 2-3)
+        eng = getattr(transport, "eng", None)
+        self._plan_eng = eng if hasattr(eng, "level_plan_tell") else None
 
     def _counted(self, fn):
         if self.counter is None:
@@ -236,7 +273,99 @@ class RowShardedController:
         return r
 
     def __getattr__(self, name):            # everything that is not a row loop: replicated, as the inner controller does it
-        return getattr(self.c, name)
+        f = getattr(self.c, name)
+        if not callable(f):
+            return f
+
+        def call(*a, **kw):                 # ... on the VALUES of pending chains
+            return f(*[self._res(x) for x in a], **{k: self._res(v) for k, v in kw.items()})
+        return call
+
+    # ---- single-ciphertext heavy calls in loops over independent ciphertexts: one rank each -------------------------------------
+    def _plan_pos(self):
+        return self._plan_eng.level_plan_tell() if self._plan_eng is not None else ("off", 0)
+
+    def _chain(self, name, x, a, kw, source):
+        mode, pos = self._plan_pos()
+        if self.world == 1 or not self.shard_chains or mode == "record":   # a recording pass runs the whole program on every rank
+            return getattr(self.c, name)(self._res(x), *a, **kw)
+        ordinal = None
+        if source and mode == "apply":       # the call is a source of the level plan: it keeps its place in the program's order
+            ordinal = pos
+            self._plan_eng.level_plan_seek(pos + 1)
+        op = (name, a, kw, ordinal)
+        if isinstance(x, _Chain) and x.value is None:
+            if x in self._pending:
+                self._pending.remove(x)      # superseded by the longer chain (evaluated by itself if somebody still reads it)
+            ch = _Chain(x.src, x.ops + [op], x.owner)
+        else:
+            ch = _Chain(x.value if isinstance(x, _Chain) else x, [op], None)
+        self._pending.append(ch)
+        return ch
+
+    def bootstrap(self, x):
+        return self._chain("bootstrap", x, (), {}, True)
+
+    def eval_gelu_function(self, x, *a, **kw):
+        return self._chain("eval_gelu_function", x, a, kw, False)
+
+    def _res(self, x):
+        """x with every pending chain in it (lists / tuples searched) replaced by its value; x itself when there is none"""
+        if isinstance(x, _Chain):
+            if x.value is None:
+                if x not in self._pending:
+                    self._pending.append(x)
+                self._flush()
+            return x.value
+        if type(x) in (list, tuple):
+            if not any(isinstance(e, _Chain) or type(e) in (list, tuple) for e in x):
+                return x
+            y = [self._res(e) for e in x]
+            if all(p is q for p, q in zip(x, y)):
+                return x
+            return y if type(x) is list else tuple(y)
+        return x
+
+    def _flush(self):
+        chains, self._pending = self._pending, []
+        if not chains:
+            return
+        if len(chains) == 1 and chains[0].owner is None:        # nothing to split: replicated, no gather
+            ch = chains[0]
+            _, pos = self._plan_pos()
+            ch.value = self._run_chains([ch])[0]
+            if self._plan_eng is not None:
+                self._plan_eng.level_plan_seek(pos)
+            return
+        load = [sum(1 for c in chains if c.owner == r) for r in range(self.world)]
+        for c in chains:                                        # the same assignment on every rank
+            if c.owner is None:
+                c.owner = load.index(min(load))
+                load[c.owner] += 1
+        mine = [c for c in chains if c.owner == self.rank]
+        _, pos = self._plan_pos()
+        vals = self._counted(lambda: self._run_chains(mine))
+        if self._plan_eng is not None:
+            self._plan_eng.level_plan_seek(pos)
+        local = {k: vals[mine.index(c)] for k, c in enumerate(chains) if c.owner == self.rank}
+        self.gathers += 1
+        self.gather_rows.append(len(chains))
+        got = all_gather_owned(self.dist, self.t, local, [c.owner for c in chains])
+        for c, v in zip(chains, got):
+            c.value = v
+
+    def _run_chains(self, chains):
+        """step by step over all chains, so that the engine's own deferral sees the calls of one kind next to each other and
+        evaluates them as ONE batched call (three Chebyshev evaluations, then three bootstraps)"""
+        vals = [c.src for c in chains]
+        for s in range(max((len(c.ops) for c in chains), default=0)):
+            for k, c in enumerate(chains):
+                if s < len(c.ops):
+                    name, a, kw, ordinal = c.ops[s]
+                    if ordinal is not None:
+                        self._plan_eng.level_plan_seek(ordinal)
+                    vals[k] = getattr(self.c, name)(vals[k], *a, **kw)
+        return vals
 
     def _mine(self, n):
         return sample_ids(n, self.world, self.rank)
@@ -262,15 +391,18 @@ class RowShardedController:
             return _ShardedRows(self, rows)
         return self._gather({i: rows[i] for i in ids}, n)
 
+    @_resolved
     def matmulRE(self, rows, w, bias=None, row_size=128, padding=128):
         if not _is_ct(w):       # plaintext weight: deferred rows, a rank reads (= evaluates) only the rows it owns
             return self._rows(len(rows), lambda: self.c.matmulRE(rows, w, bias, row_size, padding))
         return self._rows(len(rows), lambda: self.c.matmulRE(rows, w, bias, row_size, padding),
                           lambda ids: self.c.matmulRE([rows[i] for i in ids], w, bias, row_size, padding))
 
+    @_resolved
     def matmulCR(self, rows, w, bias=None):
         return self._rows(len(rows), lambda: self.c.matmulCR(rows, w, bias))
 
+    @_resolved
     def matmulRElarge(self, rows, weights, bias, mask_val=1.0):
         if self.world == 1:
             return self.c.matmulRElarge(rows, weights, bias, mask_val)
@@ -280,6 +412,7 @@ class RowShardedController:
         return self._rows(len(rows), lambda: self.c.matmulRElarge(rows, weights, bias, mask_val),
                           lambda ids: self.c.matmulRElarge([rows[i] for i in ids], weights, bias, mask_val))
 
+    @_resolved
     def generate_containers(self, inputs, bias=None):
         """containers of unread matmulRElarge rows: the groups of 32 rows are split over the ranks, every rank runs the engine's two
         calls on its groups (fused there) and ONE all-gather puts the containers on every rank - the same residues as the unsharded
@@ -297,16 +430,26 @@ class RowShardedController:
                         outs = self.c.matmulRElarge(rows[32 * g:32 * g + 32], weights, rbias, mask_val)
                         local[g] = self.c.generate_containers(outs, bias)[0]
                 self._counted(run)
+                if self.shard_chains:
+                    # the containers stay where they were computed: the driver's next calls on them (GELU, bootstrap) run on the
+                    # owner, and the gather moves the refreshed ciphertexts once (the first other reader flushes)
+                    owners = [r for r in range(self.world) for _ in sample_ids(n_groups, self.world, r)]
+                    chains = [_Chain(local.get(g), [], owners[g]) for g in range(n_groups)]
+                    self._pending += chains
+                    return chains
                 return self._gather(local, n_groups)
         return self.c.generate_containers(list(inputs), bias)
 
+    @_resolved
     def matmulCRlarge(self, rows, weights, bias):
         return self._rows(len(rows), lambda: self.c.matmulCRlarge(rows, weights, bias),
                           lambda ids: self.c.matmulCRlarge([rows[i] for i in ids], weights, bias))
 
+    @_resolved
     def unwrapExpanded(self, c, n):
         return self._rows(n, lambda: self.c.unwrapExpanded(c, n))
 
+    @_resolved
     def unwrapRepeatedLarge(self, cs, n):
         if self.world == 1 or n < self.min_rows:
             return self.c.unwrapRepeatedLarge(cs, n)
@@ -330,31 +473,6 @@ def _is_ct(x):
 
 def all_gather_rows_blocked(dist, transport, local, n_groups, world, group):
     """like all_gather_rows for n_groups groups of `group` consecutive rows, ownership by group"""
-    import torch
-    rank = dist.get_rank()
-    per = -(-n_groups // world) * group
-    dev = _device(dist)
-    mine = [g * group + k for g in sample_ids(n_groups, world, rank) for k in range(group)]
-    packed = [transport.pack(local[i]) for i in mine]
-    size = torch.zeros(1, dtype=torch.int64, device=dev)
-    for p, _ in packed:
-        size[0] = max(int(size[0]), int(p.numel() if hasattr(p, "numel") else p.size))
-    dist.all_reduce(size, op=dist.ReduceOp.MAX)
-    meta = torch.zeros((per, 8), dtype=torch.float64, device=dev)
-    buf = torch.zeros((per, int(size[0])), dtype=torch.uint8, device=dev)
-    for k, (p, m) in enumerate(packed):
-        meta[k] = torch.as_tensor(m, dtype=torch.float64)
-        t = p if hasattr(p, "numel") else torch.from_numpy(np.ascontiguousarray(p))
-        buf[k, : t.numel()] = t.to(dev)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    bufs = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    dist.all_gather(bufs, buf)
-    _payload_ready(dev)
-    out = [None] * (n_groups * group)
-    for r in range(world):
-        idx = [g * group + k for g in sample_ids(n_groups, world, r) for k in range(group)]
-        for k, i in enumerate(idx):
-            payload = bufs[r][k] if getattr(transport, "device", False) else bufs[r][k].cpu().numpy()
-            out[i] = transport.unpack(payload, metas[r][k].cpu().numpy())
-    return out
+    owned = [[g * group + k for g in sample_ids(n_groups, world, r) for k in range(group)] for r in range(world)]
+    got = _all_gather_indexed(dist, transport, local, owned)
+    return [got[i] for i in range(n_groups * group)]

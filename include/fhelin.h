@@ -101,6 +101,10 @@ int fhelin_ct_force(fhelin_ctx* c, const fhelin_ct* const* v, int32_t n);
 int fhelin_level_plan_begin(fhelin_ctx* c, int32_t mode);            /* 0 off, 1 record, 2 apply; resets the source counter */
 int fhelin_level_plan_seek(fhelin_ctx* c, int32_t source);           /* apply: the next source is the source-th of the program
                                                                         (a server picking up after the client's encryptions) */
+int fhelin_level_plan_tell(fhelin_ctx* c, int32_t* mode, int32_t* source);   /* the mode and the index the NEXT source call will take: a
+                                                                        driver that leaves out sources other processes run (rows and
+                                                                        bootstraps of one sample sharded over GPUs) reads the position,
+                                                                        seeks past the call it skips and back for the ones it runs */
 int fhelin_level_plan_end(fhelin_ctx* c, int32_t* n_sources);        /* record: derive the plan; back to mode 0 */
 int fhelin_level_plan_get(fhelin_ctx* c, int32_t* target, int32_t cap, int32_t* n);   /* *n = length; fills min(cap, *n) */
 int fhelin_level_plan_set(fhelin_ctx* c, const int32_t* target, int32_t n);

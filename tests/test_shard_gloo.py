@@ -71,12 +71,24 @@ def _row_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     w = pf.synthetic_model(1234)
     x_in, X_E, X_F = pf.client_inputs(w, pf.synthetic_tokens(129, 4321))
-    ctl = shard.RowShardedController(cs.SlotSimController(), dist, shard.SlotTransport())
+    calls = {}
+
+    class Counting(cs.SlotSimController):                   # which heavy single-ciphertext calls THIS rank makes
+        def bootstrap(self, c):
+            calls["bootstrap"] = calls.get("bootstrap", 0) + 1
+            return super().bootstrap(c)
+
+        def eval_gelu_function(self, c, *a, **kw):
+            calls["gelu"] = calls.get("gelu", 0) + 1
+            return super().eval_gelu_function(c, *a, **kw)
+
+    ctl = shard.RowShardedController(Counting(), dist, shard.SlotTransport())
     out = {}
     for variant in ("main", "main_2"):
         ctl.gathers = 0
         ctl.gather_rows = []
-        out[variant] = (lf.logits_from_slots(lf.forward(ctl, w, x_in, X_E, X_F, None, variant)).tolist(), ctl.gathers, list(ctl.gather_rows))
+        calls.clear()
+        out[variant] = (lf.logits_from_slots(lf.forward(ctl, w, x_in, X_E, X_F, None, variant)).tolist(), ctl.gathers, list(ctl.gather_rows), dict(calls))
     # ragged row counts through the gather itself: 5 rows over 2 ranks, 4-row groups of 3 tokens
     rows = {i: np.full(16, 10.0 * i) for i in shard.sample_ids(5, world, rank)}
     got = shard.all_gather_rows(dist, shard.SlotTransport(), rows, 5, world)
@@ -111,12 +123,17 @@ def test_rows_of_one_sample_shard_over_two_ranks():
     for variant in ("main", "main_2"):
         ref = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, x_in, X_E, X_F, None, variant))
         for rank, out, _, _ in res:
-            logits, gathers, gather_rows = out[variant]
+            logits, gathers, gather_rows, calls = out[variant]
             assert np.array_equal(np.array(logits), ref), (variant, rank)
             assert gathers >= 7                     # K/V (Q in main_2), W_O, the unwraps, the FFN matmuls: every row loop was split
             # the rows of matmulRElarge are never gathered: generate_containers takes them unread and the five GROUPS of 32 rows are
             # split over the ranks (one gather of five containers)
             assert 5 in gather_rows, gather_rows
+            # ... and they stay with their owners through the driver's GELU + bootstrap loop (src/main.cpp:354-358): 3 + 2 chains, gathered
+            # once afterwards; the two bootstraps after affine-1 (:313-314) run one per rank (a gather of 2); the pooler's single
+            # bootstrap is replicated
+            assert 2 in gather_rows, gather_rows
+            assert calls == ({"bootstrap": 1 + 3 + 1, "gelu": 3} if rank == 0 else {"bootstrap": 1 + 2 + 1, "gelu": 2}), (rank, calls)
     for _, _, rows, blk in res:
         assert rows == [0.0, 10.0, 20.0, 30.0, 40.0]
         assert blk == [100.0 * g + k for g in range(3) for k in range(4)]
