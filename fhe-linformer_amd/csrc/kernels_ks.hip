@@ -95,14 +95,15 @@ __global__ __launch_bounds__(256) void modup_conv_kernel(DeviceTables t, KsShape
 struct KsBlock {
     int bx, bi, tt;
 };
-__device__ __forceinline__ KsBlock ks_block(const KsShape& sh) {
+__device__ __forceinline__ KsBlock ks_block(const KsShape& sh, int rows = 0) {
     const unsigned nx = gridDim.x, nblk = gridDim.x * gridDim.y;
+    const unsigned nb = rows ? (unsigned)rows : (unsigned)sh.batch;   // batch rows (or row pairs) of the launch
     unsigned b = blockIdx.y * nx + blockIdx.x;
     if ((nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
     KsBlock k;
-    k.bi = (int)(b % (unsigned)sh.batch);
-    k.bx = (int)((b / (unsigned)sh.batch) % nx);
-    k.tt = (int)(b / ((unsigned)sh.batch * nx));
+    k.bi = (int)(b % nb);
+    k.bx = (int)((b / nb) % nx);
+    k.tt = (int)(b / (nb * nx));
     return k;
 }
 
@@ -191,50 +192,73 @@ __device__ __forceinline__ u32 sel_mask(u32 a, u32 b, unsigned long long mask) {
 // N/256: rotations by multiples of 64 slots at N = 2^16 - the 128 s and 512 s units of the matmul trees) and all rotations read
 // the same digits: the workgroup's beta digit tiles are loaded ONCE, coalesced, into LDS and every rotation gathers from there.
 // Without it each rotation re-gathers the tile through L2, where the key stream (112 KB per tile) keeps evicting it.
-template <bool STAGE>
+// ROWS = 2: a thread carries TWO batch rows (bi, bi + 1) of the same (limb, coefficient pair): the rows share the rotation keys, so every
+// key word is loaded once for two multiply-accumulate sets (the loop was paced by its three loads per four products); an odd
+// last row runs with its partner switched off (computed on the row's own data, not stored).
+template <bool STAGE, int ROWS>
 __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsShape sh, u64* __restrict__ accQ, u64* __restrict__ accP,
                                                              const u64* __restrict__ ext, const u64* __restrict__ c_ntt) {
-    __shared__ u64x2 dl[STAGE ? 4 : 1][256];
+    __shared__ u64x2 dl[STAGE ? ROWS : 1][STAGE ? 4 : 1][256];
     const int nt = sh.ell + sh.k;
-    const KsBlock kb_ = ks_block(sh);
-    const int bi = kb_.bi, tt = kb_.tt;
+    const KsBlock kb_ = ks_block(sh, (sh.batch + ROWS - 1) / ROWS);
+    const int bi = kb_.bi * ROWS, tt = kb_.tt;
     const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
     const size_t N = (size_t)1 << t.log_n, row = N >> 1;
-    ext += (size_t)bi * (sh.ext_batch_stride ? sh.ext_batch_stride : (size_t)sh.beta * nt * N);
-    c_ntt += (size_t)bi * sh.c_stride;
+    const size_t ext_stride = sh.ext_batch_stride ? sh.ext_batch_stride : (size_t)sh.beta * nt * N;
     const int own = tt < sh.ell ? tt / sh.alpha : -1;
-    accQ += (size_t)bi * 2 * sh.ell * N;
-    accP += (size_t)bi * 2 * sh.k * N;
     const Barrett br = load_barrett(t, limb);
     const size_t n2 = (size_t)kb_.bx * 256 + threadIdx.x;
     const size_t kstride = (size_t)(sh.L1 + sh.k) * row;  // one evk component, in u64x2 units
-    u64 lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};      // b.x, b.y, a.x, a.y
-    Acc30 b0 = {0, 0, 0}, b1 = {0, 0, 0}, a0 = {0, 0, 0}, a1 = {0, 0, 0};
+    bool live[ROWS];
+    const u64* extr[ROWS];
+    const u64* cr_[ROWS];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+        live[q] = bi + q < sh.batch;
+        const int b = live[q] ? bi + q : bi;
+        extr[q] = ext + (size_t)b * ext_stride;
+        cr_[q] = c_ntt + (size_t)b * sh.c_stride;
+    }
+    u64 lo[ROWS][4], hi[ROWS][4];      // b.x, b.y, a.x, a.y
+    Acc30 acc[ROWS][4];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lo[q][i] = hi[q][i] = 0;
+            acc[q][i] = Acc30{0, 0, 0};
+        }
     int pending = 0, folded = 0;
     if constexpr (STAGE) {
-        const u64x2* __restrict__ e0 = reinterpret_cast<const u64x2*>(ext);
-        const u64x2* __restrict__ c0 = reinterpret_cast<const u64x2*>(c_ntt);
-        for (int j = 0; j < sh.beta; ++j) dl[j][threadIdx.x] = j == own ? c0[(size_t)tt * row + n2] : e0[((size_t)j * nt + tt) * row + n2];
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
+            const u64x2* __restrict__ e0 = reinterpret_cast<const u64x2*>(extr[q]);
+            const u64x2* __restrict__ c0 = reinterpret_cast<const u64x2*>(cr_[q]);
+            for (int j = 0; j < sh.beta; ++j) dl[q][j][threadIdx.x] = j == own ? c0[(size_t)tt * row + n2] : e0[((size_t)j * nt + tt) * row + n2];
+        }
         __syncthreads();
     }
-    // The (rotation, digit) iterations form ONE software-pipelined loop: the loads of iteration i+1 (a 16-byte digit gather and two
+    // The (rotation, digit) iterations form ONE software-pipelined loop: the loads of iteration i+1 (a 16-byte digit gather per row and two
     // key words) are issued before the multiply-accumulates of iteration i, and the map entry of rotation r+1 one rotation ahead.  A wave
     // then keeps six loads in flight instead of three; with three the kernel ran at the pace of one HBM round trip per iteration
     // (152 waves per SIMD in rounds of 8 x 14 iterations x ~1.4 us = the 387 us measured in round 2).
     struct Operands {
-        u64x2 d, kb, ka;
+        u64x2 d[ROWS], kb, ka;
     };
     auto map_of = [&](int r) -> u32 { return sh.map_rot[r] ? sh.map_rot[r][2 * n2] : (u32)(2 * n2); };
     auto issue = [&](int r, int j, u32 m0) {
         const size_t mp = m0 >> 1;
         const u64x2* __restrict__ K = reinterpret_cast<const u64x2*>(sh.evk_rot[r]) + (size_t)limb * row + n2;
         Operands o;
-        if constexpr (STAGE) {
-            o.d = dl[j][mp & 255];
-        } else {
-            const u64x2* __restrict__ er = reinterpret_cast<const u64x2*>(ext + (size_t)r * sh.rot_ext_stride);
-            const u64x2* __restrict__ cr = reinterpret_cast<const u64x2*>(c_ntt + (size_t)r * sh.rot_input_stride);
-            o.d = j == own ? cr[(size_t)tt * row + mp] : er[((size_t)j * nt + tt) * row + mp];
+#pragma unroll
+        for (int q = 0; q < ROWS; ++q) {
+            if constexpr (STAGE) {
+                o.d[q] = dl[q][j][mp & 255];
+            } else {
+                const u64x2* __restrict__ er = reinterpret_cast<const u64x2*>(extr[q] + (size_t)r * sh.rot_ext_stride);
+                const u64x2* __restrict__ cr = reinterpret_cast<const u64x2*>(cr_[q] + (size_t)r * sh.rot_input_stride);
+                o.d[q] = j == own ? cr[(size_t)tt * row + mp] : er[((size_t)j * nt + tt) * row + mp];
+            }
         }
         o.kb = K[(size_t)(2 * j) * kstride];
         o.ka = K[(size_t)(2 * j + 1) * kstride];
@@ -259,35 +283,41 @@ __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsS
         }
         {
             const unsigned long long swp = __ballot((m_cur & 1) != 0);
-            const u64x2 d = cur.d, kb = cur.kb, ka = cur.ka;
-            u32 p0, p1, q0, q1;
-            split30(d.x, p0, p1);
-            split30(d.y, q0, q1);
-            // element 2m of the rotated digit is d.x, or d.y when the map sends 2m to an odd position
-            const u32 dx0 = sel_mask(p0, q0, swp), dx1 = sel_mask(p1, q1, swp), dy0 = sel_mask(q0, p0, swp), dy1 = sel_mask(q1, p1, swp);
+            const u64x2 kb = cur.kb, ka = cur.ka;
             // the key words come pre-split (pack30: low half in the low dword, high half in the high dword)
-            mac30(b0, dx0, dx1, (u32)kb.x, (u32)(kb.x >> 32));
-            mac30(b1, dy0, dy1, (u32)kb.y, (u32)(kb.y >> 32));
-            mac30(a0, dx0, dx1, (u32)ka.x, (u32)(ka.x >> 32));
-            mac30(a1, dy0, dy1, (u32)ka.y, (u32)(ka.y >> 32));
+            const u32 kbx0 = (u32)kb.x, kbx1 = (u32)(kb.x >> 32), kby0 = (u32)kb.y, kby1 = (u32)(kb.y >> 32);
+            const u32 kax0 = (u32)ka.x, kax1 = (u32)(ka.x >> 32), kay0 = (u32)ka.y, kay1 = (u32)(ka.y >> 32);
+#pragma unroll
+            for (int q = 0; q < ROWS; ++q) {
+                const u64x2 d = cur.d[q];
+                u32 p0, p1, q0, q1;
+                split30(d.x, p0, p1);
+                split30(d.y, q0, q1);
+                // element 2m of the rotated digit is d.x, or d.y when the map sends 2m to an odd position
+                const u32 dx0 = sel_mask(p0, q0, swp), dx1 = sel_mask(p1, q1, swp), dy0 = sel_mask(q0, p0, swp), dy1 = sel_mask(q1, p1, swp);
+                mac30(acc[q][0], dx0, dx1, kbx0, kbx1);
+                mac30(acc[q][1], dy0, dy1, kby0, kby1);
+                mac30(acc[q][2], dx0, dx1, kax0, kax1);
+                mac30(acc[q][3], dy0, dy1, kay0, kay1);
+            }
             if (++pending == 8) {  // at most 8 products of 60-bit halves fit the 64-bit columns
-                acc30_flush(b0, lo[0], hi[0]);
-                acc30_flush(b1, lo[1], hi[1]);
-                acc30_flush(a0, lo[2], hi[2]);
-                acc30_flush(a1, lo[3], hi[3]);
-                b0 = b1 = a0 = a1 = Acc30{0, 0, 0};
                 pending = 0;
                 // barrett_reduce128 needs a sum below q * 2^64: 16 products of operands below 2^60 (special limbs:
                 // canonical digits and keys, 16 p^2 < p * 2^64; scaling limbs: digits below 86q, 16 * 86 q^2 < q * 2^64
                 // for q < 2^53) plus one carried residue.  R * beta can reach 28 (giant steps): fold every 16.
-                if (++folded == 2) {
+                const bool fold = ++folded == 2;
+                if (fold) folded = 0;
+#pragma unroll
+                for (int q = 0; q < ROWS; ++q)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        lo[i] = barrett_reduce128(lo[i], hi[i], br);
-                        hi[i] = 0;
+                        acc30_flush(acc[q][i], lo[q][i], hi[q][i]);
+                        acc[q][i] = Acc30{0, 0, 0};
+                        if (fold) {
+                            lo[q][i] = barrett_reduce128(lo[q][i], hi[q][i], br);
+                            hi[q][i] = 0;
+                        }
                     }
-                    folded = 0;
-                }
             }
         }
         cur = nxt;
@@ -295,24 +325,26 @@ __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsS
         j = jn;
         m_cur = mn;
     }
-    acc30_flush(b0, lo[0], hi[0]);
-    acc30_flush(b1, lo[1], hi[1]);
-    acc30_flush(a0, lo[2], hi[2]);
-    acc30_flush(a1, lo[3], hi[3]);
-    u64x2 rb, ra;
-    rb.x = barrett_reduce128(lo[0], hi[0], br);
-    rb.y = barrett_reduce128(lo[1], hi[1], br);
-    ra.x = barrett_reduce128(lo[2], hi[2], br);
-    ra.y = barrett_reduce128(lo[3], hi[3], br);
-    if (tt < sh.ell) {
-        u64x2* O = reinterpret_cast<u64x2*>(accQ);
-        O[(size_t)tt * row + n2] = rb;
-        O[(size_t)(sh.ell + tt) * row + n2] = ra;
-    } else {
-        u64x2* O = reinterpret_cast<u64x2*>(accP);
-        const int pj = tt - sh.ell;
-        O[(size_t)pj * row + n2] = rb;
-        O[(size_t)(sh.k + pj) * row + n2] = ra;
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+        if (!live[q]) continue;
+        u64x2 rb, ra;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc30_flush(acc[q][i], lo[q][i], hi[q][i]);
+        rb.x = barrett_reduce128(lo[q][0], hi[q][0], br);
+        rb.y = barrett_reduce128(lo[q][1], hi[q][1], br);
+        ra.x = barrett_reduce128(lo[q][2], hi[q][2], br);
+        ra.y = barrett_reduce128(lo[q][3], hi[q][3], br);
+        if (tt < sh.ell) {
+            u64x2* O = reinterpret_cast<u64x2*>(accQ + (size_t)(bi + q) * 2 * sh.ell * N);
+            O[(size_t)tt * row + n2] = rb;
+            O[(size_t)(sh.ell + tt) * row + n2] = ra;
+        } else {
+            u64x2* O = reinterpret_cast<u64x2*>(accP + (size_t)(bi + q) * 2 * sh.k * N);
+            const int pj = tt - sh.ell;
+            O[(size_t)pj * row + n2] = rb;
+            O[(size_t)(sh.k + pj) * row + n2] = ra;
+        }
     }
 }
 
@@ -643,11 +675,21 @@ void launch_ks_inner(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* a
 }
 void launch_ks_inner_multi(const DeviceTables& t, const KsShape& sh, u64* accQ, u64* accP, const u64* ext, const u64* c_ntt,
                            hipStream_t s) {
+    static const int pair_rows = [] { const char* e = std::getenv("FHELIN_KS_ROW_PAIRS"); return e ? std::atoi(e) : 1; }();
+    const bool stage = sh.lds_digits && sh.rot_ext_stride == 0 && sh.beta <= 4;
+    if (pair_rows && sh.batch >= 2) {       // two rows per thread: the rows' key words are loaded once
+        dim3 g((1u << t.log_n) / 512, (unsigned)(((sh.batch + 1) / 2) * (sh.ell + sh.k)));
+        if (stage)
+            hipLaunchKernelGGL((ks_inner_multi_kernel<true, 2>), g, dim3(256), 0, s, t, sh, accQ, accP, ext, c_ntt);
+        else
+            hipLaunchKernelGGL((ks_inner_multi_kernel<false, 2>), g, dim3(256), 0, s, t, sh, accQ, accP, ext, c_ntt);
+        return;
+    }
     dim3 g((1u << t.log_n) / 512, (unsigned)(sh.batch * (sh.ell + sh.k)));
-    if (sh.lds_digits && sh.rot_ext_stride == 0 && sh.beta <= 4)
-        hipLaunchKernelGGL(ks_inner_multi_kernel<true>, g, dim3(256), 0, s, t, sh, accQ, accP, ext, c_ntt);
+    if (stage)
+        hipLaunchKernelGGL((ks_inner_multi_kernel<true, 1>), g, dim3(256), 0, s, t, sh, accQ, accP, ext, c_ntt);
     else
-        hipLaunchKernelGGL(ks_inner_multi_kernel<false>, g, dim3(256), 0, s, t, sh, accQ, accP, ext, c_ntt);
+        hipLaunchKernelGGL((ks_inner_multi_kernel<false, 1>), g, dim3(256), 0, s, t, sh, accQ, accP, ext, c_ntt);
 }
 void launch_gather_sum(const DeviceTables& t, const KsShape& sh, u64* out, const u64* in, size_t in_stride, hipStream_t s) {
     dim3 g((1u << t.log_n) / 256, (unsigned)(sh.batch * sh.ell));
