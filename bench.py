@@ -775,20 +775,24 @@ def main():
         alg_bytes = 16.0 * eng.N                            # read N + write N u64 per limb-NTT
         achieved = n_ntt * alg_bytes / (ntt_ms * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # PMC passes of this round's kernels (tools/profile_kernels.sh)
+        tpath = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")   # PMC passes of this round's kernels (tools/profile_kernels.sh)
+        by_counters = None
         if os.path.exists(tpath) and eng.log_n == 16:     # the counters were collected at N=2^16
             try:
                 traffic = json.load(open(tpath)).get("ntt_bytes_per_limb_transform")
+                # what the HBM counters say the transforms move per second at the rate measured in THIS run (two tile passes, each reading
+                # and writing its vectors once: twice the algorithmic bytes), as a fraction of the peak
+                by_counters = round(traffic * n_ntt / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "frac_of_peak_by_counter_traffic": by_counters,
                     "kernel": "ntt_cols_kernel + ntt_rows_kernel (one limb-NTT = one tile pass of each)",
                     "limb_ntt_per_s_per_gpu": round(n_ntt / (ntt_ms * 1e-3), 1),
                     "limb_ntt_per_s_by_batch_of_ciphertexts": by_batch,
                     "algorithmic_bytes_per_limb_ntt": alg_bytes,
-                    "traffic_source": "profiles/r03_pmc_traffic.json: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch / 384 limb vectors, measured in "
-                                      "round 3 on these kernels in separate --pmc passes (a static file: the bench run itself does not collect counters)",
+                    "traffic_source": "profiles/r04_pmc_traffic.json: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch / 768 limb vectors, measured in "
+                                      "round 4 on these kernels in separate --pmc passes (a static file: the bench run itself does not collect counters)",
                     "note": "64-bit modular-integer butterflies: bound by VALU issue slots (92 % busy; 14 instr per forward / 15 per inverse butterfly, "
                             "9 of them 32x32 multiplies); 100 % VALU utilisation at the sustained 1.6 GHz would be 2.5 M limb-NTT/s = 0.31 of the HBM roofline "
                             "(instruction-count bound in DESIGN.md 6b)"}
