@@ -89,8 +89,20 @@ std::vector<CtPtr> Evaluator::make_contiguous(const std::vector<CtPtr>& v, int s
     if (v.size() <= 1 || contiguous_base(v)) return v;
     if (site >= 0 && site < 8) gather_copies[site] += v.size();   // FHELIN_COPY_STATS=1 prints these when the context goes away
     std::vector<CtPtr> o = new_ct_batch((int)v.size(), v[0]->npoly, v[0]->ell, v[0]->deg, v[0]->scale, v[0]->slots);
-    for (size_t i = 0; i < v.size(); ++i)
-        hip_check(hipMemcpyAsync(o[i]->d, v[i]->d, v[i]->words() * 8, hipMemcpyDeviceToDevice, c_.stream), "batch gather");
+    for (size_t lo = 0; lo < v.size(); lo += EwItems::MAX_ITEMS) {   // one launch per 32 ciphertexts (a copy each costs 6.5 us in the stream)
+        EwItems it;
+        it.n = (int)std::min<size_t>(EwItems::MAX_ITEMS, v.size() - lo);
+        it.vecs = v[0]->npoly * v[0]->ell;
+        it.b_vecs = 0;
+        for (int i = 0; i < it.n; ++i) {
+            if (v[lo + i]->words() != v[0]->words()) throw Error(FHELIN_ERR_INTERNAL, "make_contiguous: operands of different shapes");
+            it.out[i] = o[lo + i]->d;
+            it.a[i] = v[lo + i]->d;
+            it.b[i] = nullptr;
+        }
+        launch_ew_items(c_.dt, it, 4, v[0]->ell, c_.stream);
+    }
+    hip_check(hipGetLastError(), "batch gather");
     return o;
 }
 

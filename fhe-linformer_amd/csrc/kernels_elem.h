@@ -46,7 +46,8 @@ void launch_reduce_i128(const DeviceTables& t, u64* out, const u64* coeffs, int 
 // ---- hybrid key switching (K6-K8)
 // Element-wise op over up to MAX_ITEMS independent operands of identical shape in ONE launch (grid.y = items x vectors):
 //   out_i[v] = a_i[v] (op) b_i[v % b_vecs]     op 0 mul, 1 add, 2 sub;   op 3: add for v < b_vecs, copy otherwise
-// (op 3 = ciphertext + plaintext: only component 0 changes).  Pointers travel in the kernel arguments.
+// (op 3 = ciphertext + plaintext: only component 0 changes); op 4: out_i = a_i (scattered ciphertexts gathered into one block by ONE
+// launch instead of a copy per ciphertext, Evaluator::make_contiguous).  Pointers travel in the kernel arguments.
 struct EwItems {
     static constexpr int MAX_ITEMS = 32;
     int n = 0;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void ew_items_kernel(DeviceTables t, EwItems i
     const size_t row = ((size_t)1 << t.log_n) >> 1;
     const u64x2 x = reinterpret_cast<const u64x2*>(it.a[item])[(size_t)v * row + n2];
     u64x2 r = x;
-    if (OP != 3 || v < it.b_vecs) {
+    if (OP != 4 && (OP != 3 || v < it.b_vecs)) {
         const u64x2 y = reinterpret_cast<const u64x2*>(it.b[item])[(size_t)(v % it.b_vecs) * row + n2];
         if (OP == 0) {
             const Barrett br = load_barrett(t, limb);
@@ -544,6 +544,7 @@ void launch_ew_items(const DeviceTables& t, const EwItems& it, int op, int limb_
         case 0: hipLaunchKernelGGL((ew_items_kernel<0>), g, dim3(256), 0, s, t, it, limb_count); break;
         case 1: hipLaunchKernelGGL((ew_items_kernel<1>), g, dim3(256), 0, s, t, it, limb_count); break;
         case 2: hipLaunchKernelGGL((ew_items_kernel<2>), g, dim3(256), 0, s, t, it, limb_count); break;
+        case 4: hipLaunchKernelGGL((ew_items_kernel<4>), g, dim3(256), 0, s, t, it, limb_count); break;
         default: hipLaunchKernelGGL((ew_items_kernel<3>), g, dim3(256), 0, s, t, it, limb_count); break;
     }
 }
