@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-level-plan", action="store_true", help="run every pass at the levels the driver asks for (no recorded level plan)")
     ap.add_argument("--throughput-batch", type=int, default=4, help="after the timed region (one sample per pass: `value`), also measure passes that "
                     "carry this many samples through the SAME engine (one key set: linformer.BatchedController); 0/1: skip")
+    ap.add_argument("--no-reference-ring", dest="reference_ring", action="store_false", help="skip the extra passes at N=2^15, the ring the reference "
+                    "is built with (reported as ms_per_sample_at_the_reference_ring_n15; `value` stays BASELINE's N=2^16)")
     ap.add_argument("--inflight", type=int, default=0, help="after the timed region (one sample in flight: `value`), also measure the "
                     "throughput with this many samples in flight on the GPU, one engine (context, stream, host thread) each; 0/1: skip")
     ap.add_argument("--forward-only", action="store_true", help="profiling runs: only the timed forward passes (no eager comparison, "
@@ -733,6 +735,54 @@ def main():
             if use_plan:
                 eng.set_level_plan(plan)
             del encs_t, outs_t
+        # ---- the same pass at the ring the reference is BUILT with (src/FHEController.cpp:12-13: SetRingDim(1 << 15), 16384 slots = full packing;
+        # BASELINE.json quotes N=2^16, which is `value`): a second engine, its own keys and level plan, a few passes after the timed region
+        fwd["n15"] = None
+        if args.reference_ring and world == 1 and not row_mode and not batched and args.log_n == 16:
+            eng.trim()
+            e15 = fa.Engine("bench", device=local_rank, seed=args.key_seed, log_n=15, n_q=n_q, n_p=n_p, special_bits=args.special_bits)
+            e15.keygen()
+            e15.gen_relin_key()
+            e15.gen_rotation_keys(fa.circuit_rotation_indices())
+            e15.bootstrap_setup(3, 3, 16384)
+            c15 = lf.GpuController(e15)
+            x15 = pf.synthetic_tokens(S, 4321)
+            n_src15 = 0
+            if use_plan:
+                e15.level_plan_begin("record")
+                enc15 = lf.encrypt_inputs(c15, *pf.client_inputs(w, pf.synthetic_tokens(S, 999)))
+                n_src15 = sum(len(v) for v in enc15.values())
+                e15.decrypt(lf.forward_encrypted(c15, w, enc15, None, args.variant))
+                e15.level_plan_end()
+                del enc15
+                e15.level_plan_begin("apply")
+            enc15 = lf.ingest_sample(c15, w, x15)
+
+            def pass15():
+                if use_plan:
+                    e15.level_plan_begin("apply", first_source=n_src15)
+                return lf.forward_encrypted(c15, w, enc15, None, args.variant)
+            lg15 = None
+            for _ in range(3):                                 # untimed: plaintext caches, the arena
+                m0 = e15.stats()["pool_malloc_calls"]
+                lg15 = lf.logits_from_slots(e15.decrypt(pass15()))
+                e15.sync()
+                if e15.stats()["pool_malloc_calls"] == m0:
+                    break
+            e15.stats(reset=True)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                e15.decrypt(pass15())
+            e15.sync()
+            ms15 = (time.perf_counter() - t1) * 1e3 / 3
+            st15 = e15.stats()
+            ref15 = lf.logits_from_slots(lf.forward(cs.SlotSimController(), w, *pf.client_inputs(w, x15), None, args.variant))
+            err15 = float(np.max(np.abs(lg15 - ref15)))
+            assert err15 < 2e-2, f"N=2^15 pass: encrypted logits differ from the circuit oracle ({err15})"
+            fwd["n15"] = {"ms_per_sample": round(ms15, 2), "limb_ntt_per_pass": st15["limb_ntt"] // 3, "logit_err_vs_circuit_oracle": round(err15, 5),
+                          "ring": "N=2^15, 16384 slots (full packing), %d+%d limbs" % (e15.n_q, e15.n_p)}
+            del enc15
+            e15.close()
         # ---- K samples in flight on the one GPU, one engine EACH (replicated keys; off by default since round 4: the batched pass above shares one key set)
         fwd["inflight"] = None
         if args.inflight > 1 and world == 1 and not row_mode:
@@ -852,6 +902,8 @@ def main():
                                       "pass, same build, same process, after the timed region"},
                            "ms_per_sample_with_4_samples_per_pass": (fwd["tb"] or {}).get("ms_per_sample") if (fwd["tb"] or {}).get("samples_per_pass") == 4 else None,
                            "throughput_with_several_samples_per_pass": fwd["tb"],
+                           "ms_per_sample_at_the_reference_ring_n15": (fwd["n15"] or {}).get("ms_per_sample"),
+                           "pass_at_the_reference_ring_n15": fwd["n15"],
                            "throughput_with_samples_in_flight": fwd["inflight"],
                            "client_ingest_ms_per_sample": round(fwd["client_ms"], 2),
                            "client_ingest_note": "fhelin_client_ingest: positional embedding, the two Linformer projections, packing, encoding and encryption of the sample's "
