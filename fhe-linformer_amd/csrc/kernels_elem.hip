@@ -9,6 +9,8 @@
 // grid = (N / 512, vectors); per-limb constants (q, Barrett ratio, Shoup scalars) are wave-uniform and come
 // in through scalar loads.  No MFMA (64-bit modular integers).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 #include "kernels_elem.h"
 
@@ -220,50 +222,90 @@ __device__ __forceinline__ void acc_flush_sh(const Acc30& a, u64& lo, u64& hi) {
     lo = t;
 }
 
-template <int O0, int SH>
+// G outputs of a segment per trip (FHELIN_WINDOW_GROUP, default 2; 4 spills): the outputs o .. o + G - 1 meet the mask m_(o - j) on the columns j, j + 1, ..,
+// j + G - 1 - ONE LDS read feeds G multiply-accumulates.  With one output per trip (rounds 3) every product had its own 8-byte LDS read: 2 MB per
+// workgroup at 128 bytes per clock is as long as the products themselves take on the four SIMDs, and the two do not overlap well at two waves per SIMD.
+#ifndef WSPLIT
+#define WSPLIT 1
+#endif
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, I1) - every index inside is a constant whatever the unroller's budget says
+// (a loop the unroller gives up on turns the register arrays below into scratch memory: measured 1.5 ms per launch instead of 0.9)
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
+
+template <int O0, int SH, int G>
 __device__ __forceinline__ void window_segment(const EwWindow& d, const Barrett& br, const u64 (&cur)[EwWindow::W], const u64 (&prv)[EwWindow::W],
                                                const u64 (*ml)[256], size_t oc) {
     constexpr int P = EwWindow::W;
 #pragma unroll 1
-    for (int oo = 0; oo < 8; ++oo) {
-        const int o = O0 + oo;
-        u64 lo = d.accumulate ? d.out[o][oc] : 0, hi = 0;
-        Acc30 x = {0, 0, 0};
-#pragma unroll
-        for (int j0 = 0; j0 < P; j0 += 8) {
-#pragma unroll
-            for (int j = j0; j < j0 + 8; ++j) {
-                u64 a, w;
-                if (j < O0) {                     // always the current window, no wrap: row o - j = oo + (O0 - j)
-                    a = cur[j];
-                    w = ml[oo + (O0 - j)][threadIdx.x];
-                } else if (j >= O0 + 8) {         // always the previous window, wrapped: row o - j + 32 = oo + (O0 - j + 32)
-                    a = prv[j];
-                    w = ml[oo + (O0 - j + P)][threadIdx.x];
-                } else {
-                    a = j <= o ? cur[j] : prv[j];
-                    w = ml[(o - j) & (P - 1)][threadIdx.x];
-                }
-                mac30(x, (u32)a, (u32)(a >> 32), (u32)w, (u32)(w >> 32));
+    for (int oo = 0; oo < 8; oo += G) {
+        u64 lo[G], hi[G];
+        Acc30 x[G][WSPLIT];   // WSPLIT independent accumulation chains per output (consecutive columns alternate)
+        static_for<0, G>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            lo[i] = d.accumulate ? d.out[O0 + oo + i][oc] : 0;
+            hi[i] = 0;
+            static_for<0, WSPLIT>([&](auto U) __attribute__((always_inline)) { x[i][decltype(U)::value] = Acc30{0, 0, 0}; });
+        });
+        static_for<0, P / 8>([&](auto J0) __attribute__((always_inline)) {
+            constexpr int j0 = 8 * decltype(J0)::value;
+            static_for<j0, j0 + 8>([&](auto J) __attribute__((always_inline)) {
+                constexpr int j = decltype(J)::value;
+                // the mask of the diagonal o - j' = O0 + oo - j (mod 32), the same for the G outputs: row oo + c, c = O0 - j
+                constexpr int c = O0 - j;
+                u64 w;
+                if constexpr (c >= 0)                  // oo + c <= (8 - G) + 24: no wrap
+                    w = ml[oo + c][threadIdx.x];
+                else if constexpr (c + (8 - G) < 0)    // below zero for every trip: wrapped
+                    w = ml[oo + c + P][threadIdx.x];
+                else
+                    w = ml[(oo + c) & (P - 1)][threadIdx.x];
+                const u32 w0 = (u32)w, w1 = (u32)(w >> 32);
+                static_for<0, G>([&](auto I) __attribute__((always_inline)) {
+                    constexpr int i = decltype(I)::value;
+                    constexpr int jj = (j + i) & (P - 1);      // the column output o = O0 + oo + i meets this mask on
+                    constexpr int e = jj - O0 - i;             // cur_jj iff jj <= o iff e <= oo
+                    u64 a;
+                    if constexpr (jj < O0 || e <= 0)
+                        a = cur[jj];
+                    else if constexpr (jj >= O0 + 8 || e > 8 - G)
+                        a = prv[jj];
+                    else
+                        a = oo >= e ? cur[jj] : prv[jj];       // wave-uniform
+                    mac30(x[i][j % WSPLIT], (u32)a, (u32)(a >> 32), w0, w1);
+                });
+            });
+            if constexpr (SH == 30) {
+                static_for<0, G>([&](auto I) __attribute__((always_inline)) {
+                    constexpr int i = decltype(I)::value;
+                    static_for<0, WSPLIT>([&](auto U) __attribute__((always_inline)) {
+                        acc_flush_sh<30>(x[i][decltype(U)::value], lo[i], hi[i]);
+                        x[i][decltype(U)::value] = Acc30{0, 0, 0};
+                    });
+                    if constexpr (j0 == 8 || j0 == 24) {   // <= 16 products (+ one carried residue) per fold: below q * 2^64 for the 60-bit limbs too
+                        lo[i] = barrett_reduce128(lo[i], hi[i], br);
+                        hi[i] = 0;
+                    }
+                });
             }
-            if (SH == 30) {
-                acc_flush_sh<30>(x, lo, hi);
-                x = Acc30{0, 0, 0};
-                if (j0 == 8 || j0 == 24) {   // <= 16 products (+ one carried residue) per fold: below q * 2^64 for the 60-bit limbs too
-                    lo = barrett_reduce128(lo, hi, br);
-                    hi = 0;
-                }
+        });
+        static_for<0, G>([&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            if constexpr (SH != 30) {
+                static_for<0, WSPLIT>([&](auto U) __attribute__((always_inline)) { acc_flush_sh<SH>(x[i][decltype(U)::value], lo[i], hi[i]); });
+                lo[i] = barrett_reduce128(lo[i], hi[i], br);
             }
-        }
-        if (SH != 30) {
-            acc_flush_sh<SH>(x, lo, hi);
-            lo = barrett_reduce128(lo, hi, br);
-        }
-        d.out[o][oc] = lo;
+            d.out[O0 + oo + i][oc] = lo[i];
+        });
     }
 }
 
-template <int SH>
+template <int SH, int G>
 __device__ __forceinline__ void window_body(const DeviceTables& t, const EwWindow& d, const Barrett& br, u64 (*ml)[256]) {
     constexpr int P = EwWindow::W;
     const int tt = blockIdx.y;
@@ -272,26 +314,41 @@ __device__ __forceinline__ void window_body(const DeviceTables& t, const EwWindo
     const size_t om = (size_t)tt * N + n, oc = (size_t)(blockIdx.z * d.ell + tt) * N + n;
 #pragma unroll
     for (int k = 0; k < P; ++k) ml[k][threadIdx.x] = pack_sh<SH>(d.m[k][om]);
+    // Segment O0 reads cur_j for j < O0 + 8 and prev_j for j >= O0: 40 of the 64 window values are live at a time when the current window
+    // arrives segment by segment (one segment ahead of its use) and the previous one drains - 80 VGPRs instead of 128, which is what lets G
+    // outputs travel together without spills.
     u64 cur[P], prv[P];
+    // an absent entry (null) counts as zero: its load goes to an address that is always valid (the first output) and the value is dropped by
+    // a wave-uniform select - 64 scalar branches around the loads cut the kernel into as many blocks and cost the allocator its view
+    auto fetch = [&](const u64* p) -> u64 {
+        const u64 v = (p ? p : d.out[0])[oc];
+        return p ? pack_sh<SH>(v) : 0;
+    };
+    auto load_cur = [&](int j0) {
 #pragma unroll
-    for (int j = 0; j < P; ++j) {
-        cur[j] = d.cur[j] ? pack_sh<SH>(d.cur[j][oc]) : 0;
-        prv[j] = d.prev[j] ? pack_sh<SH>(d.prev[j][oc]) : 0;
-    }
+        for (int j = j0; j < j0 + 8; ++j) cur[j] = fetch(d.cur[j]);
+    };
+#pragma unroll
+    for (int j = 0; j < P; ++j) prv[j] = fetch(d.prev[j]);
+    load_cur(0);
+    load_cur(8);
     // every thread reads only its own column of ml: no barrier needed (a thread sees its own LDS writes in program order)
-    window_segment<0, SH>(d, br, cur, prv, ml, oc);
-    window_segment<8, SH>(d, br, cur, prv, ml, oc);
-    window_segment<16, SH>(d, br, cur, prv, ml, oc);
-    window_segment<24, SH>(d, br, cur, prv, ml, oc);
+    window_segment<0, SH, G>(d, br, cur, prv, ml, oc);
+    load_cur(16);
+    window_segment<8, SH, G>(d, br, cur, prv, ml, oc);
+    load_cur(24);
+    window_segment<16, SH, G>(d, br, cur, prv, ml, oc);
+    window_segment<24, SH, G>(d, br, cur, prv, ml, oc);
 }
 
-__global__ __launch_bounds__(256) void ew_window_dot_kernel(DeviceTables t, EwWindow d) {
+template <int G>
+__global__ __launch_bounds__(256, 2) void ew_window_dot_kernel(DeviceTables t, EwWindow d) {
     __shared__ u64 ml[EwWindow::W][256];             // the plaintext values of this workgroup's 256 coefficients, pre-split
     const Barrett br = load_barrett(t, blockIdx.y);
     if ((br.q >> 53) == 0)                           // wave-uniform: the limb of the block
-        window_body<27>(t, d, br, ml);
+        window_body<27, G>(t, d, br, ml);
     else
-        window_body<30>(t, d, br, ml);
+        window_body<30, G>(t, d, br, ml);
 }
 
 // out[v] = acc[v] + a[v] * b[v % b_mod]
@@ -566,7 +623,13 @@ void launch_ew_cyclic_dot(const DeviceTables& t, const EwCyclic& d, hipStream_t 
 }
 void launch_ew_window_dot(const DeviceTables& t, const EwWindow& d, hipStream_t s) {
     if (d.ell <= 0) return;
-    hipLaunchKernelGGL(ew_window_dot_kernel, dim3((1u << t.log_n) / 256, (unsigned)d.ell, 2), dim3(256), 0, s, t, d);
+    static const int group = [] { const char* e = std::getenv("FHELIN_WINDOW_GROUP"); return e ? std::atoi(e) : 2; }();
+    const dim3 g((1u << t.log_n) / 256, (unsigned)d.ell, 2);
+    switch (group) {
+        case 1: hipLaunchKernelGGL(ew_window_dot_kernel<1>, g, dim3(256), 0, s, t, d); break;
+        case 4: hipLaunchKernelGGL(ew_window_dot_kernel<4>, g, dim3(256), 0, s, t, d); break;
+        default: hipLaunchKernelGGL(ew_window_dot_kernel<2>, g, dim3(256), 0, s, t, d); break;
+    }
 }
 void launch_ew_mul(const DeviceTables& t, u64* out, const u64* a, const u64* b, int nvec, int b_mod, int limb_first, int limb_count, hipStream_t s) {
     if (nvec <= 0) return;
