@@ -323,7 +323,7 @@ __device__ __forceinline__ void cols_body(const NttArgs& a, u64* lds, int vec, i
 }
 
 template <int A, bool INVERSE, bool LIFT = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void ntt_cols_kernel(NttArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LIFT ? 3 : 4))) void ntt_cols_kernel(NttArgs a) {
     constexpr int LOGTILES = A - 4;
     __shared__ u64 lds[LDS_WORDS];
     const int vec = a.vec0 + (blockIdx.x >> LOGTILES);
