@@ -1406,8 +1406,10 @@ bool Evaluator::dot_plain_window(const std::vector<CtPtr>& cur, const std::vecto
     for (int j = 0; j < W; ++j) {
         hold.push_back(pts[j]->at(f->ell, sf));
         d.m[j] = hold.back()->d;
-        d.cur[j] = cur[j] ? cur[j]->d : nullptr;
-        d.prev[j] = prev[j] ? prev[j]->d : nullptr;
+        d.cur[j] = cur[j] ? cur[j]->d : dest[0]->d;      // absent: any readable block of the operands' shape, dropped by the mask
+        d.prev[j] = prev[j] ? prev[j]->d : dest[0]->d;
+        if (cur[j]) d.cur_mask |= 1u << j;
+        if (prev[j]) d.prev_mask |= 1u << j;
         d.out[j] = dest[j]->d;
         dest[j]->deg = f->deg + 1;
         dest[j]->scale = f->scale * sf;

@@ -78,6 +78,7 @@ struct EwDotGroups {
     int nbatch = 1;
     size_t a_stride[MAX_A] = {};
     size_t out_stride[MAX_G] = {};
+    u32 pmask[MAX_G] = {};       // filled by launch_ew_dot_groups: bit b of pmask[g] = term (g, b) present
 };
 void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& d, hipStream_t s);
 // The 32 CYCLIC plaintext-weighted sums over n <= 32 ciphertexts of one shape (Composite::relarge_container):
@@ -97,10 +98,11 @@ void launch_ew_cyclic_dot(const DeviceTables& t, const EwCyclic& d, hipStream_t 
 //     out_t (+)= sum_{j<32} (j <= t ? cur_j : prev_j) * m_{(t - j) mod 32},   t < 32
 // cur_j = D_{p+j}, prev_j = D_{p-32+j} for the block's window position p: the pairs (i, k) = (32 g + t, 32 c + k') of one output
 // block g and one tap chunk c.  Same structure as launch_ew_cyclic_dot (plaintext values in LDS, ciphertext values in registers,
-// both pre-split); a null cur / prev entry counts as zero; accumulate: out_t already holds the sum of earlier tap chunks.
+// both pre-split); an entry whose mask bit is clear counts as zero; accumulate: out_t already holds the sum of earlier tap chunks.
 struct EwWindow {
     static constexpr int W = 32;
     int ell = 0, accumulate = 0;
+    u32 cur_mask = 0, prev_mask = 0;   // bit j: cur[j] / prev[j] is present; an absent entry still points at readable memory of the operands' shape
     const u64* cur[W];
     const u64* prev[W];
     const u64* m[W];

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void ew_dot_kernel(DeviceTables t, u64* out, E
 // only in c read the same plaintext tile: in XCD-aware order (logical id = (tt, tile, c), c fastest, contiguous id ranges per
 // XCD) they run back to back on one XCD and the second finds the tile in L2.
 template <int NA>
-__global__ __launch_bounds__(256) void ew_dot_groups_kernel(DeviceTables t, EwDotGroups d) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NA <= 8 ? 4 : 3))) void ew_dot_groups_kernel(DeviceTables t, EwDotGroups d) {
     const unsigned nx = gridDim.x, nblk = gridDim.x * gridDim.y;
     unsigned id = blockIdx.y * nx + blockIdx.x;
     if ((nblk & 7) == 0) id = (id & 7) * (nblk >> 3) + (id >> 3);
@@ -117,23 +117,56 @@ __global__ __launch_bounds__(256) void ew_dot_groups_kernel(DeviceTables t, EwDo
     const size_t n2 = (size_t)bx * 256 + threadIdx.x;
     const size_t row = ((size_t)1 << t.log_n) >> 1;
     const size_t op = (size_t)tt * row + n2, oc = (size_t)(comp * d.ell + tt) * row + n2;
+    // Every pointer of the struct is readable (launch_ew_dot_groups pads absent terms and the columns up to NA; pmask says which count): the NA
+    // plaintext loads of a group go out back to back, and for NA <= 8 the next group's are in flight while this group's products are formed.
+    // With a null test per term the compiler put a full wait behind every plaintext load - NA serial round trips per group.
     u64x2 a[NA];
 #pragma unroll
-    for (int b = 0; b < NA; ++b)
-        if (b < d.na) a[b] = reinterpret_cast<const u64x2*>(d.a[b] + (size_t)xb * d.a_stride[b])[oc];
-    for (int g = 0; g < d.ng; ++g) {
-        Acc128 x = {0, 0}, y = {0, 0};
+    for (int b = 0; b < NA; ++b) a[b] = reinterpret_cast<const u64x2*>(d.a[b] + (size_t)xb * d.a_stride[b])[oc];
+    if constexpr (NA <= 8) {
+        u64x2 w[NA], wn[NA];
 #pragma unroll
-        for (int b = 0; b < NA; ++b)
-            if (b < d.na && d.p[g][b]) {
-                const u64x2 w = reinterpret_cast<const u64x2*>(d.p[g][b])[op];
-                acc_mac(x, a[b].x, w.x);
-                acc_mac(y, a[b].y, w.y);
+        for (int b = 0; b < NA; ++b) w[b] = reinterpret_cast<const u64x2*>(d.p[0][b])[op];
+        for (int g = 0; g < d.ng; ++g) {
+            const int gn = g + 1 < d.ng ? g + 1 : g;
+#pragma unroll
+            for (int b = 0; b < NA; ++b) wn[b] = reinterpret_cast<const u64x2*>(d.p[gn][b])[op];
+            Acc128 x = {0, 0}, y = {0, 0};
+            const u32 m = d.pmask[g];
+#pragma unroll
+            for (int b = 0; b < NA; ++b)
+                if (m >> b & 1u) {
+                    acc_mac(x, a[b].x, w[b].x);
+                    acc_mac(y, a[b].y, w[b].y);
+                }
+            u64x2 r;
+            r.x = barrett_reduce128(x.lo, x.hi, br);
+            r.y = barrett_reduce128(y.lo, y.hi, br);
+            reinterpret_cast<u64x2*>(d.out[g] + (size_t)xb * d.out_stride[g])[oc] = r;
+#pragma unroll
+            for (int b = 0; b < NA; ++b) w[b] = wn[b];
+        }
+    } else {   // 16 columns: the plaintexts of a group in two batches of eight (the 16 ciphertext pairs already hold 64 registers)
+        for (int g = 0; g < d.ng; ++g) {
+            Acc128 x = {0, 0}, y = {0, 0};
+            const u32 m = d.pmask[g];
+#pragma unroll
+            for (int b0 = 0; b0 < NA; b0 += 8) {
+                u64x2 w[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) w[b] = reinterpret_cast<const u64x2*>(d.p[g][b0 + b])[op];
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (m >> (b0 + b) & 1u) {
+                        acc_mac(x, a[b0 + b].x, w[b].x);
+                        acc_mac(y, a[b0 + b].y, w[b].y);
+                    }
             }
-        u64x2 r;
-        r.x = barrett_reduce128(x.lo, x.hi, br);
-        r.y = barrett_reduce128(y.lo, y.hi, br);
-        reinterpret_cast<u64x2*>(d.out[g] + (size_t)xb * d.out_stride[g])[oc] = r;
+            u64x2 r;
+            r.x = barrett_reduce128(x.lo, x.hi, br);
+            r.y = barrett_reduce128(y.lo, y.hi, br);
+            reinterpret_cast<u64x2*>(d.out[g] + (size_t)xb * d.out_stride[g])[oc] = r;
+        }
     }
 }
 
@@ -238,9 +271,12 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// `pre`: the sums of earlier tap chunks for the NEXT trip's outputs, fetched one trip ahead.  On gfx9 one counter orders loads AND stores: a load
+// issued after a trip's stores is only known complete once those stores are acknowledged, so fetching the running sums at the top of their own
+// trip made every trip wait for a store round trip and a load round trip (SQ_WAIT_ANY: 65 % of a wave's life at two waves per SIMD).
 template <int O0, int SH, int G>
 __device__ __forceinline__ void window_segment(const EwWindow& d, const Barrett& br, const u64 (&cur)[EwWindow::W], const u64 (&prv)[EwWindow::W],
-                                               const u64 (*ml)[256], size_t oc) {
+                                               const u64 (*ml)[256], size_t oc, u64 (&pre)[G]) {
     constexpr int P = EwWindow::W;
 #pragma unroll 1
     for (int oo = 0; oo < 8; oo += G) {
@@ -248,10 +284,13 @@ __device__ __forceinline__ void window_segment(const EwWindow& d, const Barrett&
         Acc30 x[G][WSPLIT];   // WSPLIT independent accumulation chains per output (consecutive columns alternate)
         static_for<0, G>([&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
-            lo[i] = d.accumulate ? d.out[O0 + oo + i][oc] : 0;
+            lo[i] = pre[i];
             hi[i] = 0;
             static_for<0, WSPLIT>([&](auto U) __attribute__((always_inline)) { x[i][decltype(U)::value] = Acc30{0, 0, 0}; });
         });
+        if (d.accumulate && O0 + oo + G < P) {
+            static_for<0, G>([&](auto I) __attribute__((always_inline)) { pre[decltype(I)::value] = d.out[O0 + oo + G + decltype(I)::value][oc]; });
+        }
         static_for<0, P / 8>([&](auto J0) __attribute__((always_inline)) {
             constexpr int j0 = 8 * decltype(J0)::value;
             static_for<j0, j0 + 8>([&](auto J) __attribute__((always_inline)) {
@@ -312,33 +351,42 @@ __device__ __forceinline__ void window_body(const DeviceTables& t, const EwWindo
     const size_t N = (size_t)1 << t.log_n;
     const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t om = (size_t)tt * N + n, oc = (size_t)(blockIdx.z * d.ell + tt) * N + n;
+    // The prologue's 96 loads go out back to back (every entry of the struct is a valid pointer - the host points absent ones at the first
+    // output - and the masks say which values count): with a null test per entry the compiler put a branch and a full wait between two loads,
+    // 96 serial round trips per thread - two thirds of a wave's life (SQ_WAIT_ANY, profiles/r04_bc_*).
+    {
+        u64 mv[P];
 #pragma unroll
-    for (int k = 0; k < P; ++k) ml[k][threadIdx.x] = pack_sh<SH>(d.m[k][om]);
+        for (int k = 0; k < P; ++k) mv[k] = d.m[k][om];
+#pragma unroll
+        for (int k = 0; k < P; ++k) ml[k][threadIdx.x] = pack_sh<SH>(mv[k]);
+    }
     // Segment O0 reads cur_j for j < O0 + 8 and prev_j for j >= O0: 40 of the 64 window values are live at a time when the current window
     // arrives segment by segment (one segment ahead of its use) and the previous one drains - 80 VGPRs instead of 128, which is what lets G
     // outputs travel together without spills.
     u64 cur[P], prv[P];
-    // an absent entry (null) counts as zero: its load goes to an address that is always valid (the first output) and the value is dropped by
-    // a wave-uniform select - 64 scalar branches around the loads cut the kernel into as many blocks and cost the allocator its view
-    auto fetch = [&](const u64* p) -> u64 {
-        const u64 v = (p ? p : d.out[0])[oc];
-        return p ? pack_sh<SH>(v) : 0;
-    };
     auto load_cur = [&](int j0) {
 #pragma unroll
-        for (int j = j0; j < j0 + 8; ++j) cur[j] = fetch(d.cur[j]);
+        for (int j = j0; j < j0 + 8; ++j) cur[j] = d.cur[j][oc];
+#pragma unroll
+        for (int j = j0; j < j0 + 8; ++j) cur[j] = (d.cur_mask >> j & 1u) ? pack_sh<SH>(cur[j]) : 0;
     };
 #pragma unroll
-    for (int j = 0; j < P; ++j) prv[j] = fetch(d.prev[j]);
+    for (int j = 0; j < P; ++j) prv[j] = d.prev[j][oc];
+#pragma unroll
+    for (int j = 0; j < P; ++j) prv[j] = (d.prev_mask >> j & 1u) ? pack_sh<SH>(prv[j]) : 0;
     load_cur(0);
     load_cur(8);
+    u64 pre[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) pre[i] = d.accumulate ? d.out[i][oc] : 0;
     // every thread reads only its own column of ml: no barrier needed (a thread sees its own LDS writes in program order)
-    window_segment<0, SH, G>(d, br, cur, prv, ml, oc);
+    window_segment<0, SH, G>(d, br, cur, prv, ml, oc, pre);
     load_cur(16);
-    window_segment<8, SH, G>(d, br, cur, prv, ml, oc);
+    window_segment<8, SH, G>(d, br, cur, prv, ml, oc, pre);
     load_cur(24);
-    window_segment<16, SH, G>(d, br, cur, prv, ml, oc);
-    window_segment<24, SH, G>(d, br, cur, prv, ml, oc);
+    window_segment<16, SH, G>(d, br, cur, prv, ml, oc, pre);
+    window_segment<24, SH, G>(d, br, cur, prv, ml, oc, pre);
 }
 
 template <int G>
@@ -609,8 +657,32 @@ void launch_ew_dot(const DeviceTables& t, u64* out, const EwItems& it, int limb_
     if (it.n <= 0 || it.vecs <= 0) return;
     hipLaunchKernelGGL(ew_dot_kernel, grid2(t.log_n, it.vecs), dim3(256), 0, s, t, out, it, limb_count);
 }
-void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& d, hipStream_t s) {
-    if (d.na <= 0 || d.ng <= 0 || d.ell <= 0) return;
+void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& din, hipStream_t s) {
+    if (din.na <= 0 || din.ng <= 0 || din.ell <= 0) return;
+    // the kernel reads through every pointer of the columns it is instantiated for: absent terms (null) and the columns beyond na point at
+    // readable memory of the right shape and are left out through pmask
+    EwDotGroups d = din;
+    const int width = d.na <= 8 ? 8 : EwDotGroups::MAX_A;
+    const u64* any = d.a[0];                       // [2][ell][N]: readable at every plaintext offset
+    for (int g = 0; g < d.ng && any == d.a[0]; ++g)
+        for (int b = 0; b < d.na; ++b)
+            if (d.p[g][b]) {
+                any = d.p[g][b];
+                break;
+            }
+    for (int b = d.na; b < width; ++b) {
+        d.a[b] = d.a[0];
+        d.a_stride[b] = d.a_stride[0];
+    }
+    for (int g = 0; g < d.ng; ++g) {
+        d.pmask[g] = 0;
+        for (int b = 0; b < width; ++b) {
+            if (b < d.na && d.p[g][b])
+                d.pmask[g] |= 1u << b;
+            else
+                d.p[g][b] = any;
+        }
+    }
     const int nb = d.nbatch > 0 ? d.nbatch : 1;
     if (d.na <= 8)
         hipLaunchKernelGGL((ew_dot_groups_kernel<8>), grid2(t.log_n, 2 * d.ell * nb), dim3(256), 0, s, t, d);
