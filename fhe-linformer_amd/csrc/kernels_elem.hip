@@ -170,68 +170,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NA <= 8 ? 4
     }
 }
 
-// grid (N/256, ell, 2 components): one coefficient per thread.  SH: see pack_sh below (limbs under 2^53 take one flush per output)
-template <int SH>
-__device__ __forceinline__ u64 cyc_pack(u64 x) { return (x & ((1ull << SH) - 1)) | ((x >> SH) << 32); }
-template <int SH>
-__device__ __forceinline__ void cyclic_body(const DeviceTables& t, const EwCyclic& d, const Barrett& br, u64 (*ml)[256]) {
-    constexpr int P = EwCyclic::PERIOD;
-    const int tt = blockIdx.y;
-    const size_t N = (size_t)1 << t.log_n;
-    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t om = (size_t)tt * N + n, oc = (size_t)(blockIdx.z * d.ell + tt) * N + n;
-#pragma unroll
-    for (int j = 0; j < P; ++j) ml[j][threadIdx.x] = cyc_pack<SH>(d.m[j][om]);
-    u64 a[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) a[i] = i < d.n ? cyc_pack<SH>(d.a[i][oc]) : 0;
-    // every thread reads only its own column of ml: no barrier needed (a thread sees its own LDS writes in program order)
-#pragma unroll 1
-    for (int k = 0; k < P; ++k) {
-        u64 lo = 0, hi = 0;
-        Acc30 x = {0, 0, 0};
-#pragma unroll
-        for (int i0 = 0; i0 < P; i0 += 8) {
-            if (i0 < d.n) {
-#pragma unroll
-                for (int i = i0; i < i0 + 8; ++i) {
-                    const u64 w = ml[(i + k) & (P - 1)][threadIdx.x];
-                    mac30(x, (u32)a[i], (u32)(a[i] >> 32), (u32)w, (u32)(w >> 32));
-                }
-                if (SH == 30) {
-                    acc30_flush(x, lo, hi);
-                    x = Acc30{0, 0, 0};
-                    if (i0 == 8) {   // 16 products so far: fold, so that the final 128-bit value stays below q * 2^64 for 60-bit limbs too
-                        lo = barrett_reduce128(lo, hi, br);
-                        hi = 0;
-                    }
-                }
-            }
-        }
-        if (SH != 30) {              // all products below 2^54: one accumulator, one flush
-            u64 tq = lo + x.s0;
-            hi += (tq < lo);
-            lo = tq;
-            tq = lo + (x.s1 << SH);
-            hi += (x.s1 >> (64 - SH)) + (tq < lo);
-            lo = tq;
-            tq = lo + (x.s2 << (2 * SH));
-            hi += (x.s2 >> (64 - 2 * SH)) + (tq < lo);
-            lo = tq;
-        }
-        d.out[k][oc] = barrett_reduce128(lo, hi, br);
-    }
-}
-
-__global__ __launch_bounds__(256) void ew_cyclic_dot_kernel(DeviceTables t, EwCyclic d) {
-    __shared__ u64 ml[EwCyclic::PERIOD][256];        // the plaintext values of this workgroup's 256 coefficients, pre-split
-    const Barrett br = load_barrett(t, blockIdx.y);
-    if ((br.q >> 53) == 0)                           // wave-uniform: the limb of the block
-        cyclic_body<27>(t, d, br, ml);
-    else
-        cyclic_body<30>(t, d, br, ml);
-}
-
 // grid (N/256, ell, 2 components): one coefficient per thread.  The plaintext values sit in LDS (a dynamically indexed register file:
 // every thread reads its own column), the two ciphertext windows in registers, all pre-split in 30-bit halves.  The outputs are
 // walked in four segments of eight (template parameter O0): inside a segment the operand of column j is cur_j for j < O0 and prev_j
@@ -269,6 +207,84 @@ __device__ __forceinline__ void static_for(F&& f) {
         f(std::integral_constant<int, I0>{});
         static_for<I0 + 1, I1>(f);
     }
+}
+
+// The 32 cyclic sums out_k = sum_i a_i * m_((i + k) mod 32): grid (N/256, ell, 2 components), one coefficient per thread, the plaintext
+// values in LDS, the ciphertext values in registers, both pre-split (SH as above).  Two outputs per trip: output k meets the mask of row i + k on
+// column i, output k + 1 on column i - 1 - ONE LDS read feeds both products; the prologue's 64 loads go out back to back (every a[] entry is a
+// readable pointer: launch_ew_cyclic_dot points the ones beyond n at the first, their values are dropped by a wave-uniform select).
+template <int SH>
+__device__ __forceinline__ void cyclic_body(const DeviceTables& t, const EwCyclic& d, const Barrett& br, u64 (*ml)[256]) {
+    constexpr int P = EwCyclic::PERIOD, G = 2;
+    const int tt = blockIdx.y;
+    const size_t N = (size_t)1 << t.log_n;
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t oc = (size_t)(blockIdx.z * d.ell + tt) * N + n;
+    // byte offsets below 4 GB (2 ell N words): loads take the scalar base + 32-bit lane offset form - no 64-bit address pair per load
+    const u32 bm = (u32)(((size_t)tt * N + n) * 8), bc = (u32)(oc * 8);
+    auto ld = [](const u64* p, u32 byte_off) -> u64 { return *reinterpret_cast<const u64*>(reinterpret_cast<const char*>(p) + byte_off); };
+    {
+        u64 mv[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) mv[j] = ld(d.m[j], bm);
+#pragma unroll
+        for (int j = 0; j < P; ++j) ml[j][threadIdx.x] = pack_sh<SH>(mv[j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // the masks' registers are free before the ciphertext values arrive
+    u64 a[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) a[i] = ld(d.a[i], bc);
+#pragma unroll
+    for (int i = 0; i < P; ++i) a[i] = i < d.n ? pack_sh<SH>(a[i]) : 0;
+    // every thread reads only its own column of ml: no barrier needed (a thread sees its own LDS writes in program order)
+#pragma unroll 1
+    for (int k = 0; k < P; k += G) {
+        u64 lo[G], hi[G];
+        Acc30 x[G];
+        static_for<0, G>([&](auto I) __attribute__((always_inline)) {
+            lo[decltype(I)::value] = hi[decltype(I)::value] = 0;
+            x[decltype(I)::value] = Acc30{0, 0, 0};
+        });
+        static_for<0, P / 8>([&](auto I0) __attribute__((always_inline)) {
+            constexpr int i0 = 8 * decltype(I0)::value;
+            static_for<i0, i0 + 8>([&](auto I) __attribute__((always_inline)) {
+                constexpr int i = decltype(I)::value;
+                const u64 w = ml[(i + k) & (P - 1)][threadIdx.x];
+                const u32 w0 = (u32)w, w1 = (u32)(w >> 32);
+                static_for<0, G>([&](auto Gi) __attribute__((always_inline)) {
+                    constexpr int g = decltype(Gi)::value;
+                    constexpr int ii = (i - g) & (P - 1);          // (ii + k + g) mod 32 = (i + k) mod 32
+                    mac30(x[g], (u32)a[ii], (u32)(a[ii] >> 32), w0, w1);
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);   // LDS reads of later chunks stay where they are (hoisted, they cost the registers two outputs need)
+            if constexpr (SH == 30) {
+                static_for<0, G>([&](auto Gi) __attribute__((always_inline)) {
+                    constexpr int g = decltype(Gi)::value;
+                    acc_flush_sh<30>(x[g], lo[g], hi[g]);
+                    x[g] = Acc30{0, 0, 0};
+                    if constexpr (i0 == 8) {   // 16 products so far: fold, so that the final 128-bit value stays below q * 2^64 for 60-bit limbs too
+                        lo[g] = barrett_reduce128(lo[g], hi[g], br);
+                        hi[g] = 0;
+                    }
+                });
+            }
+        });
+        static_for<0, G>([&](auto Gi) __attribute__((always_inline)) {
+            constexpr int g = decltype(Gi)::value;
+            if constexpr (SH != 30) acc_flush_sh<SH>(x[g], lo[g], hi[g]);   // all products below 2^54: one accumulator, one flush
+            d.out[k + g][oc] = barrett_reduce128(lo[g], hi[g], br);
+        });
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void ew_cyclic_dot_kernel(DeviceTables t, EwCyclic d) {
+    __shared__ u64 ml[EwCyclic::PERIOD][256];        // the plaintext values of this workgroup's 256 coefficients, pre-split
+    const Barrett br = load_barrett(t, blockIdx.y);
+    if ((br.q >> 53) == 0)                           // wave-uniform: the limb of the block
+        cyclic_body<27>(t, d, br, ml);
+    else
+        cyclic_body<30>(t, d, br, ml);
 }
 
 // `pre`: the sums of earlier tap chunks for the NEXT trip's outputs, fetched one trip ahead.  On gfx9 one counter orders loads AND stores: a load
@@ -689,8 +705,10 @@ void launch_ew_dot_groups(const DeviceTables& t, const EwDotGroups& din, hipStre
     else
         hipLaunchKernelGGL((ew_dot_groups_kernel<16>), grid2(t.log_n, 2 * d.ell * nb), dim3(256), 0, s, t, d);
 }
-void launch_ew_cyclic_dot(const DeviceTables& t, const EwCyclic& d, hipStream_t s) {
-    if (d.n <= 0 || d.ell <= 0) return;
+void launch_ew_cyclic_dot(const DeviceTables& t, const EwCyclic& din, hipStream_t s) {
+    if (din.n <= 0 || din.ell <= 0) return;
+    EwCyclic d = din;
+    for (int i = d.n; i < EwCyclic::PERIOD; ++i) d.a[i] = d.a[0];   // the kernel loads through all 32 entries and drops the ones beyond n
     hipLaunchKernelGGL(ew_cyclic_dot_kernel, dim3((1u << t.log_n) / 256, (unsigned)d.ell, 2), dim3(256), 0, s, t, d);
 }
 void launch_ew_window_dot(const DeviceTables& t, const EwWindow& d, hipStream_t s) {
