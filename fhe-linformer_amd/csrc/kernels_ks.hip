@@ -39,20 +39,14 @@ __device__ __forceinline__ void modup_body(const DeviceTables& t, const KsShape&
     const size_t N = (size_t)1 << t.log_n;
     const int nt = sh.ell + sh.k;
     u32 y0[MAXA], y1[MAXA];  // y_i = [c_i * (Q_j/q_i)^{-1}]_{q_i}, split in 30-bit halves
-    // the shorter last digit reads MAXA sources too - the missing ones are the digit's last limb again, zeroed by a wave-uniform select: its
-    // loads go out back to back like the full digits' (a test per source put a branch and a full wait behind every load) and its products
-    // run the unguarded loops below with zero operands
-    u64 src[MAXA];
 #pragma unroll
     for (int i = 0; i < MAXA; ++i) {
-        const int li = FULL ? lo + i : lo + (i < cnt ? i : cnt - 1);
-        src[i] = cc[(size_t)li * N + n];
-    }
-#pragma unroll
-    for (int i = 0; i < MAXA; ++i) {
-        const int li = FULL ? lo + i : lo + (i < cnt ? i : cnt - 1);
-        const u64 y = mul_shoup(src[i], hatinv[2 * li], hatinv[2 * li + 1], t.moduli[li]);
-        split30((FULL || i < cnt) ? y : 0, y0[i], y1[i]);
+        if (FULL || i < cnt) {
+            const int li = lo + i;
+            split30(mul_shoup(cc[(size_t)li * N + n], hatinv[2 * li], hatinv[2 * li + 1], t.moduli[li]), y0[i], y1[i]);
+        } else {
+            y0[i] = y1[i] = 0;
+        }
     }
     u64* dst = ext + (size_t)j * nt * N + n;
     const int t0 = blockIdx.z * sh.tch, t1 = min(nt, t0 + sh.tch);
@@ -65,11 +59,11 @@ __device__ __forceinline__ void modup_body(const DeviceTables& t, const KsShape&
         for (int i0 = 0; i0 < MAXA; i0 += 8) {
             Acc30 acc = {0, 0, 0};
 #pragma unroll
-            for (int i = i0; i < i0 + 8 && i < MAXA; ++i) {
-                const int li = FULL ? lo + i : lo + (i < cnt ? i : cnt - 1);   // absent source: a valid table row, times zero
-                const u64 h = hatmod[(size_t)li * nt + tt];  // pre-split on the host (pack30)
-                mac30(acc, y0[i], y1[i], (u32)h, (u32)(h >> 32));
-            }
+            for (int i = i0; i < i0 + 8 && i < MAXA; ++i)
+                if (FULL || i < cnt) {
+                    const u64 h = hatmod[(size_t)(lo + i) * nt + tt];  // pre-split on the host (pack30)
+                    mac30(acc, y0[i], y1[i], (u32)h, (u32)(h >> 32));
+                }
             acc30_flush(acc, slo, shi);
         }
         dst[(size_t)tt * N] = barrett_reduce128(slo, shi, br);
