@@ -89,6 +89,16 @@ def _row_worker(rank, world, port, q):
         ctl.gather_rows = []
         calls.clear()
         out[variant] = (lf.logits_from_slots(lf.forward(ctl, w, x_in, X_E, X_F, None, variant)).tolist(), ctl.gathers, list(ctl.gather_rows), dict(calls))
+    # a chain somebody still reads after a longer chain took its place is evaluated by itself; three independent chains are split 2 + 1
+    plain = cs.SlotSimController()
+    vals = [np.linspace(-0.5, 0.5, 64) * (k + 1) for k in range(3)]
+    b = [ctl.bootstrap(v) for v in vals]
+    g = [ctl.eval_gelu_function(x, -1, 1, 0.125, 119) for x in b]
+    want_g = [plain.eval_gelu_function(plain.bootstrap(v), -1, 1, 0.125, 119) for v in vals]
+    got_g = [np.asarray(ctl._res(x)) for x in g]
+    got_b = [np.asarray(ctl._res(x)) for x in b]               # superseded handles, read afterwards
+    chains_ok = all(np.array_equal(a, w_) for a, w_ in zip(got_g, want_g)) and all(np.array_equal(a, plain.bootstrap(v)) for a, v in zip(got_b, vals))
+    out["chains"] = (bool(chains_ok), 3 in ctl.gather_rows)
     # ragged row counts through the gather itself: 5 rows over 2 ranks, 4-row groups of 3 tokens
     rows = {i: np.full(16, 10.0 * i) for i in shard.sample_ids(5, world, rank)}
     got = shard.all_gather_rows(dist, shard.SlotTransport(), rows, 5, world)
@@ -134,6 +144,7 @@ def test_rows_of_one_sample_shard_over_two_ranks():
             # bootstrap is replicated
             assert 2 in gather_rows, gather_rows
             assert calls == ({"bootstrap": 1 + 3 + 1, "gelu": 3} if rank == 0 else {"bootstrap": 1 + 2 + 1, "gelu": 2}), (rank, calls)
-    for _, _, rows, blk in res:
+    for _, out, rows, blk in res:
+        assert out["chains"] == (True, True), out["chains"]
         assert rows == [0.0, 10.0, 20.0, 30.0, 40.0]
         assert blk == [100.0 * g + k for g in range(3) for k in range(4)]
