@@ -229,6 +229,8 @@ template const int* Context::upload_table<int>(const std::vector<int>&);
 template const u32* Context::upload_table<u32>(const std::vector<u32>&);
 template const double* Context::upload_table<double>(const std::vector<double>&);
 
+static u64 mont_r(u64 m) { return (u64)((((u128)1) << 64) % m); }   // 2^64 mod m
+
 static u64 prod_mod(const std::vector<u64>& ms, int skip, u64 t) {
     u64 r = 1 % t;
     for (int i = 0; i < (int)ms.size(); ++i)
@@ -361,6 +363,15 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
         dt.n_limbs = nl;
         dt.moduli = upload_table(moduli);
         dt.barrett = upload_table(bar);
+        {
+            std::vector<u64> qi(nl);
+            for (int i = 0; i < nl; ++i) {
+                u64 x = moduli[i];                       // Newton: x <- x (2 - q x), correct bits double (q odd: q * q = 1 mod 8)
+                for (int it = 0; it < 6; ++it) x *= 2 - moduli[i] * x;
+                qi[i] = x;
+            }
+            dt.qinv = upload_table(qi);
+        }
         dt.ninv = upload_table(ninv);
         std::vector<u64> f((size_t)nl * 2 * N), g((size_t)nl * 2 * N);
         for (int i = 0; i < nl; ++i) {
@@ -399,7 +410,8 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
             u64 inv = h_invmod(hat, pj);
             phatinv[2 * j] = inv;
             phatinv[2 * j + 1] = h_shoup(inv, pj);
-            for (int t = 0; t <= L; ++t) phatmod[(size_t)j * (L + 1) + t] = pack30(prod_mod(chain.p, j, chain.q[t]));  // 30-bit halves
+            // times 2^64 mod q_t: the conversion kernels finish their sums with a Montgomery reduction (modarith.h redc128)
+            for (int t = 0; t <= L; ++t) phatmod[(size_t)j * (L + 1) + t] = pack30(h_mulmod(prod_mod(chain.p, j, chain.q[t]), mont_r(chain.q[t]), chain.q[t]));  // 30-bit halves
         }
         for (int t = 0; t <= L; ++t) {
             u64 qt = chain.q[t];
@@ -449,7 +461,7 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
                 hatinv[2 * i + 1] = h_shoup(inv, qi);
                 for (int t = 0; t < nt; ++t) {
                     u64 mt = t < ell ? chain.q[t] : chain.p[t - ell];
-                    hatmod[(size_t)i * nt + t] = pack30(prod_mod(dig, i - lo, mt));  // 30-bit halves for mac30
+                    hatmod[(size_t)i * nt + t] = pack30(h_mulmod(prod_mod(dig, i - lo, mt), mont_r(mt), mt));  // times 2^64 mod m_t (redc128); 30-bit halves for mac30
                 }
             }
             for (int t = 0; t < nt; ++t) {

@@ -53,7 +53,7 @@ __device__ __forceinline__ void modup_body(const DeviceTables& t, const KsShape&
     for (int tt = t0; tt < t1; ++tt) {
         if (tt >= lo && tt < lo + cnt) continue;  // own-digit slots: the inner product reads c (NTT form) directly
         const int limb = tt < sh.ell ? tt : sh.L1 + (tt - sh.ell);
-        const Barrett br = load_barrett(t, limb);
+        const u64 qt = t.moduli[limb], qti = t.qinv[limb];
         u64 slo = 0, shi = 0;
 #pragma unroll
         for (int i0 = 0; i0 < MAXA; i0 += 8) {
@@ -66,7 +66,7 @@ __device__ __forceinline__ void modup_body(const DeviceTables& t, const KsShape&
                 }
             acc30_flush(acc, slo, shi);
         }
-        dst[(size_t)tt * N] = barrett_reduce128(slo, shi, br);
+        dst[(size_t)tt * N] = redc128(slo, shi, qt, qti);   // hatmod holds the constants times 2^64: the canonical residue of the plain sum
     }
 }
 
@@ -381,7 +381,7 @@ __device__ __forceinline__ void moddown_body(const DeviceTables& t, const KsShap
     u64* dst = conv + (size_t)c * sh.ell * N + n;
     const int t0 = blockIdx.z * sh.tch, t1 = min(sh.ell, t0 + sh.tch);
     for (int tt = t0; tt < t1; ++tt) {
-        const Barrett br = load_barrett(t, tt);
+        const u64 qt = t.moduli[tt], qti = t.qinv[tt];
         u64 slo = 0, shi = 0;
 #pragma unroll
         for (int p0 = 0; p0 < MAXK; p0 += 8) {
@@ -394,7 +394,7 @@ __device__ __forceinline__ void moddown_body(const DeviceTables& t, const KsShap
                 }
             acc30_flush(acc, slo, shi);
         }
-        dst[(size_t)tt * N] = barrett_reduce128(slo, shi, br);
+        dst[(size_t)tt * N] = redc128(slo, shi, qt, qti);   // phatmod holds the constants times 2^64
     }
 }
 
