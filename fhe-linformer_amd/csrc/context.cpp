@@ -371,6 +371,12 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
                 qi[i] = x;
             }
             dt.qinv = upload_table(qi);
+            std::vector<u64> mr(2 * (size_t)nl);
+            for (int i = 0; i < nl; ++i) {
+                mr[2 * i] = mont_r(moduli[i]);
+                mr[2 * i + 1] = h_shoup(mr[2 * i], moduli[i]);
+            }
+            dt.mont = upload_table(mr);
         }
         dt.ninv = upload_table(ninv);
         std::vector<u64> f((size_t)nl * 2 * N), g((size_t)nl * 2 * N);

@@ -45,6 +45,7 @@ struct DeviceTables {
     const u64* moduli;     // [n_limbs]
     const u64* barrett;    // [n_limbs][2]  (r0, r1) of floor(2^128/q)
     const u64* qinv;       // [n_limbs]  q^-1 mod 2^64 (modarith.h redc128)
+    const u64* mont;       // [n_limbs][2]  2^64 mod q and its Shoup companion: what a key copy made for redc128 sums is multiplied by
     const u64* tw_fwd;     // [n_limbs][2N]  (w, w') pairs, bit-reversed powers of psi
     const u64* tw_inv;     // [n_limbs][2N]  same for psi^{-1}
     // the per-thread twiddles of the row pass's last (forward) / first (inverse) four stages, transposed so that one load

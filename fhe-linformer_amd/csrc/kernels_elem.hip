@@ -566,14 +566,17 @@ __global__ __launch_bounds__(256) void automorph_kernel(int log_n, u64* out, con
 
 // the same gather with every word stored pre-split in 30-bit halves (pack30): the merged inner product multiplies key words
 // in halves anyway, so a key copy made for it (EvalKey::d_perm) carries them ready-made
-__global__ __launch_bounds__(256) void automorph_pack30_kernel(int log_n, u64* out, const u64* in, const u32* map) {
+// ... and times 2^64 (mod the vector's limb, v mod n_limbs): the merged inner product finishes its sums with redc128
+__global__ __launch_bounds__(256) void automorph_pack30_kernel(DeviceTables t, u64* out, const u64* in, const u32* map) {
     const int v = blockIdx.y;
-    const size_t n = (size_t)1 << log_n;
+    const int limb = v % t.n_limbs;
+    const u64 q = t.moduli[limb], R = t.mont[2 * limb], Rs = t.mont[2 * limb + 1];
+    const size_t n = (size_t)1 << t.log_n;
     const size_t j = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
     const u32 m0 = map[j], m1 = map[j + 1];
     u64x2 r;
-    r.x = pack30(in[v * n + m0]);
-    r.y = pack30(in[v * n + m1]);
+    r.x = pack30(mul_shoup(in[v * n + m0], R, Rs, q));
+    r.y = pack30(mul_shoup(in[v * n + m1], R, Rs, q));
     reinterpret_cast<u64x2*>(out)[(v * n + j) >> 1] = r;
 }
 
@@ -769,7 +772,7 @@ void launch_automorph(const DeviceTables& t, u64* out, const u64* in, const u32*
 }
 void launch_automorph_pack30(const DeviceTables& t, u64* out, const u64* in, const u32* map, int nvec, hipStream_t s) {
     if (nvec <= 0) return;
-    hipLaunchKernelGGL(automorph_pack30_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t.log_n, out, in, map);
+    hipLaunchKernelGGL(automorph_pack30_kernel, grid2(t.log_n, nvec), dim3(256), 0, s, t, out, in, map);
 }
 void launch_rescale_lift(const DeviceTables& t, u64* lifted, const u64* last, int npoly, int ell, const u64* qlmod_row, hipStream_t s) {
     hipLaunchKernelGGL(rescale_lift_kernel, grid2(t.log_n, npoly * (ell - 1)), dim3(256), 0, s, t, lifted, last, ell - 1, qlmod_row);

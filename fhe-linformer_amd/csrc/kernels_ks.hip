@@ -331,10 +331,13 @@ __global__ __launch_bounds__(256) void ks_inner_multi_kernel(DeviceTables t, KsS
         u64x2 rb, ra;
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc30_flush(acc[q][i], lo[q][i], hi[q][i]);
-        rb.x = barrett_reduce128(lo[q][0], hi[q][0], br);
-        rb.y = barrett_reduce128(lo[q][1], hi[q][1], br);
-        ra.x = barrett_reduce128(lo[q][2], hi[q][2], br);
-        ra.y = barrett_reduce128(lo[q][3], hi[q][3], br);
+        // the keys of this kernel (EvalKey::d_perm, folded keys) are stored times 2^64: the Montgomery reduction returns the canonical residue
+        // of the plain sum at a third of a Barrett reduction's instructions (the folds above keep the factor: they reduce, they do not divide)
+        const u64 qi = t.qinv[limb];
+        rb.x = redc128(lo[q][0], hi[q][0], br.q, qi);
+        rb.y = redc128(lo[q][1], hi[q][1], br.q, qi);
+        ra.x = redc128(lo[q][2], hi[q][2], br.q, qi);
+        ra.y = redc128(lo[q][3], hi[q][3], br.q, qi);
         if (tt < sh.ell) {
             u64x2* O = reinterpret_cast<u64x2*>(accQ + (size_t)(bi + q) * 2 * sh.ell * N);
             O[(size_t)tt * row + n2] = rb;
@@ -479,8 +482,9 @@ __global__ __launch_bounds__(256) void fold_key_kernel(DeviceTables t, u64* __re
     const u32 m0 = map[j], m1 = map[j + 1];
     const u64x2 pv = reinterpret_cast<const u64x2*>(V)[((size_t)limb * N + j) >> 1];
     u64x2 r;
-    r.x = pack30(mul_mod(pv.x, key[v * N + m0], br));
-    r.y = pack30(mul_mod(pv.y, key[v * N + m1], br));
+    const u64 R = t.mont[2 * limb], Rs = t.mont[2 * limb + 1];   // times 2^64, like EvalKey::d_perm: ks_inner_multi ends in redc128
+    r.x = pack30(mul_shoup(mul_mod(pv.x, key[v * N + m0], br), R, Rs, br.q));
+    r.y = pack30(mul_shoup(mul_mod(pv.y, key[v * N + m1], br), R, Rs, br.q));
     reinterpret_cast<u64x2*>(out)[(v * N + j) >> 1] = r;
 }
 
