@@ -455,7 +455,7 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
         lt.ell = ell;
         lt.beta = digits_at(ell);
         const int nt = ell + K;
-        std::vector<u64> hatinv(2 * ell), hatmod((size_t)ell * nt, 0);
+        std::vector<u64> hatinv(2 * ell), hatmod((size_t)ell * nt, 0), hatmod2((size_t)ell * nt, 0);
         std::vector<int> tab((size_t)lt.beta * nt, -1);
         for (int j = 0; j < lt.beta; ++j) {
             const int lo = j * alpha, hi = std::min((j + 1) * alpha, ell);
@@ -467,7 +467,9 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
                 hatinv[2 * i + 1] = h_shoup(inv, qi);
                 for (int t = 0; t < nt; ++t) {
                     u64 mt = t < ell ? chain.q[t] : chain.p[t - ell];
-                    hatmod[(size_t)i * nt + t] = pack30(h_mulmod(prod_mod(dig, i - lo, mt), mont_r(mt), mt));  // times 2^64 mod m_t (redc128); 30-bit halves for mac30
+                    const u64 hr = h_mulmod(prod_mod(dig, i - lo, mt), mont_r(mt), mt);
+                    hatmod[(size_t)i * nt + t] = pack30(hr);  // times 2^64 mod m_t (redc128); 30-bit halves for mac30
+                    hatmod2[(size_t)i * nt + t] = pack30(h_mulmod(hr, mont_r(mt), mt));
                 }
             }
             for (int t = 0; t < nt; ++t) {
@@ -477,6 +479,7 @@ Context::Context(const Params& p_in) : prm(resolve_params(p_in)) {
         }
         lt.up_hatinv = upload_table(hatinv);
         lt.up_hatmod = upload_table(hatmod);
+        lt.up_hatmod_r2 = upload_table(hatmod2);
         lt.ext_limb_tab = upload_table(tab);
         if (ell >= 2 && K >= 1) {   // ModDown + rescale in one conversion: drop B = (p_0..p_{k-1}, q_{ell-1})
             const u64 ql = chain.q[ell - 1];

@@ -117,7 +117,9 @@ struct LevelTables {
     int beta = 0;       // digits present at this level
     // ModUp: per source limb i < ell: (Qhat_i^{-1} mod q_i, shoup); and [ell][ell+k] Qhat_i mod t
     const u64* up_hatinv = nullptr;   // [ell][2]
-    const u64* up_hatmod = nullptr;   // [ell][ell+k]
+    const u64* up_hatmod = nullptr;   // [ell][ell+k]  (Q_j/q_i) mod m_t times 2^64 (the conversion ends in redc128), pre-split (pack30)
+    const u64* up_hatmod_r2 = nullptr;   // the same times 2^128: digits that come out times 2^64, for the inner product over the keys as they are
+                                         // stored (ks_inner: it ends in redc128 too and has no scaled key copy to read)
     const int* ext_limb_tab = nullptr;  // [beta*(ell+k)] limb id for the NTT after ModUp, -1 on own-digit slots
     // ModDown and rescale as ONE basis conversion (kernels_elem.h launch_moddown_rescale_conv; ell >= 2): the dropped basis is
     // B = (p_0..p_{k-1}, q_{ell-1}) with product M = P q_{ell-1}

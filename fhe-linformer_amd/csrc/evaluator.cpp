@@ -172,7 +172,7 @@ void Evaluator::keyswitch_impl(int B, const KsRows* rows, const u64* c_ntt, size
         c_.ntt(ib, true);
     }
     u64* ext = c_.dalloc<u64>((size_t)Bu * lt.beta * nt * N);
-    launch_modup_conv(c_.dt, shu, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod, s);
+    launch_modup_conv(c_.dt, shu, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod_r2, s);   // digits times 2^64: launch_ks_inner ends in redc128
     LimbBatch eb{ext, Bu * lt.beta * nt, lt.ext_limb_tab, 0, 1};
     eb.tab_len = lt.beta * nt;
     eb.lazy_out = true;  // only K7 reads the digits: it takes any residue below 2^60
@@ -996,7 +996,7 @@ std::vector<std::vector<CtPtr>> Evaluator::rotate_many_batch(const std::vector<C
             c_.ntt(ib, true);
         }
         u64* ext = c_.dalloc<u64>((size_t)B * lt.beta * nt * N);
-        launch_modup_conv(c_.dt, up, ext, cc, base + pn, lt.up_hatinv, lt.up_hatmod, s);
+        launch_modup_conv(c_.dt, up, ext, cc, base + pn, lt.up_hatinv, lt.up_hatmod_r2, s);   // digits times 2^64: launch_ks_inner ends in redc128
         LimbBatch eb{ext, B * lt.beta * nt, lt.ext_limb_tab, 0, 1};
         eb.tab_len = lt.beta * nt;
         eb.lazy_out = true;
@@ -1637,7 +1637,7 @@ std::vector<CtPtr> Evaluator::mult_affine_rescale_batch(const std::vector<CtPtr>
             c_.ntt(ib, true);
         }
         u64* ext = c_.dalloc<u64>((size_t)B * lt.beta * nt * N);
-        launch_modup_conv(c_.dt, sh, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod, s);
+        launch_modup_conv(c_.dt, sh, ext, cc, c_ntt, lt.up_hatinv, lt.up_hatmod_r2, s);   // digits times 2^64: launch_ks_inner ends in redc128
         LimbBatch eb{ext, B * lt.beta * nt, lt.ext_limb_tab, 0, 1};
         eb.tab_len = lt.beta * nt;
         eb.lazy_out = true;

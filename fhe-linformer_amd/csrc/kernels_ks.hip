@@ -136,11 +136,16 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
     const u64x2* E = reinterpret_cast<const u64x2*>(ext);
     const u64x2* K = reinterpret_cast<const u64x2*>(evk);
     u64 lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};  // b.x, b.y, a.x, a.y
+    const u64 monR = t.mont[2 * limb], monRs = t.mont[2 * limb + 1];
     for (int j0 = 0; j0 < sh.beta; j0 += 8) {
         Acc30 b0 = {0, 0, 0}, b1 = {0, 0, 0}, a0 = {0, 0, 0}, a1 = {0, 0, 0};
         const int j1 = min(sh.beta, j0 + 8);
         for (int j = j0; j < j1; ++j) {
-            const u64x2 d = j == own ? reinterpret_cast<const u64x2*>(c_ntt)[(size_t)tt * row + n2] : E[((size_t)j * nt + tt) * row + n2];
+            u64x2 d = j == own ? reinterpret_cast<const u64x2*>(c_ntt)[(size_t)tt * row + n2] : E[((size_t)j * nt + tt) * row + n2];
+            if (j == own) {   // the digits of this kernel's ModUp come times 2^64 (LevelTables::up_hatmod_r2); the ciphertext's own limb gets the factor here
+                d.x = mul_shoup(d.x, monR, monRs, br.q);
+                d.y = mul_shoup(d.y, monR, monRs, br.q);
+            }
             const u64x2 kb = K[(size_t)(2 * j) * kstride + (size_t)limb * row + n2];
             const u64x2 ka = K[(size_t)(2 * j + 1) * kstride + (size_t)limb * row + n2];
             u32 dx0, dx1, dy0, dy1, k0, k1;
@@ -161,10 +166,11 @@ __global__ __launch_bounds__(256) void ks_inner_kernel(DeviceTables t, KsShape s
         acc30_flush(a1, lo[3], hi[3]);
     }
     u64x2 rb, ra;
-    rb.x = barrett_reduce128(lo[0], hi[0], br);
-    rb.y = barrett_reduce128(lo[1], hi[1], br);
-    ra.x = barrett_reduce128(lo[2], hi[2], br);
-    ra.y = barrett_reduce128(lo[3], hi[3], br);
+    const u64 qi = t.qinv[limb];       // every term carries 2^64 through its digit: the Montgomery reduction returns the plain sum's residue
+    rb.x = redc128(lo[0], hi[0], br.q, qi);
+    rb.y = redc128(lo[1], hi[1], br.q, qi);
+    ra.x = redc128(lo[2], hi[2], br.q, qi);
+    ra.y = redc128(lo[3], hi[3], br.q, qi);
     if (tt < sh.ell) {
         u64x2* O = reinterpret_cast<u64x2*>(accQ);
         O[(size_t)tt * row + n2] = rb;
